@@ -1,0 +1,385 @@
+"""ctypes binding of oracle/liboracle.so.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product path (sc_gameengine_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+F32P = C.POINTER(C.c_float)
+U32P = C.POINTER(C.c_uint32)
+I32P = C.POINTER(C.c_int32)
+U8P = C.POINTER(C.c_uint8)
+
+
+class CameraState(C.Structure):
+    _fields_ = [("viewProj", C.c_float * 16), ("activeCamera", C.c_uint32), ("aspect", C.c_float)]
+
+
+class Plane(C.Structure):
+    _fields_ = [("n", C.c_float * 3), ("d", C.c_float)]
+
+
+class Frustum(C.Structure):
+    _fields_ = [("planes", Plane * 6), ("valid", C.c_uint8)]
+
+
+class Bounds(C.Structure):
+    _fields_ = [("min", C.c_float * 3), ("max", C.c_float * 3)]
+
+
+class CullingState(C.Structure):
+    _fields_ = [("freezeCulling", C.c_int), ("frustum", Frustum),
+                ("renderablesTotal", C.c_uint32), ("visibleCount", C.c_uint32), ("culledCount", C.c_uint32),
+                ("candidates", U32P), ("candidatesLen", C.c_uint32), ("candidatesCap", C.c_uint32),
+                ("visible", U32P), ("visibleLen", C.c_uint32), ("visibleCap", C.c_uint32),
+                ("culled", U32P), ("culledLen", C.c_uint32), ("culledCap", C.c_uint32),
+                ("visibilityMask", U8P), ("maskLen", C.c_uint32)]
+
+
+class DrawItem(C.Structure):
+    _fields_ = [("entity", C.c_uint32), ("meshId", C.c_uint32), ("materialId", C.c_uint32), ("_pad", C.c_uint32),
+                ("model", C.c_float * 16)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(HERE, "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.orc_mat4_rotation_xyz.argtypes = [C.c_float, C.c_float, C.c_float, F32P]
+    L.orc_mat4_perspective_rh_zo.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, F32P]
+    L.orc_world_new.restype = vp
+    L.orc_world_free.argtypes = [vp]
+    L.orc_entity_create.argtypes = [vp]
+    L.orc_entity_create.restype = C.c_uint32
+    L.orc_entity_destroy.argtypes = [vp, C.c_uint32]
+    L.orc_entity_alive.argtypes = [vp, C.c_uint32]
+    for name in ("orc_add_transform", "orc_get_transform", "orc_add_camera", "orc_add_render_mesh", "orc_add_bounds"):
+        getattr(L, name).argtypes = [vp, C.c_uint32]
+        getattr(L, name).restype = vp
+    L.orc_has_bounds.argtypes = [vp, C.c_uint32]
+    L.orc_has_render_mesh.argtypes = [vp, C.c_uint32]
+    L.orc_transform_count.argtypes = [vp]
+    L.orc_transform_count.restype = C.c_uint32
+    L.orc_transform_dense_entities.argtypes = [vp]
+    L.orc_transform_dense_entities.restype = U32P
+    L.orc_world_build.argtypes = [vp, C.c_uint32, F32P, F32P, F32P, I32P, U8P, U32P, U32P, U8P, F32P, F32P]
+    L.orc_set_local_positions.argtypes = [vp, C.c_uint32, U32P, F32P]
+    L.orc_nudge_roots_x.argtypes = [vp, C.c_float]
+    L.orc_mark_dirty.argtypes = [vp, C.c_uint32, U32P]
+    L.orc_read_world_matrices.argtypes = [vp, F32P]
+    L.orc_read_dirty.argtypes = [vp, U8P]
+    L.orc_read_parents.argtypes = [vp, U32P]
+    L.orc_read_local_scales.argtypes = [vp, F32P]
+    L.orc_jobs_init.argtypes = [C.c_uint32]
+    L.orc_jobs_workers.restype = C.c_uint32
+    L.orc_transform_system.argtypes = [vp]
+    L.orc_camera_system.argtypes = [vp, C.POINTER(CameraState)]
+    L.orc_frustum_from_viewproj.argtypes = [F32P, C.POINTER(Frustum)]
+    L.orc_sphere_in_frustum.argtypes = [C.POINTER(Frustum), F32P, C.c_float]
+    L.orc_world_bounds_sphere.argtypes = [F32P, C.POINTER(Bounds), F32P, F32P]
+    L.orc_culling_state_new.restype = C.POINTER(CullingState)
+    L.orc_culling_state_free.argtypes = [C.POINTER(CullingState)]
+    L.orc_culling_system.argtypes = [vp, C.POINTER(CullingState), F32P]
+    L.orc_render_prep_streaming.argtypes = [vp, C.POINTER(CullingState), C.c_uint32, C.POINTER(DrawItem), C.c_uint32, U32P]
+    L.orc_render_prep_streaming.restype = C.c_uint32
+    L.orc_world_to_sector.argtypes = [C.c_float, C.c_float, C.c_float, I32P, I32P]
+    L.orc_world_aabb.argtypes = [F32P, C.POINTER(Bounds), F32P, F32P]
+    L.orc_read_world_aabbs.argtypes = [vp, F32P, F32P]
+    L.orc_broadphase_bruteforce.argtypes = [C.c_uint32, F32P, F32P, U32P, U32P, U32P, C.c_uint64]
+    L.orc_broadphase_bruteforce.restype = C.c_uint64
+    L.orc_broadphase_grid.argtypes = [C.c_uint32, F32P, F32P, U32P, U32P, C.c_float, U32P, C.c_uint64]
+    L.orc_broadphase_grid.restype = C.c_uint64
+    L.orc_tick.argtypes = [vp, C.POINTER(CameraState), C.POINTER(CullingState)]
+    _LIB = L
+    return L
+
+
+def _f(a):
+    return a.ctypes.data_as(F32P)
+
+
+def _u(a):
+    return a.ctypes.data_as(U32P)
+
+
+def _c32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ---- math wrappers -------------------------------------------------------------------------
+def mat4_mul(a, b):
+    a, b, o = _c32(a), _c32(b), np.zeros(16, np.float32)
+    lib().orc_mat4_mul(_f(a), _f(b), _f(o))
+    return o
+
+
+def mat4_rotation_xyz(rx, ry, rz):
+    o = np.zeros(16, np.float32)
+    lib().orc_mat4_rotation_xyz(float(rx), float(ry), float(rz), _f(o))
+    return o
+
+
+def mat4_trs(pos, rot, scale):
+    p, r, s, o = _c32(pos), _c32(rot), _c32(scale), np.zeros(16, np.float32)
+    lib().orc_mat4_trs(_f(p), _f(r), _f(s), _f(o))
+    return o
+
+
+def mat4_inverse(a):
+    a, o = _c32(a), np.zeros(16, np.float32)
+    lib().orc_mat4_inverse(_f(a), _f(o))
+    return o
+
+
+def mat4_perspective_rh_zo(fov, aspect, zn, zf, flip):
+    o = np.zeros(16, np.float32)
+    lib().orc_mat4_perspective_rh_zo(float(fov), float(aspect), float(zn), float(zf), int(flip), _f(o))
+    return o
+
+
+def frustum_from_viewproj(vp):
+    vp = _c32(vp)
+    fr = Frustum()
+    lib().orc_frustum_from_viewproj(_f(vp), C.byref(fr))
+    planes = np.array([[p.n[0], p.n[1], p.n[2], p.d] for p in fr.planes], np.float32)
+    return planes, int(fr.valid)
+
+
+def world_to_sector(size, x, z):
+    sx, sz = C.c_int32(), C.c_int32()
+    lib().orc_world_to_sector(float(size), float(x), float(z), C.byref(sx), C.byref(sz))
+    return sx.value, sz.value
+
+
+def broadphase_bruteforce(mn, mx, group, mask):
+    mn, mx = _c32(mn), _c32(mx)
+    g, m = np.ascontiguousarray(group, np.uint32), np.ascontiguousarray(mask, np.uint32)
+    n = mn.shape[0]
+    cnt = lib().orc_broadphase_bruteforce(n, _f(mn), _f(mx), _u(g), _u(m), None, 0)
+    out = np.zeros((int(cnt), 2), np.uint32)
+    if cnt:
+        lib().orc_broadphase_bruteforce(n, _f(mn), _f(mx), _u(g), _u(m), _u(out), cnt)
+    return out
+
+
+def broadphase_grid(mn, mx, group, mask, cell):
+    mn, mx = _c32(mn), _c32(mx)
+    g, m = np.ascontiguousarray(group, np.uint32), np.ascontiguousarray(mask, np.uint32)
+    n = mn.shape[0]
+    cnt = lib().orc_broadphase_grid(n, _f(mn), _f(mx), _u(g), _u(m), float(cell), None, 0)
+    out = np.zeros((int(cnt), 2), np.uint32)
+    if cnt:
+        lib().orc_broadphase_grid(n, _f(mn), _f(mx), _u(g), _u(m), float(cell), _u(out), cnt)
+    return out
+
+
+# ---- world wrapper ---------------------------------------------------------------------------
+class TransformView(C.Structure):
+    _fields_ = [("parent", C.c_uint32), ("localPos", C.c_float * 3), ("localRot", C.c_float * 3),
+                ("localScale", C.c_float * 3), ("_pad0", C.c_uint32 * 2), ("worldMatrix", C.c_float * 16),
+                ("dirty", C.c_uint8), ("_pad1", C.c_uint8 * 15)]
+
+
+class CameraView(C.Structure):
+    _fields_ = [("fovY", C.c_float), ("nearZ", C.c_float), ("farZ", C.c_float), ("aspect", C.c_float),
+                ("active", C.c_uint8)]
+
+
+class OracleWorld:
+    """The oracle's reference-faithful ECS world (sparse-set pools, AoS 128-byte Transform)."""
+
+    def __init__(self):
+        self.L = lib()
+        self.w = self.L.orc_world_new()
+        self.cam = CameraState()
+        self.cam.aspect = 16.0 / 9.0
+        self.cull = self.L.orc_culling_state_new()
+
+    def close(self):
+        if self.w:
+            self.L.orc_culling_state_free(self.cull)
+            self.L.orc_world_free(self.w)
+            self.w = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @classmethod
+    def from_arrays(cls, pos, rot, scale, parent, bmin, bmax, has_mesh=None, has_bounds=None,
+                    mesh_id=None, material_id=None):
+        self = cls()
+        n = len(pos)
+        pos, rot, scale, bmin, bmax = map(_c32, (pos, rot, scale, bmin, bmax))
+        parent = np.ascontiguousarray(parent, np.int32)
+        hm = None if has_mesh is None else np.ascontiguousarray(has_mesh, np.uint8)
+        hb = None if has_bounds is None else np.ascontiguousarray(has_bounds, np.uint8)
+        mi = None if mesh_id is None else np.ascontiguousarray(mesh_id, np.uint32)
+        ma = None if material_id is None else np.ascontiguousarray(material_id, np.uint32)
+        ok = self.L.orc_world_build(self.w, n, _f(pos), _f(rot), _f(scale), parent.ctypes.data_as(I32P),
+                                    None if hm is None else hm.ctypes.data_as(U8P),
+                                    None if mi is None else _u(mi), None if ma is None else _u(ma),
+                                    None if hb is None else hb.ctypes.data_as(U8P), _f(bmin), _f(bmax))
+        assert ok
+        return self
+
+    # entity / component access
+    def create(self):
+        return int(self.L.orc_entity_create(self.w))
+
+    def destroy(self, e):
+        return bool(self.L.orc_entity_destroy(self.w, e))
+
+    def alive(self, e):
+        return bool(self.L.orc_entity_alive(self.w, e))
+
+    def add_transform(self, e):
+        return C.cast(self.L.orc_add_transform(self.w, e), C.POINTER(TransformView)).contents
+
+    def get_transform(self, e):
+        p = self.L.orc_get_transform(self.w, e)
+        return C.cast(p, C.POINTER(TransformView)).contents if p else None
+
+    def add_camera(self, e):
+        return C.cast(self.L.orc_add_camera(self.w, e), C.POINTER(CameraView)).contents
+
+    def add_render_mesh(self, e):
+        self.L.orc_add_render_mesh(self.w, e)
+
+    def add_bounds(self, e, mn, mx):
+        b = C.cast(self.L.orc_add_bounds(self.w, e), C.POINTER(Bounds)).contents
+        for k in range(3):
+            b.min[k] = mn[k]
+            b.max[k] = mx[k]
+
+    def add_camera_entity(self, pos, rot, active=True, aspect=16.0 / 9.0):
+        e = self.create()
+        t = self.add_transform(e)
+        for k in range(3):
+            t.localPos[k] = pos[k]
+            t.localRot[k] = rot[k]
+        t.dirty = 1
+        c = self.add_camera(e)
+        c.active = 1 if active else 0
+        self.cam.aspect = aspect
+        return e
+
+    def count(self):
+        return int(self.L.orc_transform_count(self.w))
+
+    def dense_entities(self):
+        n = self.count()
+        p = self.L.orc_transform_dense_entities(self.w)
+        return np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+
+    # mutators
+    def set_local_positions(self, entities, pos):
+        e = np.ascontiguousarray(entities, np.uint32)
+        p = _c32(pos)
+        self.L.orc_set_local_positions(self.w, len(e), _u(e), _f(p))
+
+    def nudge_roots_x(self, dx):
+        self.L.orc_nudge_roots_x(self.w, float(dx))
+
+    def mark_dirty(self, entities):
+        e = np.ascontiguousarray(entities, np.uint32)
+        self.L.orc_mark_dirty(self.w, len(e), _u(e))
+
+    # systems
+    def transform_system(self):
+        self.L.orc_transform_system(self.w)
+
+    def camera_system(self):
+        self.L.orc_camera_system(self.w, C.byref(self.cam))
+        return np.array(self.cam.viewProj[:], np.float32)
+
+    def culling_system(self, view_proj=None, freeze=False):
+        vp = _c32(self.cam.viewProj[:] if view_proj is None else view_proj)
+        self.cull.contents.freezeCulling = 1 if freeze else 0
+        self.L.orc_culling_system(self.w, self.cull, _f(vp))
+        return self.visible()
+
+    def tick(self):
+        self.L.orc_tick(self.w, C.byref(self.cam), self.cull)
+
+    # read-back
+    def _vec(self, ptr, n):
+        return np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+
+    def visible(self):
+        s = self.cull.contents
+        return self._vec(s.visible, s.visibleLen)
+
+    def culled(self):
+        s = self.cull.contents
+        return self._vec(s.culled, s.culledLen)
+
+    def candidates(self):
+        s = self.cull.contents
+        return self._vec(s.candidates, s.candidatesLen)
+
+    def visibility_mask(self):
+        s = self.cull.contents
+        n = s.candidatesLen
+        return np.ctypeslib.as_array(s.visibilityMask, shape=(n,)).copy() if n else np.zeros(0, np.uint8)
+
+    def frustum_planes(self):
+        fr = self.cull.contents.frustum
+        return np.array([[p.n[0], p.n[1], p.n[2], p.d] for p in fr.planes], np.float32)
+
+    def world_matrices(self):
+        n = self.count()
+        out = np.zeros((n, 16), np.float32)
+        self.L.orc_read_world_matrices(self.w, _f(out))
+        return out
+
+    def dirty(self):
+        out = np.zeros(self.count(), np.uint8)
+        self.L.orc_read_dirty(self.w, out.ctypes.data_as(U8P))
+        return out
+
+    def parents(self):
+        out = np.zeros(self.count(), np.uint32)
+        self.L.orc_read_parents(self.w, _u(out))
+        return out
+
+    def local_scales(self):
+        out = np.zeros((self.count(), 3), np.float32)
+        self.L.orc_read_local_scales(self.w, _f(out))
+        return out
+
+    def world_aabbs(self):
+        n = self.count()
+        mn, mx = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        self.L.orc_read_world_aabbs(self.w, _f(mn), _f(mx))
+        return mn, mx
+
+    def draw_items(self, max_draws=0):
+        s = self.cull.contents
+        cap = max(1, s.visibleLen)
+        buf = (DrawItem * cap)()
+        dropped = C.c_uint32()
+        n = self.L.orc_render_prep_streaming(self.w, self.cull, max_draws, buf, cap, C.byref(dropped))
+        ent = np.array([buf[i].entity for i in range(n)], np.uint32)
+        mesh = np.array([buf[i].meshId for i in range(n)], np.uint32)
+        mat = np.array([buf[i].materialId for i in range(n)], np.uint32)
+        model = np.array([buf[i].model[:] for i in range(n)], np.float32).reshape(n, 16)
+        return ent, mesh, mat, model, int(dropped.value)

@@ -1,0 +1,930 @@
+/*
+ * sc_oracle.c -- CPU oracle for the world-tick path.  TEST INFRASTRUCTURE ONLY
+ * (see sc_oracle.h for the pin status of every function).
+ *
+ * Build: gcc -std=c11 -O2 -ffp-contract=off -fno-fast-math -fPIC -shared -pthread
+ * (-ffp-contract=off matters: the reference is /fp:precise, nothing may fuse into FMA).
+ *
+ * Everything here is written from the reference's behaviour, not its text; each block cites
+ * the reference file:line (relative to the reference tree) it follows.
+ */
+#define _GNU_SOURCE
+#include "sc_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * Math -- src/core/src/sc_math.cpp.  Column-major: element(row r, col c) = m[c*4 + r].
+ * ---------------------------------------------------------------------------------------- */
+
+void orc_mat4_identity(float out[16])
+{
+  for (int i = 0; i < 16; ++i) out[i] = 0.0f;
+  out[0] = out[5] = out[10] = out[15] = 1.0f;
+}
+
+/* sc_math.cpp:52-68 (the SSE variant, which is what x64 builds take): every output element is
+ * ((a[0*4+r]*b[c*4+0] + a[1*4+r]*b[c*4+1]) + a[2*4+r]*b[c*4+2]) + a[3*4+r]*b[c*4+3], unfused,
+ * starting from the first product (not from 0.0f as the scalar fallback at :70-83 does). */
+void orc_mat4_mul(const float a[16], const float b[16], float out[16])
+{
+  float r[16];
+  for (int c = 0; c < 4; ++c) {
+    const float* bc = b + c * 4;
+    for (int row = 0; row < 4; ++row) {
+      float acc = a[row] * bc[0];
+      acc = acc + a[4 + row] * bc[1];
+      acc = acc + a[8 + row] * bc[2];
+      acc = acc + a[12 + row] * bc[3];
+      r[c * 4 + row] = acc;
+    }
+  }
+  memcpy(out, r, sizeof r);
+}
+
+/* sc_math.cpp:100-128: three axis matrices from host libm cos/sin, combined as (Rz*Ry)*Rx. */
+void orc_mat4_rotation_xyz(float rx, float ry, float rz, float out[16])
+{
+  const float cx = cosf(rx), sx = sinf(rx);
+  const float cy = cosf(ry), sy = sinf(ry);
+  const float cz = cosf(rz), sz = sinf(rz);
+
+  float mx[16], my[16], mz[16], zy[16];
+  orc_mat4_identity(mx);
+  mx[5] = cx;  mx[6] = sx;  mx[9] = -sx; mx[10] = cx;
+  orc_mat4_identity(my);
+  my[0] = cy;  my[2] = -sy; my[8] = sy;  my[10] = cy;
+  orc_mat4_identity(mz);
+  mz[0] = cz;  mz[1] = sz;  mz[4] = -sz; mz[5] = cz;
+
+  orc_mat4_mul(mz, my, zy);
+  orc_mat4_mul(zy, mx, out);
+}
+
+/* sc_math.cpp:130-142: local = T * (R * S), each a full 4x4 product. */
+void orc_mat4_trs(const float pos[3], const float rot[3], const float scale[3], float out[16])
+{
+  if (!pos || !rot || !scale) { orc_mat4_identity(out); return; }
+  float t[16], r[16], s[16], rs[16];
+  orc_mat4_identity(t);
+  t[12] = pos[0]; t[13] = pos[1]; t[14] = pos[2];
+  orc_mat4_rotation_xyz(rot[0], rot[1], rot[2], r);
+  memset(s, 0, sizeof s);
+  s[0] = scale[0]; s[5] = scale[1]; s[10] = scale[2]; s[15] = 1.0f;
+  orc_mat4_mul(r, s, rs);
+  orc_mat4_mul(t, rs, out);
+}
+
+/* sc_math.cpp:144-207: cofactor inverse.  Each adjugate entry is a left-to-right sum of six
+ * signed triple products (m[i]*m[j])*m[k]; the table below lists, per output slot, the six
+ * (sign,i,j,k) terms in the order the reference adds them (order fixes the fp32 rounding). */
+typedef struct { int8_t s; uint8_t i, j, k; } OrcCofTerm;
+static const struct { uint8_t slot; OrcCofTerm t[6]; } kCofactors[16] = {
+  { 0, {{+1,5,10,15},{-1,5,11,14},{-1,9,6,15},{+1,9,7,14},{+1,13,6,11},{-1,13,7,10}}},
+  { 4, {{-1,4,10,15},{+1,4,11,14},{+1,8,6,15},{-1,8,7,14},{-1,12,6,11},{+1,12,7,10}}},
+  { 8, {{+1,4,9,15},{-1,4,11,13},{-1,8,5,15},{+1,8,7,13},{+1,12,5,11},{-1,12,7,9}}},
+  {12, {{-1,4,9,14},{+1,4,10,13},{+1,8,5,14},{-1,8,6,13},{-1,12,5,10},{+1,12,6,9}}},
+  { 1, {{-1,1,10,15},{+1,1,11,14},{+1,9,2,15},{-1,9,3,14},{-1,13,2,11},{+1,13,3,10}}},
+  { 5, {{+1,0,10,15},{-1,0,11,14},{-1,8,2,15},{+1,8,3,14},{+1,12,2,11},{-1,12,3,10}}},
+  { 9, {{-1,0,9,15},{+1,0,11,13},{+1,8,1,15},{-1,8,3,13},{-1,12,1,11},{+1,12,3,9}}},
+  {13, {{+1,0,9,14},{-1,0,10,13},{-1,8,1,14},{+1,8,2,13},{+1,12,1,10},{-1,12,2,9}}},
+  { 2, {{+1,1,6,15},{-1,1,7,14},{-1,5,2,15},{+1,5,3,14},{+1,13,2,7},{-1,13,3,6}}},
+  { 6, {{-1,0,6,15},{+1,0,7,14},{+1,4,2,15},{-1,4,3,14},{-1,12,2,7},{+1,12,3,6}}},
+  {10, {{+1,0,5,15},{-1,0,7,13},{-1,4,1,15},{+1,4,3,13},{+1,12,1,7},{-1,12,3,5}}},
+  {14, {{-1,0,5,14},{+1,0,6,13},{+1,4,1,14},{-1,4,2,13},{-1,12,1,6},{+1,12,2,5}}},
+  { 3, {{-1,1,6,11},{+1,1,7,10},{+1,5,2,11},{-1,5,3,10},{-1,9,2,7},{+1,9,3,6}}},
+  { 7, {{+1,0,6,11},{-1,0,7,10},{-1,4,2,11},{+1,4,3,10},{+1,8,2,7},{-1,8,3,6}}},
+  {11, {{-1,0,5,11},{+1,0,7,9},{+1,4,1,11},{-1,4,3,9},{-1,8,1,7},{+1,8,3,5}}},
+  {15, {{+1,0,5,10},{-1,0,6,9},{-1,4,1,10},{+1,4,2,9},{+1,8,1,6},{-1,8,2,5}}},
+};
+
+void orc_mat4_inverse(const float a[16], float out[16])
+{
+  float o[16];
+  for (int e = 0; e < 16; ++e) {
+    float acc = 0.0f;
+    for (int q = 0; q < 6; ++q) {
+      const OrcCofTerm t = kCofactors[e].t[q];
+      /* a leading "-m[i]*m[j]*m[k]" is ((-m[i])*m[j])*m[k] == -((m[i]*m[j])*m[k]) exactly, and
+       * "x - y" == "x + (-y)" exactly, so applying the sign to the product is bit-identical. */
+      float p = (a[t.i] * a[t.j]) * a[t.k];
+      if (t.s < 0) p = -p;
+      acc = (q == 0) ? p : acc + p;
+    }
+    o[kCofactors[e].slot] = acc;
+  }
+  float det = a[0] * o[0];
+  det = det + a[1] * o[4];
+  det = det + a[2] * o[8];
+  det = det + a[3] * o[12];
+  if (fabsf(det) <= 1e-6f) { orc_mat4_identity(out); return; }   /* sc_math.h:6 EPSILON, :199 */
+  const float inv_det = 1.0f / det;
+  for (int i = 0; i < 16; ++i) out[i] = o[i] * inv_det;
+}
+
+/* sc_math.cpp:209-232 */
+void orc_mat4_perspective_rh_zo(float fovYRadians, float aspect, float zNear, float zFar,
+                                int flipY, float out[16])
+{
+  const float eps = 1e-6f;
+  if (fovYRadians <= eps || aspect <= eps || zNear <= eps || zFar <= zNear + eps) {
+    orc_mat4_identity(out);
+    return;
+  }
+  memset(out, 0, 16 * sizeof(float));
+  const float f = 1.0f / tanf(fovYRadians * 0.5f);
+  out[0] = f / aspect;
+  out[5] = flipY ? -f : f;
+  out[10] = zFar / (zNear - zFar);
+  out[14] = (zFar * zNear) / (zNear - zFar);
+  out[11] = -1.0f;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ECS storage -- sc_ecs.h:14-34 (Entity), :42-58 + sc_ecs.cpp:11-56 (EntityManager),
+ * sc_ecs.h:199-277 (sparse-set ComponentPool).
+ * ---------------------------------------------------------------------------------------- */
+
+#define ORC_INDEX_MASK 0x00FFFFFFu
+static inline uint32_t ent_index(uint32_t e) { return e & ORC_INDEX_MASK; }
+static inline uint32_t ent_generation(uint32_t e) { return e >> 24; }
+static inline uint32_t ent_make(uint32_t idx, uint32_t gen) { return (gen << 24) | (idx & ORC_INDEX_MASK); }
+
+typedef struct {
+  uint32_t* dense;      /* m_denseEntities */
+  uint8_t*  data;       /* m_data, elem bytes each */
+  uint32_t* sparse;     /* m_sparse: dense index + 1, 0 = absent */
+  uint32_t  size, cap, sparseLen, sparseCap;
+  size_t    elem;
+} OrcPool;
+
+struct OrcWorld {
+  uint32_t* generations; uint32_t genLen, genCap;
+  uint32_t* freeList;    uint32_t freeLen, freeCap;
+  uint32_t  alive;
+  OrcPool transforms, cameras, meshes, bounds;
+};
+
+static void* xrealloc(void* p, size_t n)
+{
+  void* q = realloc(p, n ? n : 1);
+  if (!q) abort();
+  return q;
+}
+
+static void pool_init(OrcPool* p, size_t elem) { memset(p, 0, sizeof *p); p->elem = elem; }
+static void pool_free(OrcPool* p) { free(p->dense); free(p->data); free(p->sparse); }
+
+static int pool_has(const OrcPool* p, uint32_t e)
+{
+  const uint32_t idx = ent_index(e);
+  return idx < p->sparseLen && p->sparse[idx] != 0;
+}
+
+static void* pool_get(OrcPool* p, uint32_t e)
+{
+  const uint32_t idx = ent_index(e);
+  if (idx >= p->sparseLen) return NULL;
+  const uint32_t slot = p->sparse[idx];
+  return slot ? p->data + (size_t)(slot - 1u) * p->elem : NULL;
+}
+
+/* sc_ecs.h:203-218.  Returns the slot; *fresh tells whether it was appended. */
+static void* pool_add(OrcPool* p, uint32_t e, int* fresh)
+{
+  const uint32_t idx = ent_index(e);
+  if (idx >= p->sparseLen) {
+    if (idx + 1u > p->sparseCap) {
+      uint32_t nc = p->sparseCap ? p->sparseCap : 64u;
+      while (nc < idx + 1u) nc *= 2u;
+      p->sparse = xrealloc(p->sparse, (size_t)nc * sizeof(uint32_t));
+      p->sparseCap = nc;
+    }
+    memset(p->sparse + p->sparseLen, 0, (size_t)(idx + 1u - p->sparseLen) * sizeof(uint32_t));
+    p->sparseLen = idx + 1u;
+  }
+  const uint32_t slot = p->sparse[idx];
+  if (slot) { *fresh = 0; return p->data + (size_t)(slot - 1u) * p->elem; }
+  if (p->size == p->cap) {
+    const uint32_t nc = p->cap ? p->cap * 2u : 64u;
+    p->dense = xrealloc(p->dense, (size_t)nc * sizeof(uint32_t));
+    p->data = xrealloc(p->data, (size_t)nc * p->elem);
+    p->cap = nc;
+  }
+  p->dense[p->size] = e;
+  p->sparse[idx] = p->size + 1u;
+  *fresh = 1;
+  return p->data + (size_t)(p->size++) * p->elem;
+}
+
+/* sc_ecs.h:240-262: the last element is swapped into the hole, so dense order changes. */
+static void pool_remove(OrcPool* p, uint32_t e)
+{
+  const uint32_t idx = ent_index(e);
+  if (idx >= p->sparseLen) return;
+  const uint32_t slot = p->sparse[idx];
+  if (!slot) return;
+  const uint32_t di = slot - 1u, last = p->size - 1u;
+  if (di != last) {
+    p->dense[di] = p->dense[last];
+    memcpy(p->data + (size_t)di * p->elem, p->data + (size_t)last * p->elem, p->elem);
+    p->sparse[ent_index(p->dense[di])] = di + 1u;
+  }
+  p->size--;
+  p->sparse[idx] = 0;
+}
+
+OrcWorld* orc_world_new(void)
+{
+  OrcWorld* w = calloc(1, sizeof *w);
+  if (!w) abort();
+  pool_init(&w->transforms, sizeof(OrcTransform));
+  pool_init(&w->cameras, sizeof(OrcCamera));
+  pool_init(&w->meshes, sizeof(OrcRenderMesh));
+  pool_init(&w->bounds, sizeof(OrcBounds));
+  return w;
+}
+
+void orc_world_free(OrcWorld* w)
+{
+  if (!w) return;
+  pool_free(&w->transforms); pool_free(&w->cameras); pool_free(&w->meshes); pool_free(&w->bounds);
+  free(w->generations); free(w->freeList); free(w);
+}
+
+uint32_t orc_entity_create(OrcWorld* w)
+{
+  if (w->freeLen) {
+    const uint32_t idx = w->freeList[--w->freeLen];
+    w->alive++;
+    return ent_make(idx, w->generations[idx]);
+  }
+  if (w->genLen == w->genCap) {
+    w->genCap = w->genCap ? w->genCap * 2u : 64u;
+    w->generations = xrealloc(w->generations, (size_t)w->genCap * sizeof(uint32_t));
+  }
+  const uint32_t idx = w->genLen++;
+  w->generations[idx] = 0;
+  w->alive++;
+  return ent_make(idx, 0);
+}
+
+int orc_entity_alive(const OrcWorld* w, uint32_t e)
+{
+  const uint32_t idx = ent_index(e);
+  return idx < w->genLen && w->generations[idx] == ent_generation(e);
+}
+
+int orc_entity_destroy(OrcWorld* w, uint32_t e)
+{
+  const uint32_t idx = ent_index(e);
+  if (idx >= w->genLen) return 0;
+  const uint32_t gen = w->generations[idx];
+  if (gen != ent_generation(e)) return 0;
+  w->generations[idx] = gen + 1u;     /* kept as a full u32, as the reference does */
+  if (w->freeLen == w->freeCap) {
+    w->freeCap = w->freeCap ? w->freeCap * 2u : 64u;
+    w->freeList = xrealloc(w->freeList, (size_t)w->freeCap * sizeof(uint32_t));
+  }
+  w->freeList[w->freeLen++] = idx;
+  if (w->alive) w->alive--;
+  pool_remove(&w->transforms, e); pool_remove(&w->cameras, e);
+  pool_remove(&w->meshes, e);     pool_remove(&w->bounds, e);
+  return 1;
+}
+
+static void transform_default(OrcTransform* t)
+{
+  memset(t, 0, sizeof *t);
+  t->parent = ORC_INVALID_ENTITY;
+  t->localScale[0] = t->localScale[1] = t->localScale[2] = 1.0f;
+  orc_mat4_identity(t->worldMatrix);
+  t->dirty = 1;
+}
+
+/* World::add<T>(e) assigns T{} even when the component already exists (sc_ecs.h:292-299). */
+OrcTransform* orc_add_transform(OrcWorld* w, uint32_t e)
+{
+  int fresh; OrcTransform* t = pool_add(&w->transforms, e, &fresh);
+  transform_default(t);
+  return t;
+}
+OrcTransform* orc_get_transform(OrcWorld* w, uint32_t e) { return pool_get(&w->transforms, e); }
+
+OrcCamera* orc_add_camera(OrcWorld* w, uint32_t e)
+{
+  int fresh; OrcCamera* c = pool_add(&w->cameras, e, &fresh);
+  memset(c, 0, sizeof *c);
+  c->fovY = 60.0f; c->nearZ = 0.1f; c->farZ = 1000.0f; c->aspect = 16.0f / 9.0f; c->active = 0;
+  return c;
+}
+OrcRenderMesh* orc_add_render_mesh(OrcWorld* w, uint32_t e)
+{
+  int fresh; OrcRenderMesh* m = pool_add(&w->meshes, e, &fresh);
+  m->meshId = 0; m->materialId = 0;
+  return m;
+}
+OrcBounds* orc_add_bounds(OrcWorld* w, uint32_t e)
+{
+  int fresh; OrcBounds* b = pool_add(&w->bounds, e, &fresh);
+  memset(b, 0, sizeof *b);
+  return b;
+}
+int orc_has_bounds(const OrcWorld* w, uint32_t e) { return pool_has(&w->bounds, e); }
+int orc_has_render_mesh(const OrcWorld* w, uint32_t e) { return pool_has(&w->meshes, e); }
+
+uint32_t orc_transform_count(const OrcWorld* w) { return w->transforms.size; }
+const uint32_t* orc_transform_dense_entities(const OrcWorld* w) { return w->transforms.dense; }
+OrcTransform* orc_transform_dense_data(OrcWorld* w) { return (OrcTransform*)w->transforms.data; }
+
+int orc_world_build(OrcWorld* w, uint32_t n,
+                    const float* pos3, const float* rot3, const float* scale3,
+                    const int32_t* parent_index,
+                    const uint8_t* has_mesh, const uint32_t* mesh_id, const uint32_t* material_id,
+                    const uint8_t* has_bounds, const float* bmin3, const float* bmax3)
+{
+  if (w->genLen != 0) return 0;                 /* only on an empty world: entity i == index i */
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t e = orc_entity_create(w);
+    OrcTransform* t = orc_add_transform(w, e);
+    for (int k = 0; k < 3; ++k) {               /* setLocal, sc_ecs.h:78-84 */
+      t->localPos[k] = pos3[3 * i + k];
+      t->localRot[k] = rot3[3 * i + k];
+      t->localScale[k] = scale3[3 * i + k];
+    }
+    t->dirty = 1;
+    if (parent_index && parent_index[i] >= 0) t->parent = ent_make((uint32_t)parent_index[i], 0);
+    if (!has_mesh || has_mesh[i]) {
+      OrcRenderMesh* m = orc_add_render_mesh(w, e);
+      if (mesh_id) m->meshId = mesh_id[i];
+      if (material_id) m->materialId = material_id[i];
+    }
+    if (!has_bounds || has_bounds[i]) {
+      OrcBounds* b = orc_add_bounds(w, e);
+      for (int k = 0; k < 3; ++k) { b->min[k] = bmin3[3 * i + k]; b->max[k] = bmax3[3 * i + k]; }
+    }
+  }
+  return 1;
+}
+
+void orc_set_local_positions(OrcWorld* w, uint32_t n, const uint32_t* entities, const float* pos3)
+{
+  for (uint32_t i = 0; i < n; ++i) {
+    OrcTransform* t = orc_get_transform(w, entities[i]);
+    if (!t) continue;
+    t->localPos[0] = pos3[3 * i]; t->localPos[1] = pos3[3 * i + 1]; t->localPos[2] = pos3[3 * i + 2];
+    t->dirty = 1;                               /* setLocalPosition, sc_ecs.h:92-96 */
+  }
+}
+
+void orc_nudge_roots_x(OrcWorld* w, float dx)
+{
+  OrcTransform* d = (OrcTransform*)w->transforms.data;
+  for (uint32_t i = 0; i < w->transforms.size; ++i) {
+    if (d[i].parent == ORC_INVALID_ENTITY) { d[i].localPos[0] = d[i].localPos[0] + dx; d[i].dirty = 1; }
+  }
+}
+
+void orc_mark_dirty(OrcWorld* w, uint32_t n, const uint32_t* entities)
+{
+  for (uint32_t i = 0; i < n; ++i) {
+    OrcTransform* t = orc_get_transform(w, entities[i]);
+    if (t) t->dirty = 1;
+  }
+}
+
+void orc_read_world_matrices(OrcWorld* w, float* out)
+{
+  const OrcTransform* d = (const OrcTransform*)w->transforms.data;
+  for (uint32_t i = 0; i < w->transforms.size; ++i) memcpy(out + 16u * (size_t)i, d[i].worldMatrix, 64);
+}
+void orc_read_dirty(OrcWorld* w, uint8_t* out)
+{
+  const OrcTransform* d = (const OrcTransform*)w->transforms.data;
+  for (uint32_t i = 0; i < w->transforms.size; ++i) out[i] = d[i].dirty;
+}
+void orc_read_parents(OrcWorld* w, uint32_t* out)
+{
+  const OrcTransform* d = (const OrcTransform*)w->transforms.data;
+  for (uint32_t i = 0; i < w->transforms.size; ++i) out[i] = d[i].parent;
+}
+void orc_read_local_scales(OrcWorld* w, float* out)
+{
+  const OrcTransform* d = (const OrcTransform*)w->transforms.data;
+  for (uint32_t i = 0; i < w->transforms.size; ++i) memcpy(out + 3u * (size_t)i, d[i].localScale, 12);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Job pool -- stand-in for JobSystem::Dispatch(count, groupSize, f) + Wait as CullingSystem
+ * uses it (sc_jobs.h:70-134, sc_jobs.cpp:202-218): ceil(count/groupSize) groups handed to N
+ * worker threads, the waiting caller executes groups too.  The reference's per-worker rings and
+ * stealing are replaced by one shared atomic group cursor (same work split, less queue traffic).
+ * ---------------------------------------------------------------------------------------- */
+
+typedef void (*OrcRangeFn)(uint32_t start, uint32_t end, void* user);
+
+static struct {
+  pthread_t* threads; uint32_t workers; int running;
+  pthread_mutex_t mu; pthread_cond_t cvWork, cvDone;
+  uint64_t epoch;
+  OrcRangeFn fn; void* user; uint32_t count, groupSize, groupCount;
+  atomic_uint cursor; atomic_uint remaining;
+} gJobs = { .mu = PTHREAD_MUTEX_INITIALIZER, .cvWork = PTHREAD_COND_INITIALIZER, .cvDone = PTHREAD_COND_INITIALIZER };
+
+static void jobs_drain(void)
+{
+  for (;;) {
+    const uint32_t g = atomic_fetch_add(&gJobs.cursor, 1u);
+    if (g >= gJobs.groupCount) break;
+    const uint32_t s = g * gJobs.groupSize;
+    const uint32_t e = (s + gJobs.groupSize > gJobs.count) ? gJobs.count : s + gJobs.groupSize;
+    gJobs.fn(s, e, gJobs.user);
+    if (atomic_fetch_sub(&gJobs.remaining, 1u) == 1u) {
+      pthread_mutex_lock(&gJobs.mu);
+      pthread_cond_broadcast(&gJobs.cvDone);
+      pthread_mutex_unlock(&gJobs.mu);
+    }
+  }
+}
+
+static void* jobs_worker(void* arg)
+{
+  (void)arg;
+  uint64_t seen = 0;
+  pthread_mutex_lock(&gJobs.mu);
+  while (gJobs.running) {
+    if (gJobs.epoch == seen) { pthread_cond_wait(&gJobs.cvWork, &gJobs.mu); continue; }
+    seen = gJobs.epoch;
+    pthread_mutex_unlock(&gJobs.mu);
+    jobs_drain();
+    pthread_mutex_lock(&gJobs.mu);
+  }
+  pthread_mutex_unlock(&gJobs.mu);
+  return NULL;
+}
+
+int orc_jobs_init(uint32_t workers)
+{
+  orc_jobs_shutdown();
+  if (workers == 0) return 1;
+  gJobs.threads = calloc(workers, sizeof(pthread_t));
+  gJobs.running = 1; gJobs.epoch = 0; gJobs.groupCount = 0;
+  atomic_store(&gJobs.cursor, 0u); atomic_store(&gJobs.remaining, 0u);
+  for (uint32_t i = 0; i < workers; ++i) {
+    if (pthread_create(&gJobs.threads[i], NULL, jobs_worker, NULL) != 0) { gJobs.workers = i; orc_jobs_shutdown(); return 0; }
+  }
+  gJobs.workers = workers;
+  return 1;
+}
+
+void orc_jobs_shutdown(void)
+{
+  if (!gJobs.threads) { gJobs.workers = 0; return; }
+  pthread_mutex_lock(&gJobs.mu);
+  gJobs.running = 0;
+  pthread_cond_broadcast(&gJobs.cvWork);
+  pthread_mutex_unlock(&gJobs.mu);
+  for (uint32_t i = 0; i < gJobs.workers; ++i) pthread_join(gJobs.threads[i], NULL);
+  free(gJobs.threads); gJobs.threads = NULL; gJobs.workers = 0;
+}
+
+uint32_t orc_jobs_workers(void) { return gJobs.workers; }
+
+static void jobs_dispatch_wait(uint32_t count, uint32_t groupSize, OrcRangeFn fn, void* user)
+{
+  if (count == 0 || groupSize == 0) return;
+  const uint32_t groups = (count + groupSize - 1u) / groupSize;
+  if (gJobs.workers == 0) {
+    for (uint32_t g = 0; g < groups; ++g) {
+      const uint32_t s = g * groupSize, e = (s + groupSize > count) ? count : s + groupSize;
+      fn(s, e, user);
+    }
+    return;
+  }
+  pthread_mutex_lock(&gJobs.mu);
+  gJobs.fn = fn; gJobs.user = user; gJobs.count = count; gJobs.groupSize = groupSize; gJobs.groupCount = groups;
+  atomic_store(&gJobs.remaining, groups);
+  atomic_store(&gJobs.cursor, 0u);
+  gJobs.epoch++;
+  pthread_cond_broadcast(&gJobs.cvWork);
+  pthread_mutex_unlock(&gJobs.mu);
+  jobs_drain();                                   /* Wait(): the caller helps (sc_jobs.cpp:202-218) */
+  pthread_mutex_lock(&gJobs.mu);
+  while (atomic_load(&gJobs.remaining) != 0u) pthread_cond_wait(&gJobs.cvDone, &gJobs.mu);
+  pthread_mutex_unlock(&gJobs.mu);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * TransformSystem -- sc_ecs.cpp:118-211.
+ * Kept structurally faithful on purpose (per-tick entity gather, one growable child list per
+ * entity index allocated every tick, explicit-stack DFS) because this is also the CPU baseline.
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct { uint32_t* p; uint32_t n, cap; } OrcEntVec;
+
+static void entvec_push(OrcEntVec* v, uint32_t e)
+{
+  if (v->n == v->cap) {
+    v->cap = v->cap ? v->cap * 2u : 1u;          /* std::vector doubling from 1 */
+    v->p = xrealloc(v->p, (size_t)v->cap * sizeof(uint32_t));
+  }
+  v->p[v->n++] = e;
+}
+
+void orc_transform_system(OrcWorld* w)
+{
+  OrcPool* tp = &w->transforms;
+  if (tp->size == 0) return;
+
+  /* :122-126 gather in pool dense order */
+  OrcEntVec entities = {0};
+  for (uint32_t i = 0; i < tp->size; ++i) entvec_push(&entities, tp->dense[i]);
+
+  /* :131-137 */
+  uint32_t maxIndex = 0;
+  for (uint32_t i = 0; i < entities.n; ++i) {
+    const uint32_t ix = ent_index(entities.p[i]);
+    if (ix > maxIndex) maxIndex = ix;
+  }
+  OrcEntVec* children = calloc((size_t)maxIndex + 1u, sizeof(OrcEntVec));
+  uint32_t* roots = xrealloc(NULL, (size_t)entities.n * sizeof(uint32_t));
+  uint32_t rootCount = 0;
+  if (!children) abort();
+
+  /* :139-165 */
+  for (uint32_t i = 0; i < entities.n; ++i) {
+    const uint32_t e = entities.p[i];
+    OrcTransform* t = pool_get(tp, e);
+
+    if (t->localScale[0] == 0.0f && t->localScale[1] == 0.0f && t->localScale[2] == 0.0f) {
+      t->localScale[0] = t->localScale[1] = t->localScale[2] = 1.0f;
+      t->dirty = 1;
+    }
+
+    const uint32_t p = t->parent;
+    const int validParent = p != ORC_INVALID_ENTITY && p != e && orc_entity_alive(w, p) && pool_has(tp, p);
+    if (!validParent) {
+      if (p != ORC_INVALID_ENTITY) t->dirty = 1;
+      t->parent = ORC_INVALID_ENTITY;
+      roots[rootCount++] = e;
+    } else {
+      entvec_push(&children[ent_index(p)], e);
+    }
+  }
+
+  /* :167-210 explicit-stack DFS; an entity in a parent cycle has no root above it and is never visited */
+  typedef struct { uint32_t e; uint8_t parentDirty; } Item;
+  Item* stack = xrealloc(NULL, (size_t)entities.n * sizeof(Item));
+  uint32_t sp = 0;
+  for (uint32_t i = 0; i < rootCount; ++i) { stack[sp].e = roots[i]; stack[sp].parentDirty = 0; sp++; }
+
+  while (sp) {
+    const Item it = stack[--sp];
+    OrcTransform* t = pool_get(tp, it.e);
+    const int nodeDirty = t->dirty || it.parentDirty;
+    if (nodeDirty) {
+      float local[16];
+      orc_mat4_trs(t->localPos, t->localRot, t->localScale, local);
+      if (t->parent != ORC_INVALID_ENTITY) {
+        OrcTransform* pt = pool_get(tp, t->parent);
+        if (pt) orc_mat4_mul(pt->worldMatrix, local, t->worldMatrix);
+        else memcpy(t->worldMatrix, local, sizeof local);
+      } else {
+        memcpy(t->worldMatrix, local, sizeof local);
+      }
+      t->dirty = 0;
+    }
+    const uint32_t ix = ent_index(it.e);
+    if (ix <= maxIndex) {
+      const OrcEntVec* ch = &children[ix];
+      for (uint32_t c = 0; c < ch->n; ++c) { stack[sp].e = ch->p[c]; stack[sp].parentDirty = (uint8_t)nodeDirty; sp++; }
+    }
+  }
+
+  for (uint32_t i = 0; i <= maxIndex; ++i) free(children[i].p);
+  free(children); free(roots); free(stack); free(entities.p);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * CameraSystem -- sc_ecs.cpp:213-272.  ForEach<Camera, Transform> is driven by the Camera pool.
+ * ---------------------------------------------------------------------------------------- */
+void orc_camera_system(OrcWorld* w, OrcCameraState* st)
+{
+  if (!st) return;
+  OrcCamera *active = NULL, *fallback = NULL;
+  OrcTransform *activeT = NULL, *fallbackT = NULL;
+  uint32_t activeE = ORC_INVALID_ENTITY, fallbackE = ORC_INVALID_ENTITY;
+
+  for (uint32_t i = 0; i < w->cameras.size; ++i) {
+    const uint32_t e = w->cameras.dense[i];
+    OrcTransform* t = pool_get(&w->transforms, e);
+    if (!t) continue;
+    OrcCamera* c = (OrcCamera*)w->cameras.data + i;
+    if (!fallback) { fallback = c; fallbackT = t; fallbackE = e; }
+    if (!active && c->active) { active = c; activeT = t; activeE = e; }
+  }
+  if (!active && fallback) { active = fallback; activeT = fallbackT; activeE = fallbackE; }
+  if (!active) { orc_mat4_identity(st->viewProj); st->activeCamera = ORC_INVALID_ENTITY; return; }
+
+  active->aspect = (st->aspect > 0.0f) ? st->aspect : active->aspect;
+  const float fovRad = active->fovY * 3.1415926535f / 180.0f;
+  float proj[16], view[16];
+  orc_mat4_perspective_rh_zo(fovRad, active->aspect, active->nearZ, active->farZ, 1, proj);
+  orc_mat4_inverse(activeT->worldMatrix, view);
+  orc_mat4_mul(proj, view, st->viewProj);
+  st->activeCamera = activeE;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Culling -- sc_world_partition.cpp:1071-1144, 1199-1284.
+ * ---------------------------------------------------------------------------------------- */
+
+/* :1071-1103.  Rows of the column-major viewProj; the "near" plane is r3 + r2 (the OpenGL form,
+ * kept although depth is 0..1 -- a reference quirk that must be reproduced). */
+void orc_frustum_from_viewproj(const float m[16], OrcFrustum* out)
+{
+  const float row[4][4] = {
+    { m[0], m[4], m[8],  m[12] },
+    { m[1], m[5], m[9],  m[13] },
+    { m[2], m[6], m[10], m[14] },
+    { m[3], m[7], m[11], m[15] },
+  };
+  memset(out, 0, sizeof *out);
+  for (int p = 0; p < 6; ++p) {
+    const int axis = p >> 1;
+    const int minus = p & 1;           /* 0: r3 + r_axis, 1: r3 - r_axis */
+    float v[4];
+    for (int k = 0; k < 4; ++k) v[k] = minus ? row[3][k] - row[axis][k] : row[3][k] + row[axis][k];
+    const float lenSq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    if (lenSq > 1e-8f) {
+      const float invLen = 1.0f / sqrtf(lenSq);
+      out->planes[p].n[0] = v[0] * invLen;
+      out->planes[p].n[1] = v[1] * invLen;
+      out->planes[p].n[2] = v[2] * invLen;
+      out->planes[p].d = v[3] * invLen;
+    }
+  }
+  out->valid = 1;
+}
+
+/* :1105-1117 */
+int orc_sphere_in_frustum(const OrcFrustum* f, const float c[3], float radius)
+{
+  if (!f->valid) return 1;
+  for (int p = 0; p < 6; ++p) {
+    const OrcPlane* pl = &f->planes[p];
+    const float d = pl->n[0] * c[0] + pl->n[1] * c[1] + pl->n[2] * c[2] + pl->d;
+    if (d < -radius) return 0;
+  }
+  return 1;
+}
+
+/* :1119-1144 */
+void orc_world_bounds_sphere(const float m[16], const OrcBounds* b, float outCenter[3], float* outRadius)
+{
+  const float cx = (b->min[0] + b->max[0]) * 0.5f, cy = (b->min[1] + b->max[1]) * 0.5f, cz = (b->min[2] + b->max[2]) * 0.5f;
+  const float ex = (b->max[0] - b->min[0]) * 0.5f, ey = (b->max[1] - b->min[1]) * 0.5f, ez = (b->max[2] - b->min[2]) * 0.5f;
+  outCenter[0] = m[0] * cx + m[4] * cy + m[8] * cz + m[12];
+  outCenter[1] = m[1] * cx + m[5] * cy + m[9] * cz + m[13];
+  outCenter[2] = m[2] * cx + m[6] * cy + m[10] * cz + m[14];
+  const float sx = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+  const float sy = sqrtf(m[4] * m[4] + m[5] * m[5] + m[6] * m[6]);
+  const float sz = sqrtf(m[8] * m[8] + m[9] * m[9] + m[10] * m[10]);
+  const float syz = (sy < sz) ? sz : sy;          /* std::max(a,b) == (a<b)?b:a */
+  const float maxScale = (sx < syz) ? syz : sx;
+  const float localRadius = sqrtf(ex * ex + ey * ey + ez * ez);
+  *outRadius = localRadius * maxScale;
+}
+
+OrcCullingState* orc_culling_state_new(void) { OrcCullingState* s = calloc(1, sizeof *s); if (!s) abort(); return s; }
+void orc_culling_state_free(OrcCullingState* s)
+{
+  if (!s) return;
+  free(s->candidates); free(s->visible); free(s->culled); free(s->visibilityMask); free(s);
+}
+
+static void u32vec_reserve(uint32_t** p, uint32_t* cap, uint32_t need)
+{
+  if (*cap >= need) return;
+  *p = xrealloc(*p, (size_t)need * sizeof(uint32_t));
+  *cap = need;
+}
+
+typedef struct { OrcWorld* w; OrcCullingState* s; OrcFrustum fr; } CullJob;
+
+static void cull_range(uint32_t start, uint32_t end, void* user)
+{
+  CullJob* j = user;
+  for (uint32_t i = start; i < end; ++i) {                 /* :1242-1269 */
+    const uint32_t e = j->s->candidates[i];
+    const OrcTransform* t = pool_get(&j->w->transforms, e);
+    if (!t) { j->s->visibilityMask[i] = 0; continue; }
+    if (!pool_has(&j->w->bounds, e)) { j->s->visibilityMask[i] = 1; continue; }
+    const OrcBounds* b = pool_get(&j->w->bounds, e);
+    if (!b) { j->s->visibilityMask[i] = 1; continue; }
+    float c[3], r;
+    orc_world_bounds_sphere(t->worldMatrix, b, c, &r);
+    j->s->visibilityMask[i] = orc_sphere_in_frustum(&j->fr, c, r) ? 1u : 0u;
+  }
+}
+
+void orc_culling_system(OrcWorld* w, OrcCullingState* s, const float viewProj[16])
+{
+  if (!s || !viewProj) return;
+
+  /* :1206-1210 candidates = Transform-pool dense order filtered by RenderMesh */
+  s->candidatesLen = 0;
+  u32vec_reserve(&s->candidates, &s->candidatesCap, w->transforms.size);
+  for (uint32_t i = 0; i < w->transforms.size; ++i) {
+    const uint32_t e = w->transforms.dense[i];
+    if (pool_has(&w->meshes, e)) s->candidates[s->candidatesLen++] = e;
+  }
+  const uint32_t total = s->candidatesLen;
+  s->renderablesTotal = total;
+  s->visibleLen = s->culledLen = 0;
+  u32vec_reserve(&s->visible, &s->visibleCap, total);
+  u32vec_reserve(&s->culled, &s->culledCap, total);
+  if (total == 0) { s->visibleCount = s->culledCount = 0; return; }
+
+  if (s->freezeCulling) {                                   /* :1227-1233 */
+    memcpy(s->visible, s->candidates, (size_t)total * sizeof(uint32_t));
+    s->visibleLen = total; s->visibleCount = total; s->culledCount = 0;
+    return;
+  }
+
+  orc_frustum_from_viewproj(viewProj, &s->frustum);
+  if (s->maskLen < total) { s->visibilityMask = xrealloc(s->visibilityMask, total); s->maskLen = total; }
+
+  CullJob job = { w, s, s->frustum };
+  jobs_dispatch_wait(total, 128u, cull_range, &job);        /* :1240-1271 */
+
+  for (uint32_t i = 0; i < total; ++i) {                    /* :1273-1280 serial stable compaction */
+    const uint32_t e = s->candidates[i];
+    if (s->visibilityMask[i]) s->visible[s->visibleLen++] = e;
+    else s->culled[s->culledLen++] = e;
+  }
+  s->visibleCount = s->visibleLen;
+  s->culledCount = s->culledLen;
+}
+
+/* :1286-1359, draw emission only (asset touching / eviction are renderer-side and out of scope). */
+uint32_t orc_render_prep_streaming(OrcWorld* w, const OrcCullingState* s, uint32_t maxDraws,
+                                   OrcDrawItem* out, uint32_t outCap, uint32_t* droppedOut)
+{
+  uint32_t emitted = 0, dropped = 0;
+  for (uint32_t i = 0; i < s->visibleLen; ++i) {
+    const uint32_t e = s->visible[i];
+    const OrcTransform* t = pool_get(&w->transforms, e);
+    const OrcRenderMesh* rm = pool_get(&w->meshes, e);
+    if (!t || !rm) continue;
+    if (maxDraws > 0 && emitted >= maxDraws) { dropped++; continue; }
+    if (emitted < outCap) {
+      OrcDrawItem* d = &out[emitted];
+      d->entity = e; d->meshId = rm->meshId; d->materialId = rm->materialId; d->_pad = 0;
+      memcpy(d->model, t->worldMatrix, 64);
+    }
+    emitted++;
+  }
+  if (droppedOut) *droppedOut = dropped;
+  return emitted;
+}
+
+/* sc_world_partition.cpp:268-275 */
+void orc_world_to_sector(float sectorSize, float x, float z, int32_t* sx, int32_t* sz)
+{
+  const float inv = 1.0f / sectorSize;
+  *sx = (int32_t)floorf(x * inv);
+  *sz = (int32_t)floorf(z * inv);
+}
+
+void orc_tick(OrcWorld* w, OrcCameraState* cam, OrcCullingState* cull)
+{
+  orc_transform_system(w);
+  orc_camera_system(w, cam);
+  orc_culling_system(w, cull, cam->viewProj);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Broadphase -- this build's own spec (the reference hands the job to Bullet 3.25's
+ * btDbvtBroadphase, sc_physics.cpp:218-225, whose source is not in the tree).
+ *   world AABB: centre as computeWorldBoundsSphere's centre; half extent h_r = |M[r,0]|*ex +
+ *   |M[r,1]|*ey + |M[r,2]|*ez; min = c - h, max = c + h (fp32).
+ *   pair (i<j) iff closed intervals overlap on all three axes and Bullet's default filter
+ *   (gi & mj) && (gj & mi) passes (sc_physics.cpp:372-379 group/mask rules).
+ * ---------------------------------------------------------------------------------------- */
+void orc_world_aabb(const float m[16], const OrcBounds* b, float outMin[3], float outMax[3])
+{
+  const float cx = (b->min[0] + b->max[0]) * 0.5f, cy = (b->min[1] + b->max[1]) * 0.5f, cz = (b->min[2] + b->max[2]) * 0.5f;
+  const float ex = (b->max[0] - b->min[0]) * 0.5f, ey = (b->max[1] - b->min[1]) * 0.5f, ez = (b->max[2] - b->min[2]) * 0.5f;
+  for (int r = 0; r < 3; ++r) {
+    const float c = m[r] * cx + m[4 + r] * cy + m[8 + r] * cz + m[12 + r];
+    const float h = fabsf(m[r]) * ex + fabsf(m[4 + r]) * ey + fabsf(m[8 + r]) * ez;
+    outMin[r] = c - h;
+    outMax[r] = c + h;
+  }
+}
+
+void orc_read_world_aabbs(OrcWorld* w, float* min3n, float* max3n)
+{
+  const OrcTransform* d = (const OrcTransform*)w->transforms.data;
+  for (uint32_t i = 0; i < w->transforms.size; ++i) {
+    const OrcBounds* b = pool_get(&w->bounds, w->transforms.dense[i]);
+    if (b) orc_world_aabb(d[i].worldMatrix, b, min3n + 3u * (size_t)i, max3n + 3u * (size_t)i);
+    else for (int k = 0; k < 3; ++k) { min3n[3u * (size_t)i + k] = INFINITY; max3n[3u * (size_t)i + k] = -INFINITY; }
+  }
+}
+
+static inline int aabb_overlap(const float* amin, const float* amax, const float* bmin, const float* bmax)
+{
+  return amin[0] <= bmax[0] && bmin[0] <= amax[0] &&
+         amin[1] <= bmax[1] && bmin[1] <= amax[1] &&
+         amin[2] <= bmax[2] && bmin[2] <= amax[2];
+}
+static inline int filter_pass(uint32_t gi, uint32_t mi, uint32_t gj, uint32_t mj)
+{
+  return (gi & mj) != 0 && (gj & mi) != 0;
+}
+
+uint64_t orc_broadphase_bruteforce(uint32_t n, const float* mn, const float* mx,
+                                   const uint32_t* group, const uint32_t* mask,
+                                   uint32_t* pairs, uint64_t cap)
+{
+  uint64_t count = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t j = i + 1u; j < n; ++j) {
+      if (!aabb_overlap(mn + 3u * (size_t)i, mx + 3u * (size_t)i, mn + 3u * (size_t)j, mx + 3u * (size_t)j)) continue;
+      if (!filter_pass(group[i], mask[i], group[j], mask[j])) continue;
+      if (count < cap) { pairs[2 * count] = i; pairs[2 * count + 1] = j; }
+      count++;
+    }
+  }
+  return count;
+}
+
+typedef struct { uint64_t key; uint32_t obj; } GridEntry;
+static int grid_entry_cmp(const void* a, const void* b)
+{
+  const GridEntry *x = a, *y = b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return (x->obj > y->obj) - (x->obj < y->obj);
+}
+static int u64_cmp(const void* a, const void* b)
+{
+  const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+  return (x > y) - (x < y);
+}
+static inline int32_t cell_of(float v, float inv) { return (int32_t)floorf(v * inv); }   /* worldToSector arithmetic */
+static inline uint64_t cell_key(int32_t cx, int32_t cz) { return ((uint64_t)(uint32_t)cz << 32) | (uint32_t)cx; }
+
+uint64_t orc_broadphase_grid(uint32_t n, const float* mn, const float* mx,
+                             const uint32_t* group, const uint32_t* mask, float cellSize,
+                             uint32_t* pairs, uint64_t cap)
+{
+  const float inv = 1.0f / cellSize;
+  /* every object is entered into each xz cell its AABB touches; a pair is reported only from the
+   * cell holding the low corner of the xz intersection, so no pair is produced twice */
+  size_t entries = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!(mn[3u * (size_t)i] <= mx[3u * (size_t)i])) continue;      /* empty (no Bounds) */
+    const int64_t nx = (int64_t)cell_of(mx[3u * (size_t)i], inv) - cell_of(mn[3u * (size_t)i], inv) + 1;
+    const int64_t nz = (int64_t)cell_of(mx[3u * (size_t)i + 2], inv) - cell_of(mn[3u * (size_t)i + 2], inv) + 1;
+    entries += (size_t)(nx * nz);
+  }
+  GridEntry* g = xrealloc(NULL, entries * sizeof(GridEntry));
+  size_t k = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!(mn[3u * (size_t)i] <= mx[3u * (size_t)i])) continue;
+    const int32_t x0 = cell_of(mn[3u * (size_t)i], inv), x1 = cell_of(mx[3u * (size_t)i], inv);
+    const int32_t z0 = cell_of(mn[3u * (size_t)i + 2], inv), z1 = cell_of(mx[3u * (size_t)i + 2], inv);
+    for (int32_t z = z0; z <= z1; ++z) for (int32_t x = x0; x <= x1; ++x) { g[k].key = cell_key(x, z); g[k].obj = i; k++; }
+  }
+  qsort(g, entries, sizeof(GridEntry), grid_entry_cmp);
+
+  uint64_t* found = NULL; size_t foundLen = 0, foundCap = 0;
+  for (size_t s = 0; s < entries;) {
+    size_t e = s;
+    while (e < entries && g[e].key == g[s].key) e++;
+    const int32_t ccx = (int32_t)(uint32_t)(g[s].key & 0xFFFFFFFFu), ccz = (int32_t)(uint32_t)(g[s].key >> 32);
+    for (size_t a = s; a < e; ++a) for (size_t b = a + 1; b < e; ++b) {
+      const uint32_t i = g[a].obj, j = g[b].obj;          /* i < j by the sort */
+      const float* imn = mn + 3u * (size_t)i; const float* imx = mx + 3u * (size_t)i;
+      const float* jmn = mn + 3u * (size_t)j; const float* jmx = mx + 3u * (size_t)j;
+      if (!aabb_overlap(imn, imx, jmn, jmx)) continue;
+      const float lx = imn[0] > jmn[0] ? imn[0] : jmn[0], lz = imn[2] > jmn[2] ? imn[2] : jmn[2];
+      if (cell_of(lx, inv) != ccx || cell_of(lz, inv) != ccz) continue;
+      if (!filter_pass(group[i], mask[i], group[j], mask[j])) continue;
+      if (foundLen == foundCap) { foundCap = foundCap ? foundCap * 2 : 1024; found = xrealloc(found, foundCap * sizeof(uint64_t)); }
+      found[foundLen++] = ((uint64_t)i << 32) | j;
+    }
+    s = e;
+  }
+  free(g);
+  qsort(found, foundLen, sizeof(uint64_t), u64_cmp);
+  for (size_t q = 0; q < foundLen && q < cap; ++q) { pairs[2 * q] = (uint32_t)(found[q] >> 32); pairs[2 * q + 1] = (uint32_t)found[q]; }
+  free(found);
+  return foundLen;
+}
