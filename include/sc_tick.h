@@ -1,0 +1,193 @@
+/*
+ * sc_tick.h -- C ABI of the MI355X world-tick library (libsc_tick.so).
+ *
+ * One context owns the device-resident SoA state of one world tile on one GPU and runs the
+ * RenderPrep hot path of SandboxCityEngine on it:
+ *
+ *   TransformSystem            src/core/src/sc_ecs.cpp:118-211
+ *   (CameraSystem stays on the host: sc_ecs.cpp:213-272; its product, viewProj, is an input here)
+ *   CullingSystem              src/engine/world/sc_world_partition.cpp:1199-1284
+ *   RenderPrepStreamingSystem  src/engine/world/sc_world_partition.cpp:1286-1359 (draw emission)
+ *   AABB broadphase            Bullet btDbvtBroadphase behind src/engine/physics/sc_physics.cpp:218-225, :289, :296-299
+ *
+ * The reference has no FFI on this path: systems are C++ functions `void(World&, float, void*)`
+ * (src/core/include/sc_scheduler.h:38).  This ABI is what the C++ adapter systems in
+ * sc_gameengine_amd/host/sc_tick_systems.cpp (same signature, same state structs) call; a cgo /
+ * JNI / ctypes binding would bind exactly these symbols.  Conventions follow the reference's own
+ * C ABI, src/engine/include/sc_engine_render.h:130-163 and src/engine/src/sc_engine_render.cpp:88-177:
+ * extern "C", opaque context from paired create/destroy, `int` 1 = ok / 0 = failed, every entry
+ * point tolerates NULL, POD structs with fixed-size arrays, the caller owns every buffer it passes
+ * and the callee copies, and a GetApiVersion().
+ *
+ * Entities are addressed by their DENSE index in the Transform pool (ComponentPool<Transform>::
+ * denseEntities order, src/core/include/sc_ecs.h:199-277): that order defines the order of the
+ * candidate / visible / culled lists (sc_world_partition.cpp:1206-1210, :1273-1280).
+ *
+ * Threading: a context may be used from any thread, one call at a time (systems may run on any job
+ * worker: src/core/src/sc_scheduler.cpp:117-126); every call binds the device itself.
+ * All device work is queued on the context's own stream; calls that return data synchronise it.
+ */
+#ifndef SC_TICK_H
+#define SC_TICK_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_TICK_API_VERSION 1u
+#define SC_TICK_MAX_ENTITIES (1u << 24)        /* Entity::INDEX_BITS, sc_ecs.h:18-20 */
+#define SC_TICK_NO_PARENT (-1)
+
+typedef struct ScTickContext ScTickContext;
+
+/* scTickRun flags: which stages of the tick to execute */
+enum {
+  SC_TICK_XFORM       = 1u << 0,   /* TransformSystem */
+  SC_TICK_CULL        = 1u << 1,   /* CullingSystem: visibility bits + ordered visible list */
+  SC_TICK_BROADPHASE  = 1u << 2,   /* world AABBs + grid pair search */
+  SC_TICK_CULLED_LIST = 1u << 3,   /* also build CullingState::culled */
+  SC_TICK_DRAWS       = 1u << 4,   /* RenderPrepStreamingSystem draw list from the visible list */
+  SC_TICK_FULL        = SC_TICK_XFORM | SC_TICK_CULL | SC_TICK_BROADPHASE
+};
+
+typedef struct ScTickContextDesc
+{
+  int32_t  device_ordinal;     /* HIP device */
+  uint32_t capacity;           /* max entities in this context, <= SC_TICK_MAX_ENTITIES */
+  /* broadphase grid: the rectangle of sectors this context's tile covers, in worldToSector
+   * coordinates (sc_world_partition.cpp:268-275).  sectors_x == 0 disables the broadphase. */
+  int32_t  tile_origin_x;
+  int32_t  tile_origin_z;
+  uint32_t tile_sectors_x;
+  uint32_t tile_sectors_z;
+  float    sector_size;        /* WorldPartitionConfig::sectorSizeMeters, 64 m (sc_world_partition.h:151) */
+  uint32_t max_pairs;          /* capacity of the pair list (0 = capacity entities * 4) */
+  uint32_t max_draws_budget;   /* WorldStreamingBudgets::maxDrawsBudget (sc_world_partition.h:309); 0 = unlimited */
+  uint32_t reserved;
+} ScTickContextDesc;
+
+typedef struct ScTickCounts    /* CullingStats (sc_world_partition.h:334-339) + pair / draw counts */
+{
+  uint32_t entities;
+  uint32_t renderables_total;
+  uint32_t visible;
+  uint32_t culled;
+  uint32_t pairs;              /* pairs found (may exceed the pair capacity; the list is then truncated) */
+  uint32_t pairs_truncated;    /* 1 if pairs > capacity */
+  uint32_t draws_emitted;      /* RenderPrepStats (sc_world_partition.h:353-357) */
+  uint32_t draws_dropped;
+  uint32_t max_depth;          /* deepest hierarchy level after scTickSetTopology */
+  uint32_t unreachable;        /* entities in or below a parent cycle (never updated, sc_ecs.cpp:173-210) */
+  uint32_t bin_overflow;       /* broadphase entities that did not fit a sector bin and took the slow list */
+  uint32_t reserved;
+} ScTickCounts;
+
+typedef struct ScTickDrawItem  /* DrawItem, sc_ecs.h:159-165: 80 bytes, model at offset 16, column-major */
+{
+  uint32_t dense_index;        /* the host adapter maps it to the Entity handle */
+  uint32_t mesh_id;
+  uint32_t material_id;
+  uint32_t pad;
+  float    model[16];
+} ScTickDrawItem;
+
+/* kernels whose per-launch durations scTickGetKernelTimes reports */
+enum { SC_TICK_K_XFORM_CULL = 0, SC_TICK_K_COMPACT = 1, SC_TICK_K_PAIRS = 2, SC_TICK_K_NUDGE = 3, SC_TICK_K_COUNT = 4 };
+
+uint32_t       scTickGetApiVersion(void);
+ScTickContext* scTickCreateContext(const ScTickContextDesc* desc);
+void           scTickDestroyContext(ScTickContext* ctx);
+/* text of the last failure on this context (or of the last failed create when ctx is NULL) */
+const char*    scTickGetLastError(const ScTickContext* ctx);
+
+/* ---- entity state upload (host -> device SoA).  [first, first+count) are dense indices. ---- */
+int scTickSetEntityCount(ScTickContext* ctx, uint32_t count);
+/* setLocal (sc_ecs.h:78-84): position, XYZ Euler radians, scale; marks the range dirty.  sin/cos of
+ * the angles are taken here with the host libm, as mat4_rotation_xyz does (sc_math.cpp:102-107), so
+ * device matrices equal the host's bit for bit.  An all-zero scale is stored as (1,1,1), the repair
+ * TransformSystem applies (sc_ecs.cpp:143-149); repaired[i] (nullable) reports it. */
+int scTickUploadLocals(ScTickContext* ctx, uint32_t first, uint32_t count,
+                       const float* pos3, const float* rot3, const float* scale3, uint8_t* repaired);
+/* setLocalPosition (sc_ecs.h:92-96) */
+int scTickUploadPositions(ScTickContext* ctx, uint32_t first, uint32_t count, const float* pos3);
+/* Bounds::localAabb (sc_world_partition.h:298-301); has_bounds NULL = every entity has one */
+int scTickUploadBounds(ScTickContext* ctx, uint32_t first, uint32_t count,
+                       const float* min3, const float* max3, const uint8_t* has_bounds);
+/* RenderMesh (sc_ecs.h:107-111); has_mesh NULL = every entity is a culling candidate */
+int scTickUploadRenderMeshes(ScTickContext* ctx, uint32_t first, uint32_t count,
+                             const uint8_t* has_mesh, const uint32_t* mesh_id, const uint32_t* material_id);
+/* collision filter group / mask (sc_physics.cpp:372-379); low 16 bits are kept, 0xFFFFFFFF = all */
+int scTickUploadLayers(ScTickContext* ctx, uint32_t first, uint32_t count,
+                       const uint32_t* group, const uint32_t* mask);
+/* Transform::parent for every entity as a dense index (SC_TICK_NO_PARENT = root).  A parent that is
+ * out of range or the entity itself is detached and the entity marked dirty (sc_ecs.cpp:151-160).
+ * Computes hierarchy depth; entities in or below a parent cycle are flagged unreachable. */
+int scTickSetTopology(ScTickContext* ctx, const int32_t* parent_dense_index, uint32_t count);
+/* markDirty (sc_ecs.h:73-76) */
+int scTickMarkDirty(ScTickContext* ctx, uint32_t first, uint32_t count);
+int scTickMarkDirtyIndices(ScTickContext* ctx, const uint32_t* dense_indices, uint32_t count);
+/* seed Transform::worldMatrix (column-major Mat4, must be affine: row 3 == 0,0,0,1) */
+int scTickUploadWorldMatrices(ScTickContext* ctx, uint32_t first, uint32_t count, const float* mat16);
+
+/* ---- per-frame inputs ---- */
+/* RenderFrameData::viewProj (sc_ecs.h:167-173); the six planes are derived as frustumFromViewProj
+ * does (sc_world_partition.cpp:1071-1103) */
+int scTickSetViewProj(ScTickContext* ctx, const float view_proj[16]);
+/* or the planes directly: 6 x (nx, ny, nz, d), and Frustum::valid */
+int scTickSetFrustumPlanes(ScTickContext* ctx, const float planes24[24], int valid);
+int scTickGetFrustumPlanes(ScTickContext* ctx, float planes24[24], int* valid);
+/* CullingState::freezeCulling (sc_world_partition.cpp:1227-1233) */
+int scTickSetFreezeCulling(ScTickContext* ctx, int freeze);
+
+/* ---- the tick ---- */
+int scTickRun(ScTickContext* ctx, uint32_t flags);       /* queues the stages; returns at once */
+int scTickSynchronize(ScTickContext* ctx);
+/* upstream producer of SynthWorld's dirty regime (ii): localPos.x += dx on every root, marked dirty
+ * (the device-side analogue of PhysicsSyncSystem's transform writes, sc_physics.cpp:1167-1186) */
+int scTickNudgeRootsX(ScTickContext* ctx, float dx);
+
+/* ---- results (each synchronises the stream) ---- */
+int scTickGetCounts(ScTickContext* ctx, ScTickCounts* out);
+int scTickReadVisible(ScTickContext* ctx, uint32_t* dense_indices, uint32_t capacity, uint32_t* count);
+int scTickReadCulled(ScTickContext* ctx, uint32_t* dense_indices, uint32_t capacity, uint32_t* count);
+/* one bit per dense index, bit i of word i/64; set = visible candidate */
+int scTickReadVisibilityBits(ScTickContext* ctx, uint64_t* words, uint32_t word_capacity);
+int scTickReadWorldMatrices(ScTickContext* ctx, uint32_t first, uint32_t count, float* mat16);
+int scTickReadWorldMatricesIndexed(ScTickContext* ctx, const uint32_t* dense_indices, uint32_t count, float* mat16);
+int scTickReadDirty(ScTickContext* ctx, uint32_t first, uint32_t count, uint8_t* dirty);
+int scTickReadPositions(ScTickContext* ctx, uint32_t first, uint32_t count, float* pos3);
+int scTickReadWorldAabbs(ScTickContext* ctx, uint32_t first, uint32_t count, float* min3, float* max3);
+/* pairs (a, b) of dense indices, a < b, unordered list */
+int scTickReadPairs(ScTickContext* ctx, uint32_t* pairs2, uint32_t capacity, uint32_t* count);
+int scTickReadDraws(ScTickContext* ctx, ScTickDrawItem* items, uint32_t capacity, uint32_t* count);
+
+/* ---- host-side helpers (no GPU work) ----
+ * CameraSystem stays on the host (O(#cameras), sc_ecs.cpp:213-272).  These restate the four sc_math
+ * functions it and the editor use (sc_math.h:31-58) with the reference's libm calls and operation
+ * order, for callers that do not link the engine's own sc_math.  Column-major Mat4, m[c*4+r]. */
+int scTickHostMat4Mul(const float a[16], const float b[16], float out[16]);                        /* sc_math.cpp:11-85 */
+int scTickHostMat4Trs(const float pos[3], const float rot[3], const float scale[3], float out[16]); /* :130-142 */
+int scTickHostMat4Inverse(const float a[16], float out[16]);                                        /* :144-207 */
+int scTickHostMat4PerspectiveRhZo(float fov_y_radians, float aspect, float z_near, float z_far,
+                                  int flip_y, float out[16]);                                       /* :209-232 */
+/* viewProj = perspective(fovY*pi/180, aspect, near, far, flipY) * inverse(cameraWorld), sc_ecs.cpp:261-270 */
+int scTickHostCameraViewProj(const float camera_world[16], float fov_y_degrees, float aspect,
+                             float z_near, float z_far, float out_view_proj[16]);
+
+/* ---- measurement ---- */
+/* record HIP events around every kernel launch (on the context's stream) from now on / stop */
+int scTickSetProfiling(ScTickContext* ctx, int enable);
+/* durations (ms) of the launches of `kernel` recorded since profiling was enabled; synchronises */
+int scTickGetKernelTimes(ScTickContext* ctx, uint32_t kernel, float* ms, uint32_t capacity, uint32_t* count);
+/* capture the current stage sequence into a hipGraph and replay it on scTickRun (0 = eager launches) */
+int scTickSetGraphMode(ScTickContext* ctx, int enable);
+/* native stream handle (hipStream_t) for callers that order their own work against the tick */
+void* scTickGetStream(ScTickContext* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SC_TICK_H */

@@ -886,18 +886,24 @@ uint64_t orc_broadphase_grid(uint32_t n, const float* mn, const float* mx,
 {
   const float inv = 1.0f / cellSize;
   /* every object is entered into each xz cell its AABB touches; a pair is reported only from the
-   * cell holding the low corner of the xz intersection, so no pair is produced twice */
+   * cell holding the low corner of the xz intersection, so no pair is produced twice.  A box that
+   * would cover more than kBigCells cells is kept out of the grid and tested against everything. */
+  const int64_t kBigCells = 4096;
+  uint8_t* big = calloc(n ? n : 1, 1);
   size_t entries = 0;
   for (uint32_t i = 0; i < n; ++i) {
     if (!(mn[3u * (size_t)i] <= mx[3u * (size_t)i])) continue;      /* empty (no Bounds) */
+    const float wx = (mx[3u * (size_t)i] - mn[3u * (size_t)i]) * inv, wz = (mx[3u * (size_t)i + 2] - mn[3u * (size_t)i + 2]) * inv;
+    if (!(wx < 60.0f && wz < 60.0f)) { big[i] = 1; continue; }
     const int64_t nx = (int64_t)cell_of(mx[3u * (size_t)i], inv) - cell_of(mn[3u * (size_t)i], inv) + 1;
     const int64_t nz = (int64_t)cell_of(mx[3u * (size_t)i + 2], inv) - cell_of(mn[3u * (size_t)i + 2], inv) + 1;
+    if (nx * nz > kBigCells) { big[i] = 1; continue; }
     entries += (size_t)(nx * nz);
   }
   GridEntry* g = xrealloc(NULL, entries * sizeof(GridEntry));
   size_t k = 0;
   for (uint32_t i = 0; i < n; ++i) {
-    if (!(mn[3u * (size_t)i] <= mx[3u * (size_t)i])) continue;
+    if (big[i] || !(mn[3u * (size_t)i] <= mx[3u * (size_t)i])) continue;
     const int32_t x0 = cell_of(mn[3u * (size_t)i], inv), x1 = cell_of(mx[3u * (size_t)i], inv);
     const int32_t z0 = cell_of(mn[3u * (size_t)i + 2], inv), z1 = cell_of(mx[3u * (size_t)i + 2], inv);
     for (int32_t z = z0; z <= z1; ++z) for (int32_t x = x0; x <= x1; ++x) { g[k].key = cell_key(x, z); g[k].obj = i; k++; }
@@ -923,6 +929,18 @@ uint64_t orc_broadphase_grid(uint32_t n, const float* mn, const float* mx,
     s = e;
   }
   free(g);
+  for (uint32_t b = 0; b < n; ++b) {                       /* oversized boxes: against everything, once */
+    if (!big[b]) continue;
+    for (uint32_t j = 0; j < n; ++j) {
+      if (j == b || (big[j] && j < b)) continue;
+      const uint32_t lo = b < j ? b : j, hi = b < j ? j : b;
+      if (!aabb_overlap(mn + 3u * (size_t)lo, mx + 3u * (size_t)lo, mn + 3u * (size_t)hi, mx + 3u * (size_t)hi)) continue;
+      if (!filter_pass(group[lo], mask[lo], group[hi], mask[hi])) continue;
+      if (foundLen == foundCap) { foundCap = foundCap ? foundCap * 2 : 1024; found = xrealloc(found, foundCap * sizeof(uint64_t)); }
+      found[foundLen++] = ((uint64_t)lo << 32) | hi;
+    }
+  }
+  free(big);
   qsort(found, foundLen, sizeof(uint64_t), u64_cmp);
   for (size_t q = 0; q < foundLen && q < cap; ++q) { pairs[2 * q] = (uint32_t)(found[q] >> 32); pairs[2 * q + 1] = (uint32_t)found[q]; }
   free(found);

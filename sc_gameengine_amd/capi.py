@@ -1,0 +1,113 @@
+"""ctypes binding of libsc_tick.so -- exactly the symbols include/sc_tick.h declares.
+
+There is no CPU fallback: if the HIP library is missing or no AMD GPU is present, loading or
+context creation raises.  Nothing in this package imports oracle/.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsc_tick.so")
+
+# scTickRun flags (include/sc_tick.h)
+XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS = 1, 2, 4, 8, 16
+FULL = XFORM | CULL | BROADPHASE
+K_XFORM_CULL, K_COMPACT, K_PAIRS, K_NUDGE, K_COUNT = 0, 1, 2, 3, 4
+NO_PARENT = -1
+HAVE_PAIR_SEARCH = False      # flipped when the broadphase pair kernels are in the library
+
+F32P = C.POINTER(C.c_float)
+U32P = C.POINTER(C.c_uint32)
+I32P = C.POINTER(C.c_int32)
+U8P = C.POINTER(C.c_uint8)
+U64P = C.POINTER(C.c_uint64)
+
+
+class ContextDesc(C.Structure):
+    _fields_ = [("device_ordinal", C.c_int32), ("capacity", C.c_uint32),
+                ("tile_origin_x", C.c_int32), ("tile_origin_z", C.c_int32),
+                ("tile_sectors_x", C.c_uint32), ("tile_sectors_z", C.c_uint32),
+                ("sector_size", C.c_float), ("max_pairs", C.c_uint32),
+                ("max_draws_budget", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Counts(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "entities", "renderables_total", "visible", "culled", "pairs", "pairs_truncated",
+        "draws_emitted", "draws_dropped", "max_depth", "unreachable", "bin_overflow", "reserved")]
+
+
+class DrawItem(C.Structure):
+    _fields_ = [("dense_index", C.c_uint32), ("mesh_id", C.c_uint32), ("material_id", C.c_uint32),
+                ("pad", C.c_uint32), ("model", C.c_float * 16)]
+
+
+# every symbol of include/sc_tick.h: name -> (restype, argtypes)
+_CTX = C.c_void_p
+SYMBOLS = {
+    "scTickGetApiVersion": (C.c_uint32, []),
+    "scTickCreateContext": (_CTX, [C.POINTER(ContextDesc)]),
+    "scTickDestroyContext": (None, [_CTX]),
+    "scTickGetLastError": (C.c_char_p, [_CTX]),
+    "scTickSetEntityCount": (C.c_int, [_CTX, C.c_uint32]),
+    "scTickUploadLocals": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P, F32P, F32P, U8P]),
+    "scTickUploadPositions": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
+    "scTickUploadBounds": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P, F32P, U8P]),
+    "scTickUploadRenderMeshes": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P, U32P, U32P]),
+    "scTickUploadLayers": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U32P, U32P]),
+    "scTickSetTopology": (C.c_int, [_CTX, I32P, C.c_uint32]),
+    "scTickMarkDirty": (C.c_int, [_CTX, C.c_uint32, C.c_uint32]),
+    "scTickMarkDirtyIndices": (C.c_int, [_CTX, U32P, C.c_uint32]),
+    "scTickUploadWorldMatrices": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
+    "scTickSetViewProj": (C.c_int, [_CTX, F32P]),
+    "scTickSetFrustumPlanes": (C.c_int, [_CTX, F32P, C.c_int]),
+    "scTickGetFrustumPlanes": (C.c_int, [_CTX, F32P, C.POINTER(C.c_int)]),
+    "scTickSetFreezeCulling": (C.c_int, [_CTX, C.c_int]),
+    "scTickRun": (C.c_int, [_CTX, C.c_uint32]),
+    "scTickSynchronize": (C.c_int, [_CTX]),
+    "scTickNudgeRootsX": (C.c_int, [_CTX, C.c_float]),
+    "scTickGetCounts": (C.c_int, [_CTX, C.POINTER(Counts)]),
+    "scTickReadVisible": (C.c_int, [_CTX, U32P, C.c_uint32, U32P]),
+    "scTickReadCulled": (C.c_int, [_CTX, U32P, C.c_uint32, U32P]),
+    "scTickReadVisibilityBits": (C.c_int, [_CTX, U64P, C.c_uint32]),
+    "scTickReadWorldMatrices": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
+    "scTickReadWorldMatricesIndexed": (C.c_int, [_CTX, U32P, C.c_uint32, F32P]),
+    "scTickReadDirty": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P]),
+    "scTickReadPositions": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
+    "scTickReadWorldAabbs": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P, F32P]),
+    "scTickReadPairs": (C.c_int, [_CTX, U32P, C.c_uint32, U32P]),
+    "scTickReadDraws": (C.c_int, [_CTX, C.POINTER(DrawItem), C.c_uint32, U32P]),
+    "scTickSetProfiling": (C.c_int, [_CTX, C.c_int]),
+    "scTickGetKernelTimes": (C.c_int, [_CTX, C.c_uint32, F32P, C.c_uint32, U32P]),
+    "scTickSetGraphMode": (C.c_int, [_CTX, C.c_int]),
+    "scTickGetStream": (C.c_void_p, [_CTX]),
+    "scTickHostMat4Mul": (C.c_int, [F32P, F32P, F32P]),
+    "scTickHostMat4Trs": (C.c_int, [F32P, F32P, F32P, F32P]),
+    "scTickHostMat4Inverse": (C.c_int, [F32P, F32P]),
+    "scTickHostMat4PerspectiveRhZo": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, F32P]),
+    "scTickHostCameraViewProj": (C.c_int, [F32P, C.c_float, C.c_float, C.c_float, C.c_float, F32P]),
+}
+
+_LIB = None
+
+
+class ScTickError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsc_tick.so and bind every declared symbol.  Raises if the library is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ScTickError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C sc_gameengine_amd/csrc).  There is no CPU fallback for the tick path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib

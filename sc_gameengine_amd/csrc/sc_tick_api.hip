@@ -1,0 +1,806 @@
+// sc_tick_api.hip -- implementation of the C ABI in include/sc_tick.h (host side of libsc_tick.so).
+//
+// Host code here is compiled with -ffp-contract=off as well: the frustum planes and the sin/cos of
+// the Euler angles are produced on the host with the same libm calls and the same operation order
+// as the reference (sc_world_partition.cpp:1071-1103, sc_math.cpp:102-107).
+#include "../../include/sc_tick.h"
+#include "sc_tick_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace sctick;
+
+namespace {
+
+thread_local std::string gCreateError;
+
+struct EventPair { hipEvent_t a = nullptr, b = nullptr; };
+
+} // namespace
+
+struct ScTickContext
+{
+  ScTickContextDesc desc{};
+  int device = 0;
+  uint32_t cap = 0;          // padded capacity
+  uint32_t n = 0;
+  hipStream_t stream = nullptr;
+  DeviceState d{};
+  std::vector<void*> allocs;
+  std::string err;
+
+  // host mirrors needed to (re)build link words
+  std::vector<int32_t> hParent;
+  std::vector<uint8_t> hFlags;       // bit0 has mesh, bit1 has bounds
+  bool linksStale = true;
+  uint32_t maxDepth = 0, unreachable = 0;
+  std::vector<uint32_t> levelOffsets;   // offsets into dLevelList for depth kMaxChain+1, +2, ...
+  uint32_t* dLevelList = nullptr;
+  uint32_t levelListCap = 0;
+
+  Frustum6 frustum{};
+  int frustumValid = 0;
+  int freeze = 0;
+
+  uint32_t spansWanted = 2048;
+  uint32_t lastFlags = 0;
+
+  // scratch device buffers for indexed read-back
+  uint32_t* dIdx = nullptr; float* dRows = nullptr; uint32_t scratchCap = 0;
+  void* dDraws = nullptr;
+
+  // profiling
+  bool profiling = false;
+  std::vector<EventPair> times[SC_TICK_K_COUNT];
+  std::vector<EventPair> eventPool;
+
+  // graph
+  bool graphMode = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graphExec = nullptr;
+  TickParams graphParams{};
+  uint64_t topoEpoch = 0, graphEpoch = ~0ull;
+};
+
+namespace {
+
+bool fail(ScTickContext* c, const char* what, hipError_t e = hipSuccess)
+{
+  char buf[512];
+  if (e != hipSuccess) std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  else std::snprintf(buf, sizeof buf, "%s", what);
+  if (c) c->err = buf; else gCreateError = buf;
+  return false;
+}
+
+#define HIP_OK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail((c), #call, e_); return 0; } } while (0)
+
+bool bind(ScTickContext* c)
+{
+  const hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail(c, "hipSetDevice", e);
+  return true;
+}
+
+template <typename T>
+bool dalloc(ScTickContext* c, T*& p, size_t count, bool zero = true)
+{
+  void* v = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  hipError_t e = hipMalloc(&v, bytes);
+  if (e != hipSuccess) return fail(c, "hipMalloc", e);
+  if (zero) { e = hipMemset(v, 0, bytes); if (e != hipSuccess) return fail(c, "hipMemset", e); }
+  c->allocs.push_back(v);
+  p = static_cast<T*>(v);
+  return true;
+}
+
+bool rangeOk(ScTickContext* c, uint32_t first, uint32_t count)
+{
+  if ((uint64_t)first + count > c->n) return fail(c, "range exceeds entity count");
+  return true;
+}
+
+bool h2d(ScTickContext* c, void* dst, const void* src, size_t bytes)
+{
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) return fail(c, "hipMemcpyAsync H2D", e);
+  return true;
+}
+bool d2h(ScTickContext* c, void* dst, const void* src, size_t bytes)
+{
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (e != hipSuccess) return fail(c, "hipMemcpyAsync D2H", e);
+  return true;
+}
+bool sync(ScTickContext* c)
+{
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return fail(c, "hipStreamSynchronize", e);
+  return true;
+}
+
+// de-interleave [count][3] into three SoA streams and upload
+bool upload3(ScTickContext* c, const float* src3, uint32_t first, uint32_t count, float* dx, float* dy, float* dz)
+{
+  std::vector<float> sx(count), sy(count), sz(count);
+  for (uint32_t i = 0; i < count; ++i) { sx[i] = src3[3 * i]; sy[i] = src3[3 * i + 1]; sz[i] = src3[3 * i + 2]; }
+  const bool ok = h2d(c, dx + first, sx.data(), count * 4u) && h2d(c, dy + first, sy.data(), count * 4u) &&
+                  h2d(c, dz + first, sz.data(), count * 4u);
+  return ok && sync(c);      // staging vectors die here
+}
+
+void computeSpan(const ScTickContext* c, uint32_t& span, uint32_t& grid)
+{
+  const uint32_t n = std::max(c->n, 1u);
+  const uint32_t tiles = (n + kTile - 1) / kTile;
+  const uint32_t g = std::min(std::max(c->spansWanted, 1u), tiles);
+  const uint32_t tilesPer = (tiles + g - 1) / g;
+  span = tilesPer * kTile;
+  grid = (n + span - 1) / span;
+}
+
+// Transform::parent validation (sc_ecs.cpp:151-160) + depth / cycle classification.
+// Returns the dense indices that were detached (they are marked dirty by the caller).
+void rebuildLinks(ScTickContext* c, std::vector<uint32_t>& link, std::vector<uint32_t>& unreachBits,
+                  std::vector<uint32_t>& detached, std::vector<std::vector<uint32_t>>& deepLevels)
+{
+  const uint32_t n = c->n;
+  link.assign(n, 0);
+  unreachBits.assign((c->cap + 31) / 32, 0);
+  detached.clear();
+  deepLevels.clear();
+
+  std::vector<int32_t>& par = c->hParent;
+  for (uint32_t i = 0; i < n; ++i) {
+    const int32_t p = par[i];
+    if (p == SC_TICK_NO_PARENT) continue;
+    if (p < 0 || (uint32_t)p >= n || (uint32_t)p == i) { par[i] = SC_TICK_NO_PARENT; detached.push_back(i); }
+  }
+
+  // depth by walking up with memoisation; a walk that meets its own trail has found a cycle
+  constexpr int32_t kUnknown = -1, kCycle = -2;
+  std::vector<int32_t> depth(n, kUnknown);
+  std::vector<uint32_t> trailMark(n, 0);
+  std::vector<uint32_t> trail;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (depth[i] != kUnknown) continue;
+    trail.clear();
+    uint32_t cur = i;
+    int32_t above = -1;          // depth of the resolved node just above the trail (-1: the trail ends in a root)
+    bool cyc = false;
+    const uint32_t stamp = i + 1u;
+    for (;;) {
+      if (depth[cur] != kUnknown) { cyc = depth[cur] == kCycle; above = depth[cur]; break; }
+      if (trailMark[cur] == stamp) { cyc = true; break; }       // met our own trail: a parent cycle
+      trailMark[cur] = stamp;
+      trail.push_back(cur);
+      if (par[cur] == SC_TICK_NO_PARENT) break;
+      cur = (uint32_t)par[cur];
+    }
+    // trail holds the unresolved nodes from i upward; number them from the top down.  Everything
+    // that leads into a cycle has no root above it either, so it is unreachable as well.
+    for (size_t k = trail.size(); k-- > 0;) depth[trail[k]] = cyc ? kCycle : ++above;
+  }
+
+  c->maxDepth = 0; c->unreachable = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t dfield;
+    if (depth[i] == kCycle) { dfield = kUnreachable; c->unreachable++; unreachBits[i >> 5] |= 1u << (i & 31u); }
+    else {
+      const uint32_t dv = (uint32_t)depth[i];
+      c->maxDepth = std::max(c->maxDepth, dv);
+      if (dv <= kMaxChain) dfield = dv;
+      else {
+        dfield = kDeep;
+        const uint32_t lv = dv - kMaxChain - 1;
+        if (deepLevels.size() <= lv) deepLevels.resize(lv + 1);
+        deepLevels[lv].push_back(i);
+      }
+    }
+    const uint32_t p = (par[i] == SC_TICK_NO_PARENT) ? kNoParent : (uint32_t)par[i];
+    link[i] = p | ((c->hFlags[i] & 1u) ? kHasMesh : 0u) | ((c->hFlags[i] & 2u) ? kHasBounds : 0u) | (dfield << kDepthShift);
+  }
+}
+
+int flushLinks(ScTickContext* c)
+{
+  if (!c->linksStale) return 1;
+  std::vector<uint32_t> link, unreachBits, detached;
+  std::vector<std::vector<uint32_t>> deep;
+  rebuildLinks(c, link, unreachBits, detached, deep);
+  if (c->n) { if (!h2d(c, c->d.link, link.data(), (size_t)c->n * 4u)) return 0; }
+  if (!h2d(c, c->d.unreach, unreachBits.data(), unreachBits.size() * 4u)) return 0;
+
+  c->levelOffsets.assign(1, 0);
+  std::vector<uint32_t> flat;
+  for (auto& lv : deep) { flat.insert(flat.end(), lv.begin(), lv.end()); c->levelOffsets.push_back((uint32_t)flat.size()); }
+  if (!flat.empty()) {
+    if (flat.size() > c->levelListCap) {
+      uint32_t* p = nullptr;
+      if (!dalloc(c, p, flat.size(), false)) return 0;
+      c->dLevelList = p; c->levelListCap = (uint32_t)flat.size();
+    }
+    if (!h2d(c, c->dLevelList, flat.data(), flat.size() * 4u)) return 0;
+  }
+  uint32_t* dDet = nullptr;
+  if (!detached.empty()) {
+    // detached entities become dirty roots (sc_ecs.cpp:154-160)
+    if (c->scratchCap < detached.size()) {
+      if (!dalloc(c, c->dIdx, detached.size(), false) || !dalloc(c, c->dRows, detached.size() * 12, false)) return 0;
+      c->scratchCap = (uint32_t)detached.size();
+    }
+    dDet = c->dIdx;
+    if (!h2d(c, dDet, detached.data(), detached.size() * 4u)) return 0;
+    launchSetDirtyIndices(c->d, dDet, (uint32_t)detached.size(), c->stream);
+  }
+  if (!sync(c)) return 0;
+  c->linksStale = false;
+  c->topoEpoch++;
+  return 1;
+}
+
+EventPair takeEvents(ScTickContext* c)
+{
+  EventPair p;
+  if (!c->eventPool.empty()) { p = c->eventPool.back(); c->eventPool.pop_back(); return p; }
+  hipEventCreate(&p.a); hipEventCreate(&p.b);
+  return p;
+}
+
+struct Scoped
+{
+  ScTickContext* c; uint32_t k; EventPair p; bool on;
+  Scoped(ScTickContext* c_, uint32_t k_) : c(c_), k(k_), on(c_->profiling)
+  {
+    if (on) { p = takeEvents(c); hipEventRecord(p.a, c->stream); }
+  }
+  ~Scoped() { if (on) { hipEventRecord(p.b, c->stream); c->times[k].push_back(p); } }
+};
+
+void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
+{
+  std::memset(&p, 0, sizeof p);
+  p.n = c->n;
+  computeSpan(c, p.span, grid);
+  p.flags = flags & 0xFFFFu;
+  if (c->levelOffsets.size() > 1 && (flags & SC_TICK_XFORM)) p.flags |= kFlagHasDeep;
+  p.freeze = c->freeze ? 1u : 0u;
+  p.frustumValid = c->frustumValid ? 1u : 0u;
+  p.fr = c->frustum;
+}
+
+void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool allowProfile)
+{
+  const uint32_t flags = p.flags;
+  const bool prof = allowProfile && c->profiling;
+  const bool saved = c->profiling;
+  c->profiling = prof;
+  if (flags & (SC_TICK_XFORM | SC_TICK_CULL | SC_TICK_BROADPHASE)) {
+    Scoped s(c, SC_TICK_K_XFORM_CULL);
+    launchXformCull(c->d, p, grid, c->stream);
+  }
+  if (flags & kFlagHasDeep) {
+    for (size_t lv = 0; lv + 1 < c->levelOffsets.size(); ++lv) {
+      const uint32_t b = c->levelOffsets[lv], e = c->levelOffsets[lv + 1];
+      launchDeepLevel(c->d, p, c->dLevelList + b, e - b, c->stream);
+    }
+  }
+  if (flags & (SC_TICK_XFORM | SC_TICK_CULL)) {
+    Scoped s(c, SC_TICK_K_COMPACT);
+    launchCompact(c->d, p, grid, c->stream);
+  }
+  if ((flags & SC_TICK_DRAWS) && (flags & SC_TICK_CULL)) launchEmitDraws(c->d, c->desc.max_draws_budget, c->dDraws, c->stream);
+  c->profiling = saved;
+}
+
+void dropGraph(ScTickContext* c)
+{
+  if (c->graphExec) { hipGraphExecDestroy(c->graphExec); c->graphExec = nullptr; }
+  if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+}
+
+void rowsToMat4(const float* r12, float* m16)
+{
+  // rows -> column-major Mat4 (m[c*4+r]); last row (0,0,0,1)
+  for (int r = 0; r < 3; ++r) for (int col = 0; col < 4; ++col) m16[col * 4 + r] = r12[r * 4 + col];
+  m16[3] = 0.0f; m16[7] = 0.0f; m16[11] = 0.0f; m16[15] = 1.0f;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t scTickGetApiVersion(void) { return SC_TICK_API_VERSION; }
+
+const char* scTickGetLastError(const ScTickContext* ctx) { return ctx ? ctx->err.c_str() : gCreateError.c_str(); }
+
+ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
+{
+  if (!desc) { fail(nullptr, "null desc"); return nullptr; }
+  if (desc->capacity == 0 || desc->capacity > SC_TICK_MAX_ENTITIES) { fail(nullptr, "capacity must be 1..2^24"); return nullptr; }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) { fail(nullptr, "no HIP device available (libsc_tick needs an AMD GPU; there is no CPU fallback)", e); return nullptr; }
+  if (desc->device_ordinal < 0 || desc->device_ordinal >= count) { fail(nullptr, "device ordinal out of range"); return nullptr; }
+
+  ScTickContext* c = new ScTickContext();
+  c->desc = *desc;
+  c->device = desc->device_ordinal;
+  if (c->desc.sector_size <= 0.001f) c->desc.sector_size = 64.0f;     // WorldPartition::configure, sc_world_partition.cpp:222-223
+  c->cap = ((desc->capacity + kTile - 1) / kTile) * kTile;
+  if (const char* s = std::getenv("SC_TICK_SPANS")) { const int v = std::atoi(s); if (v > 0) c->spansWanted = (uint32_t)v; }
+
+  bool ok = bind(c);
+  if (ok) { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) ok = fail(c, "hipStreamCreate", e); }
+  DeviceState& d = c->d;
+  const size_t N = c->cap;
+  ok = ok && dalloc(c, d.px, N) && dalloc(c, d.py, N) && dalloc(c, d.pz, N)
+          && dalloc(c, d.rsx, N) && dalloc(c, d.rcx, N) && dalloc(c, d.rsy, N) && dalloc(c, d.rcy, N) && dalloc(c, d.rsz, N) && dalloc(c, d.rcz, N)
+          && dalloc(c, d.sx, N) && dalloc(c, d.sy, N) && dalloc(c, d.sz, N)
+          && dalloc(c, d.link, N) && dalloc(c, d.dirty, N / 32) && dalloc(c, d.unreach, N / 32)
+          && dalloc(c, d.bminx, N) && dalloc(c, d.bminy, N) && dalloc(c, d.bminz, N)
+          && dalloc(c, d.bmaxx, N) && dalloc(c, d.bmaxy, N) && dalloc(c, d.bmaxz, N)
+          && dalloc(c, d.meshId, N) && dalloc(c, d.materialId, N) && dalloc(c, d.layers, N)
+          && dalloc(c, d.w0, N) && dalloc(c, d.w1, N) && dalloc(c, d.w2, N)
+          && dalloc(c, d.vis, N / 64) && dalloc(c, d.cand, N / 64) && dalloc(c, d.recomp, N / 64)
+          && dalloc(c, d.blockVis, N / kTile) && dalloc(c, d.blockCand, N / kTile)
+          && dalloc(c, d.visibleIdx, N) && dalloc(c, d.culledIdx, N) && dalloc(c, d.counters, 16)
+          && dalloc(c, d.aabbMin, N) && dalloc(c, d.aabbMax, N);
+  if (ok) { void* p = nullptr; e = hipMalloc(&p, N * sizeof(ScTickDrawItem)); if (e != hipSuccess) ok = fail(c, "hipMalloc draws", e); else { c->allocs.push_back(p); c->dDraws = p; } }
+  if (ok) {
+    // Transform{}: worldMatrix = identity, scale = 1, cos = 1 (sc_ecs.h:63-71)
+    std::vector<float> ones(N, 1.0f);
+    std::vector<float4> e0(N, make_float4(1, 0, 0, 0)), e1(N, make_float4(0, 1, 0, 0)), e2(N, make_float4(0, 0, 1, 0));
+    ok = h2d(c, d.sx, ones.data(), N * 4) && h2d(c, d.sy, ones.data(), N * 4) && h2d(c, d.sz, ones.data(), N * 4)
+      && h2d(c, d.rcx, ones.data(), N * 4) && h2d(c, d.rcy, ones.data(), N * 4) && h2d(c, d.rcz, ones.data(), N * 4)
+      && h2d(c, d.w0, e0.data(), N * 16) && h2d(c, d.w1, e1.data(), N * 16) && h2d(c, d.w2, e2.data(), N * 16) && sync(c);
+  }
+  if (!ok) { gCreateError = c->err; scTickDestroyContext(c); return nullptr; }
+  c->hParent.assign(desc->capacity, SC_TICK_NO_PARENT);
+  c->hFlags.assign(desc->capacity, 0);
+  return c;
+}
+
+void scTickDestroyContext(ScTickContext* c)
+{
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  dropGraph(c);
+  for (auto& v : c->times) for (auto& p : v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto& p : c->eventPool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (void* p : c->allocs) hipFree(p);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int scTickSetEntityCount(ScTickContext* c, uint32_t count)
+{
+  if (!c) return 0;
+  if (count > c->desc.capacity) return fail(c, "count exceeds capacity");
+  c->n = count;
+  c->linksStale = true;
+  return 1;
+}
+
+int scTickUploadLocals(ScTickContext* c, uint32_t first, uint32_t count, const float* pos3, const float* rot3,
+                       const float* scale3, uint8_t* repaired)
+{
+  if (!c || !pos3 || !rot3 || !scale3) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!count) return 1;
+  std::vector<float> s[6], k(3 * (size_t)count);
+  for (auto& v : s) v.resize(count);
+  for (uint32_t i = 0; i < count; ++i) {
+    // host libm, float overloads -- what std::sin/std::cos resolve to in mat4_rotation_xyz
+    s[0][i] = std::sin(rot3[3 * i]);     s[1][i] = std::cos(rot3[3 * i]);
+    s[2][i] = std::sin(rot3[3 * i + 1]); s[3][i] = std::cos(rot3[3 * i + 1]);
+    s[4][i] = std::sin(rot3[3 * i + 2]); s[5][i] = std::cos(rot3[3 * i + 2]);
+    float a = scale3[3 * i], b = scale3[3 * i + 1], z = scale3[3 * i + 2];
+    const bool rep = (a == 0.0f && b == 0.0f && z == 0.0f);          // sc_ecs.cpp:143-149
+    if (rep) { a = b = z = 1.0f; }
+    if (repaired) repaired[i] = rep ? 1 : 0;
+    k[3 * (size_t)i] = a; k[3 * (size_t)i + 1] = b; k[3 * (size_t)i + 2] = z;
+  }
+  DeviceState& d = c->d;
+  float* dst[6] = { d.rsx, d.rcx, d.rsy, d.rcy, d.rsz, d.rcz };
+  for (int q = 0; q < 6; ++q) if (!h2d(c, dst[q] + first, s[q].data(), (size_t)count * 4u)) return 0;
+  if (!upload3(c, pos3, first, count, d.px, d.py, d.pz)) return 0;
+  if (!upload3(c, k.data(), first, count, d.sx, d.sy, d.sz)) return 0;
+  launchSetDirtyRange(d, first, count, c->stream);
+  return sync(c) ? 1 : 0;
+}
+
+int scTickUploadPositions(ScTickContext* c, uint32_t first, uint32_t count, const float* pos3)
+{
+  if (!c || !pos3) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!count) return 1;
+  if (!upload3(c, pos3, first, count, c->d.px, c->d.py, c->d.pz)) return 0;
+  launchSetDirtyRange(c->d, first, count, c->stream);
+  return sync(c) ? 1 : 0;
+}
+
+int scTickUploadBounds(ScTickContext* c, uint32_t first, uint32_t count, const float* min3, const float* max3, const uint8_t* has)
+{
+  if (!c || !min3 || !max3) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!count) return 1;
+  if (!upload3(c, min3, first, count, c->d.bminx, c->d.bminy, c->d.bminz)) return 0;
+  if (!upload3(c, max3, first, count, c->d.bmaxx, c->d.bmaxy, c->d.bmaxz)) return 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    uint8_t& f = c->hFlags[first + i];
+    f = (uint8_t)((f & ~2u) | ((!has || has[i]) ? 2u : 0u));
+  }
+  c->linksStale = true;
+  return 1;
+}
+
+int scTickUploadRenderMeshes(ScTickContext* c, uint32_t first, uint32_t count, const uint8_t* has, const uint32_t* mesh, const uint32_t* material)
+{
+  if (!c) return 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!count) return 1;
+  if (mesh && !h2d(c, c->d.meshId + first, mesh, (size_t)count * 4u)) return 0;
+  if (material && !h2d(c, c->d.materialId + first, material, (size_t)count * 4u)) return 0;
+  if (!sync(c)) return 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    uint8_t& f = c->hFlags[first + i];
+    f = (uint8_t)((f & ~1u) | ((!has || has[i]) ? 1u : 0u));
+  }
+  c->linksStale = true;
+  return 1;
+}
+
+int scTickUploadLayers(ScTickContext* c, uint32_t first, uint32_t count, const uint32_t* group, const uint32_t* mask)
+{
+  if (!c || !group || !mask) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!count) return 1;
+  std::vector<uint32_t> packed(count);
+  for (uint32_t i = 0; i < count; ++i) {
+    const uint32_t g = group[i], m = mask[i];
+    if ((g != 0xFFFFFFFFu && (g >> 16)) || (m != 0xFFFFFFFFu && (m >> 16))) return fail(c, "group/mask bits above 15 are not supported");
+    packed[i] = (g & 0xFFFFu) | ((m & 0xFFFFu) << 16);
+  }
+  if (!h2d(c, c->d.layers + first, packed.data(), (size_t)count * 4u)) return 0;
+  return sync(c) ? 1 : 0;
+}
+
+int scTickSetTopology(ScTickContext* c, const int32_t* parent, uint32_t count)
+{
+  if (!c || (!parent && count)) return c ? fail(c, "null argument") : 0;
+  if (count != c->n) return fail(c, "topology must cover every entity (count != entity count)");
+  if (!bind(c)) return 0;
+  std::copy(parent, parent + count, c->hParent.begin());
+  c->linksStale = true;
+  return flushLinks(c);
+}
+
+int scTickMarkDirty(ScTickContext* c, uint32_t first, uint32_t count)
+{
+  if (!c) return 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  launchSetDirtyRange(c->d, first, count, c->stream);
+  return 1;
+}
+
+int scTickMarkDirtyIndices(ScTickContext* c, const uint32_t* idx, uint32_t count)
+{
+  if (!c || (!idx && count)) return c ? fail(c, "null argument") : 0;
+  if (!bind(c)) return 0;
+  if (!count) return 1;
+  for (uint32_t i = 0; i < count; ++i) if (idx[i] >= c->n) return fail(c, "dense index out of range");
+  if (c->scratchCap < count) {
+    if (!dalloc(c, c->dIdx, count, false) || !dalloc(c, c->dRows, (size_t)count * 12, false)) return 0;
+    c->scratchCap = count;
+  }
+  if (!h2d(c, c->dIdx, idx, (size_t)count * 4u)) return 0;
+  launchSetDirtyIndices(c->d, c->dIdx, count, c->stream);
+  return sync(c) ? 1 : 0;
+}
+
+int scTickUploadWorldMatrices(ScTickContext* c, uint32_t first, uint32_t count, const float* m16)
+{
+  if (!c || !m16) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!count) return 1;
+  std::vector<float4> r0(count), r1(count), r2(count);
+  for (uint32_t i = 0; i < count; ++i) {
+    const float* m = m16 + 16 * (size_t)i;
+    if (m[3] != 0.0f || m[7] != 0.0f || m[11] != 0.0f || m[15] != 1.0f) return fail(c, "world matrix is not affine (row 3 must be 0,0,0,1)");
+    r0[i] = make_float4(m[0], m[4], m[8], m[12]);
+    r1[i] = make_float4(m[1], m[5], m[9], m[13]);
+    r2[i] = make_float4(m[2], m[6], m[10], m[14]);
+  }
+  if (!h2d(c, c->d.w0 + first, r0.data(), (size_t)count * 16u) || !h2d(c, c->d.w1 + first, r1.data(), (size_t)count * 16u) ||
+      !h2d(c, c->d.w2 + first, r2.data(), (size_t)count * 16u)) return 0;
+  return sync(c) ? 1 : 0;
+}
+
+int scTickSetFrustumPlanes(ScTickContext* c, const float planes[24], int valid)
+{
+  if (!c || !planes) return c ? fail(c, "null argument") : 0;
+  std::memcpy(c->frustum.p, planes, sizeof c->frustum.p);
+  c->frustumValid = valid ? 1 : 0;
+  return 1;
+}
+
+int scTickGetFrustumPlanes(ScTickContext* c, float planes[24], int* valid)
+{
+  if (!c || !planes) return c ? fail(c, "null argument") : 0;
+  std::memcpy(planes, c->frustum.p, sizeof c->frustum.p);
+  if (valid) *valid = c->frustumValid;
+  return 1;
+}
+
+// frustumFromViewProj, sc_world_partition.cpp:1071-1103: planes r3 +- r0, r3 +- r1, r3 +- r2 of the
+// column-major matrix' rows, normalised by 1/sqrt(a^2+b^2+c^2) when that exceeds 1e-8 (else zero plane).
+int scTickSetViewProj(ScTickContext* c, const float m[16])
+{
+  if (!c || !m) return c ? fail(c, "null argument") : 0;
+  const float row[4][4] = { { m[0], m[4], m[8], m[12] }, { m[1], m[5], m[9], m[13] },
+                            { m[2], m[6], m[10], m[14] }, { m[3], m[7], m[11], m[15] } };
+  for (int pl = 0; pl < 6; ++pl) {
+    const int axis = pl >> 1;
+    float v[4];
+    for (int k = 0; k < 4; ++k) v[k] = (pl & 1) ? row[3][k] - row[axis][k] : row[3][k] + row[axis][k];
+    const float lenSq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    float* out = c->frustum.p[pl];
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    if (lenSq > 1e-8f) {
+      const float invLen = 1.0f / std::sqrt(lenSq);
+      out[0] = v[0] * invLen; out[1] = v[1] * invLen; out[2] = v[2] * invLen; out[3] = v[3] * invLen;
+    }
+  }
+  c->frustumValid = 1;
+  return 1;
+}
+
+int scTickSetFreezeCulling(ScTickContext* c, int freeze)
+{
+  if (!c) return 0;
+  c->freeze = freeze ? 1 : 0;
+  return 1;
+}
+
+int scTickRun(ScTickContext* c, uint32_t flags)
+{
+  if (!c) return 0;
+  if (!bind(c)) return 0;
+  if (!flushLinks(c)) return 0;
+  if (c->n == 0) { c->lastFlags = flags; return 1; }
+  if ((flags & SC_TICK_BROADPHASE) && c->desc.tile_sectors_x == 0) return fail(c, "broadphase requested but the context has no tile rectangle");
+  TickParams p; uint32_t grid;
+  fillParams(c, flags, p, grid);
+  c->lastFlags = flags;
+
+  if (c->graphMode && !c->profiling) {
+    const bool stale = !c->graphExec || c->graphEpoch != c->topoEpoch || std::memcmp(&p, &c->graphParams, sizeof p) != 0;
+    if (stale) {
+      dropGraph(c);
+      HIP_OK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      enqueueStages(c, p, grid, false);
+      HIP_OK(c, hipStreamEndCapture(c->stream, &c->graph));
+      HIP_OK(c, hipGraphInstantiate(&c->graphExec, c->graph, nullptr, nullptr, 0));
+      c->graphParams = p; c->graphEpoch = c->topoEpoch;
+    }
+    HIP_OK(c, hipGraphLaunch(c->graphExec, c->stream));
+  } else {
+    enqueueStages(c, p, grid, true);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, "kernel launch", e);
+  return 1;
+}
+
+int scTickSynchronize(ScTickContext* c)
+{
+  if (!c) return 0;
+  if (!bind(c)) return 0;
+  return sync(c) ? 1 : 0;
+}
+
+int scTickNudgeRootsX(ScTickContext* c, float dx)
+{
+  if (!c) return 0;
+  if (!bind(c) || !flushLinks(c)) return 0;
+  Scoped s(c, SC_TICK_K_NUDGE);
+  launchNudgeRootsX(c->d, c->n, dx, c->stream);
+  return 1;
+}
+
+int scTickGetCounts(ScTickContext* c, ScTickCounts* out)
+{
+  if (!c || !out) return c ? fail(c, "null argument") : 0;
+  if (!bind(c)) return 0;
+  uint32_t k[16] = {};
+  if (!d2h(c, k, c->d.counters, sizeof k) || !sync(c)) return 0;
+  std::memset(out, 0, sizeof *out);
+  out->entities = c->n;
+  out->renderables_total = k[6];
+  out->visible = k[0];
+  out->culled = k[1];
+  out->pairs = k[2];
+  out->pairs_truncated = 0;
+  out->bin_overflow = k[3];
+  out->draws_emitted = k[4];
+  out->draws_dropped = k[5];
+  out->max_depth = c->maxDepth;
+  out->unreachable = c->unreachable;
+  return 1;
+}
+
+static int readIndexList(ScTickContext* c, const uint32_t* dev, uint32_t counterSlot, uint32_t* out, uint32_t cap, uint32_t* count)
+{
+  if (!c || !count) return c ? fail(c, "null argument") : 0;
+  if (!bind(c)) return 0;
+  uint32_t k[16] = {};
+  if (!d2h(c, k, c->d.counters, sizeof k) || !sync(c)) return 0;
+  const uint32_t total = k[counterSlot];
+  *count = total;
+  const uint32_t take = std::min(total, cap);
+  if (take && out) { if (!d2h(c, out, dev, (size_t)take * 4u) || !sync(c)) return 0; }
+  return 1;
+}
+
+int scTickReadVisible(ScTickContext* c, uint32_t* out, uint32_t cap, uint32_t* count)
+{
+  return c ? readIndexList(c, c->d.visibleIdx, 0, out, cap, count) : 0;
+}
+
+int scTickReadCulled(ScTickContext* c, uint32_t* out, uint32_t cap, uint32_t* count)
+{
+  if (!c) return 0;
+  if (!(c->lastFlags & SC_TICK_CULLED_LIST)) return fail(c, "the last scTickRun did not request SC_TICK_CULLED_LIST");
+  return readIndexList(c, c->d.culledIdx, 1, out, cap, count);
+}
+
+int scTickReadVisibilityBits(ScTickContext* c, uint64_t* words, uint32_t wordCap)
+{
+  if (!c || !words) return c ? fail(c, "null argument") : 0;
+  if (!bind(c)) return 0;
+  const uint32_t nWords = (c->n + 63u) / 64u;
+  if (wordCap < nWords) return fail(c, "word capacity too small");
+  if (nWords && (!d2h(c, words, c->d.vis, (size_t)nWords * 8u) || !sync(c))) return 0;
+  if (c->n & 63u) words[nWords - 1] &= (1ull << (c->n & 63u)) - 1ull;
+  return 1;
+}
+
+int scTickReadWorldMatrices(ScTickContext* c, uint32_t first, uint32_t count, float* m16)
+{
+  if (!c || !m16) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!count) return 1;
+  std::vector<float4> r0(count), r1(count), r2(count);
+  if (!d2h(c, r0.data(), c->d.w0 + first, (size_t)count * 16u) || !d2h(c, r1.data(), c->d.w1 + first, (size_t)count * 16u) ||
+      !d2h(c, r2.data(), c->d.w2 + first, (size_t)count * 16u) || !sync(c)) return 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    const float rows[12] = { r0[i].x, r0[i].y, r0[i].z, r0[i].w, r1[i].x, r1[i].y, r1[i].z, r1[i].w, r2[i].x, r2[i].y, r2[i].z, r2[i].w };
+    rowsToMat4(rows, m16 + 16 * (size_t)i);
+  }
+  return 1;
+}
+
+int scTickReadWorldMatricesIndexed(ScTickContext* c, const uint32_t* idx, uint32_t count, float* m16)
+{
+  if (!c || !m16 || (!idx && count)) return c ? fail(c, "null argument") : 0;
+  if (!bind(c)) return 0;
+  if (!count) return 1;
+  for (uint32_t i = 0; i < count; ++i) if (idx[i] >= c->n) return fail(c, "dense index out of range");
+  if (c->scratchCap < count) {
+    if (!dalloc(c, c->dIdx, count, false) || !dalloc(c, c->dRows, (size_t)count * 12, false)) return 0;
+    c->scratchCap = count;
+  }
+  if (!h2d(c, c->dIdx, idx, (size_t)count * 4u)) return 0;
+  launchGatherRows(c->d, c->dIdx, count, c->dRows, c->stream);
+  std::vector<float> rows((size_t)count * 12);
+  if (!d2h(c, rows.data(), c->dRows, rows.size() * 4u) || !sync(c)) return 0;
+  for (uint32_t i = 0; i < count; ++i) rowsToMat4(rows.data() + 12 * (size_t)i, m16 + 16 * (size_t)i);
+  return 1;
+}
+
+int scTickReadDirty(ScTickContext* c, uint32_t first, uint32_t count, uint8_t* out)
+{
+  if (!c || !out) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!count) return 1;
+  const uint32_t w0 = first >> 5, w1 = (first + count + 31u) >> 5;
+  std::vector<uint32_t> words(w1 - w0);
+  if (!d2h(c, words.data(), c->d.dirty + w0, words.size() * 4u) || !sync(c)) return 0;
+  for (uint32_t i = 0; i < count; ++i) { const uint32_t g = first + i; out[i] = (words[(g >> 5) - w0] >> (g & 31u)) & 1u; }
+  return 1;
+}
+
+int scTickReadPositions(ScTickContext* c, uint32_t first, uint32_t count, float* pos3)
+{
+  if (!c || !pos3) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!count) return 1;
+  std::vector<float> x(count), y(count), z(count);
+  if (!d2h(c, x.data(), c->d.px + first, (size_t)count * 4u) || !d2h(c, y.data(), c->d.py + first, (size_t)count * 4u) ||
+      !d2h(c, z.data(), c->d.pz + first, (size_t)count * 4u) || !sync(c)) return 0;
+  for (uint32_t i = 0; i < count; ++i) { pos3[3 * i] = x[i]; pos3[3 * i + 1] = y[i]; pos3[3 * i + 2] = z[i]; }
+  return 1;
+}
+
+int scTickReadWorldAabbs(ScTickContext* c, uint32_t first, uint32_t count, float* min3, float* max3)
+{
+  if (!c || !min3 || !max3) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!count) return 1;
+  std::vector<float4> a(count), b(count);
+  if (!d2h(c, a.data(), c->d.aabbMin + first, (size_t)count * 16u) || !d2h(c, b.data(), c->d.aabbMax + first, (size_t)count * 16u) || !sync(c)) return 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    min3[3 * i] = a[i].x; min3[3 * i + 1] = a[i].y; min3[3 * i + 2] = a[i].z;
+    max3[3 * i] = b[i].x; max3[3 * i + 1] = b[i].y; max3[3 * i + 2] = b[i].z;
+  }
+  return 1;
+}
+
+int scTickReadPairs(ScTickContext* c, uint32_t* pairs2, uint32_t cap, uint32_t* count)
+{
+  if (!c || !count) return c ? fail(c, "null argument") : 0;
+  (void)pairs2; (void)cap;
+  *count = 0;
+  return fail(c, "pair search not built yet");
+}
+
+int scTickReadDraws(ScTickContext* c, ScTickDrawItem* items, uint32_t cap, uint32_t* count)
+{
+  if (!c || !count) return c ? fail(c, "null argument") : 0;
+  if (!bind(c)) return 0;
+  if (!(c->lastFlags & SC_TICK_DRAWS)) return fail(c, "the last scTickRun did not request SC_TICK_DRAWS");
+  uint32_t k[16] = {};
+  if (!d2h(c, k, c->d.counters, sizeof k) || !sync(c)) return 0;
+  *count = k[4];
+  const uint32_t take = std::min(k[4], cap);
+  if (take && items) { if (!d2h(c, items, c->dDraws, (size_t)take * sizeof(ScTickDrawItem)) || !sync(c)) return 0; }
+  return 1;
+}
+
+int scTickSetProfiling(ScTickContext* c, int enable)
+{
+  if (!c) return 0;
+  if (!bind(c)) return 0;
+  if (enable) {
+    sync(c);
+    for (auto& v : c->times) { for (auto& p : v) c->eventPool.push_back(p); v.clear(); }
+  }
+  c->profiling = enable != 0;
+  return 1;
+}
+
+int scTickGetKernelTimes(ScTickContext* c, uint32_t kernel, float* ms, uint32_t cap, uint32_t* count)
+{
+  if (!c || !count || kernel >= SC_TICK_K_COUNT) return c ? fail(c, "bad argument") : 0;
+  if (!bind(c) || !sync(c)) return 0;
+  auto& v = c->times[kernel];
+  *count = (uint32_t)v.size();
+  for (uint32_t i = 0; i < v.size() && i < cap && ms; ++i) {
+    float t = 0.0f;
+    HIP_OK(c, hipEventElapsedTime(&t, v[i].a, v[i].b));
+    ms[i] = t;
+  }
+  return 1;
+}
+
+int scTickSetGraphMode(ScTickContext* c, int enable)
+{
+  if (!c) return 0;
+  if (!bind(c)) return 0;
+  c->graphMode = enable != 0;
+  if (!enable) { sync(c); dropGraph(c); }
+  return 1;
+}
+
+void* scTickGetStream(ScTickContext* c) { return c ? (void*)c->stream : nullptr; }
+
+} // extern "C"

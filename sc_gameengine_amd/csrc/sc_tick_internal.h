@@ -1,0 +1,75 @@
+// sc_tick_internal.h -- device-side data layout shared by the kernels and the C-ABI implementation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sctick {
+
+// ---- link word: one dword per entity carries topology + component flags --------------------
+//   bits  0..23  dense index of the parent (kNoParent = root)          Transform::parent
+//   bit   24     has RenderMesh  (culling candidate)                   sc_world_partition.cpp:1206-1210
+//   bit   25     has Bounds                                            sc_world_partition.cpp:1252-1263
+//   bits 26..31  hierarchy depth: 0..kMaxChain exact, kDeep.. = handled by level kernels,
+//                kUnreachable = in/below a parent cycle (never visited, sc_ecs.cpp:173-210)
+constexpr uint32_t kParentMask  = 0x00FFFFFFu;
+constexpr uint32_t kNoParent    = 0x00FFFFFFu;
+constexpr uint32_t kHasMesh     = 1u << 24;
+constexpr uint32_t kHasBounds   = 1u << 25;
+constexpr uint32_t kDepthShift  = 26;
+constexpr uint32_t kMaxChain    = 4;      // ancestors the fused kernel walks itself
+constexpr uint32_t kDeep        = 62;     // depth > kMaxChain: level kernels
+constexpr uint32_t kUnreachable = 63;
+
+constexpr uint32_t kTile = 256;           // entities per workgroup pass (4 waves of 64)
+
+struct Frustum6 { float p[6][4]; };       // (nx, ny, nz, d) x 6, Frustum (sc_world_partition.h:39-43)
+
+// Device SoA state of one context.  All arrays are sized to `cap` (padded to kTile).
+struct DeviceState {
+  // inputs: Transform locals (sc_ecs.h:63-71); rotation kept as host-libm sin/cos of the Euler angles
+  float *px, *py, *pz;
+  float *rsx, *rcx, *rsy, *rcy, *rsz, *rcz;
+  float *sx, *sy, *sz;
+  uint32_t* link;
+  uint32_t* dirty;          // 1 bit per entity (Transform::dirty), word i/32
+  uint32_t* unreach;        // 1 bit per entity: depth == kUnreachable (dirty survives the tick there)
+  // Bounds::localAabb (sc_world_partition.h:298-301)
+  float *bminx, *bminy, *bminz, *bmaxx, *bmaxy, *bmaxz;
+  // RenderMesh + collision layers
+  uint32_t *meshId, *materialId;
+  uint32_t* layers;         // group | mask << 16
+  // outputs
+  float4 *w0, *w1, *w2;     // world matrix rows 0..2 (affine 3x4; row 3 is 0,0,0,1)
+  uint64_t* vis;            // visibility bits, word i/64
+  uint64_t* cand;           // candidate bits (only written when the culled list is requested)
+  uint64_t* recomp;         // "recomputed this tick" bits (only when deep levels exist)
+  uint32_t* blockVis;       // visible count per span
+  uint32_t* blockCand;      // candidate count per span
+  uint32_t* visibleIdx;     // ordered visible dense indices
+  uint32_t* culledIdx;
+  uint32_t* counters;       // [0] visible total, [1] culled total, [2] pairs, [3] bin overflow, [4] draws, [5] dropped
+  // broadphase
+  float4 *aabbMin, *aabbMax;   // world AABB, .w of min carries the packed layers (as bits)
+};
+
+struct TickParams {
+  uint32_t n;               // entities
+  uint32_t span;            // entities per workgroup (multiple of kTile)
+  uint32_t flags;           // SC_TICK_* | internal bits below
+  uint32_t freeze;          // CullingState::freezeCulling
+  uint32_t frustumValid;
+  Frustum6 fr;
+};
+constexpr uint32_t kFlagHasDeep = 1u << 16;   // write recomp bits for the level kernels
+
+// launchers (sc_tick_kernels.hip)
+void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
+void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);
+void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
+void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s);
+void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, hipStream_t s);
+void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);
+void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s);
+void launchEmitDraws(const DeviceState& d, uint32_t budget, void* items, hipStream_t s);
+
+} // namespace sctick

@@ -1,0 +1,483 @@
+// sc_tick_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the world tick.
+//
+// Build with -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt: the reference is
+// /fp:precise C++ (no FMA contraction, correctly rounded sqrt) and visibility is decided by an
+// fp32 compare, so every rounding here has to be the host's rounding.
+//
+// The path is HBM-bound integer/fp32 streaming work (3-5 flop/B): no MFMA.  What matters is
+// coalesced SoA streams (64 lanes x 4 B = 256 B per wave load, 64 x 16 B = 1 KiB per row store),
+// no inter-workgroup dependency inside the big kernel (a child re-derives its ancestors' matrices
+// instead of waiting for them), and wave-ballot compaction.
+#include "sc_tick_internal.h"
+#include "../../include/sc_tick.h"
+
+namespace sctick {
+
+// ------------------------------------------------------------------------------------------
+// 3x4 affine helpers.  Row r of the world matrix is (M[r,0], M[r,1], M[r,2], M[r,3]); the
+// reference's column-major Mat4 has m[c*4+r] == M[r,c] and a constant last row (0,0,0,1).
+// ------------------------------------------------------------------------------------------
+struct Aff { float r0[4], r1[4], r2[4]; };
+
+__device__ __forceinline__ bool dirtyBit(const uint32_t* __restrict__ bits, uint32_t i)
+{
+  return (bits[i >> 5] >> (i & 31u)) & 1u;
+}
+
+// local = T * (R * S) with R = (Rz * Ry) * Rx  (sc_math.cpp:100-142).
+// The reference forms it with four full 4x4 products; multiplying by the exact 0 / 1 entries of
+// T, S and the axis rotations contributes +-0 terms or x*1, so the non-zero results below are the
+// same fp32 values (each sum keeps the reference's left-to-right order); only the sign of an
+// exact zero can differ.
+__device__ __forceinline__ Aff loadLocal(const DeviceState& d, uint32_t j)
+{
+  const float sx = d.rsx[j], cx = d.rcx[j];
+  const float sy = d.rsy[j], cy = d.rcy[j];
+  const float sz = d.rsz[j], cz = d.rcz[j];
+  const float kx = d.sx[j], ky = d.sy[j], kz = d.sz[j];
+  // A = Rz * Ry
+  const float a00 = cz * cy, a10 = sz * cy, a20 = -sy;
+  const float a01 = -sz,     a11 = cz;                 // a21 = 0
+  const float a02 = cz * sy, a12 = sz * sy, a22 = cy;
+  // R = A * Rx : col0 = A col0; col1 = A1*cx + A2*sx; col2 = A1*(-sx) + A2*cx
+  const float nsx = -sx;
+  const float r01 = a01 * cx + a02 * sx, r11 = a11 * cx + a12 * sx, r21 = a22 * sx;
+  const float r02 = a01 * nsx + a02 * cx, r12 = a11 * nsx + a12 * cx, r22 = a22 * cx;
+  Aff L;
+  L.r0[0] = a00 * kx; L.r0[1] = r01 * ky; L.r0[2] = r02 * kz; L.r0[3] = d.px[j];
+  L.r1[0] = a10 * kx; L.r1[1] = r11 * ky; L.r1[2] = r12 * kz; L.r1[3] = d.py[j];
+  L.r2[0] = a20 * kx; L.r2[1] = r21 * ky; L.r2[2] = r22 * kz; L.r2[3] = d.pz[j];
+  return L;
+}
+
+// world = parent * local  (mat4_mul, sc_math.cpp:52-68): ((p0*l0 + p1*l1) + p2*l2) + p3*l3 with
+// l3 the local's last row (0,0,0,1): the fourth term is +-0 for columns 0..2 and p3 for column 3.
+__device__ __forceinline__ void mulRow(const float p[4], const Aff& L, float out[4])
+{
+  out[0] = (p[0] * L.r0[0] + p[1] * L.r1[0]) + p[2] * L.r2[0];
+  out[1] = (p[0] * L.r0[1] + p[1] * L.r1[1]) + p[2] * L.r2[1];
+  out[2] = (p[0] * L.r0[2] + p[1] * L.r1[2]) + p[2] * L.r2[2];
+  out[3] = ((p[0] * L.r0[3] + p[1] * L.r1[3]) + p[2] * L.r2[3]) + p[3];
+}
+__device__ __forceinline__ Aff mulAff(const Aff& P, const Aff& L)
+{
+  Aff W;
+  mulRow(P.r0, L, W.r0); mulRow(P.r1, L, W.r1); mulRow(P.r2, L, W.r2);
+  return W;
+}
+
+__device__ __forceinline__ Aff loadRows(const DeviceState& d, uint32_t j)
+{
+  const float4 a = d.w0[j], b = d.w1[j], c = d.w2[j];
+  Aff M;
+  M.r0[0] = a.x; M.r0[1] = a.y; M.r0[2] = a.z; M.r0[3] = a.w;
+  M.r1[0] = b.x; M.r1[1] = b.y; M.r1[2] = b.z; M.r1[3] = b.w;
+  M.r2[0] = c.x; M.r2[1] = c.y; M.r2[2] = c.z; M.r2[3] = c.w;
+  return M;
+}
+__device__ __forceinline__ void storeRows(const DeviceState& d, uint32_t j, const Aff& M)
+{
+  d.w0[j] = make_float4(M.r0[0], M.r0[1], M.r0[2], M.r0[3]);
+  d.w1[j] = make_float4(M.r1[0], M.r1[1], M.r1[2], M.r1[3]);
+  d.w2[j] = make_float4(M.r2[0], M.r2[1], M.r2[2], M.r2[3]);
+}
+
+struct BoundsCE { float cx, cy, cz, ex, ey, ez; };
+__device__ __forceinline__ BoundsCE loadBounds(const DeviceState& d, uint32_t j)
+{
+  const float x0 = d.bminx[j], y0 = d.bminy[j], z0 = d.bminz[j];
+  const float x1 = d.bmaxx[j], y1 = d.bmaxy[j], z1 = d.bmaxz[j];
+  BoundsCE b;
+  b.cx = (x0 + x1) * 0.5f; b.cy = (y0 + y1) * 0.5f; b.cz = (z0 + z1) * 0.5f;
+  b.ex = (x1 - x0) * 0.5f; b.ey = (y1 - y0) * 0.5f; b.ez = (z1 - z0) * 0.5f;
+  return b;
+}
+
+// computeWorldBoundsSphere + sphereInFrustum (sc_world_partition.cpp:1105-1144).  All six planes
+// are evaluated; OR-ing "d < -radius" equals the reference's early-out (NaN compares false in both).
+__device__ __forceinline__ bool sphereVisible(const Aff& M, const BoundsCE& b, const Frustum6& fr,
+                                              float& c0, float& c1, float& c2)
+{
+  c0 = M.r0[0] * b.cx + M.r0[1] * b.cy + M.r0[2] * b.cz + M.r0[3];
+  c1 = M.r1[0] * b.cx + M.r1[1] * b.cy + M.r1[2] * b.cz + M.r1[3];
+  c2 = M.r2[0] * b.cx + M.r2[1] * b.cy + M.r2[2] * b.cz + M.r2[3];
+  const float sx = sqrtf(M.r0[0] * M.r0[0] + M.r1[0] * M.r1[0] + M.r2[0] * M.r2[0]);
+  const float sy = sqrtf(M.r0[1] * M.r0[1] + M.r1[1] * M.r1[1] + M.r2[1] * M.r2[1]);
+  const float sz = sqrtf(M.r0[2] * M.r0[2] + M.r1[2] * M.r1[2] + M.r2[2] * M.r2[2]);
+  const float syz = (sy < sz) ? sz : sy;               // std::max(a,b) == (a<b)?b:a
+  const float maxScale = (sx < syz) ? syz : sx;
+  const float radius = sqrtf(b.ex * b.ex + b.ey * b.ey + b.ez * b.ez) * maxScale;
+  bool out = false;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float dist = fr.p[k][0] * c0 + fr.p[k][1] * c1 + fr.p[k][2] * c2 + fr.p[k][3];
+    out = out || (dist < -radius);
+  }
+  return !out;
+}
+
+// world AABB of the bounds box (broadphase spec): centre as above, half extent
+// h_r = |M[r,0]|*ex + |M[r,1]|*ey + |M[r,2]|*ez
+__device__ __forceinline__ void worldAabb(const Aff& M, const BoundsCE& b, float mn[3], float mx[3])
+{
+  const float c0 = M.r0[0] * b.cx + M.r0[1] * b.cy + M.r0[2] * b.cz + M.r0[3];
+  const float c1 = M.r1[0] * b.cx + M.r1[1] * b.cy + M.r1[2] * b.cz + M.r1[3];
+  const float c2 = M.r2[0] * b.cx + M.r2[1] * b.cy + M.r2[2] * b.cz + M.r2[3];
+  const float h0 = fabsf(M.r0[0]) * b.ex + fabsf(M.r0[1]) * b.ey + fabsf(M.r0[2]) * b.ez;
+  const float h1 = fabsf(M.r1[0]) * b.ex + fabsf(M.r1[1]) * b.ey + fabsf(M.r1[2]) * b.ez;
+  const float h2 = fabsf(M.r2[0]) * b.ex + fabsf(M.r2[1]) * b.ey + fabsf(M.r2[2]) * b.ez;
+  mn[0] = c0 - h0; mn[1] = c1 - h1; mn[2] = c2 - h2;
+  mx[0] = c0 + h0; mx[1] = c1 + h1; mx[2] = c2 + h2;
+}
+
+__device__ __forceinline__ void storeAabb(const DeviceState& d, uint32_t i, bool hasBounds, const Aff& M, const BoundsCE& b)
+{
+  float mn[3], mx[3];
+  if (hasBounds) worldAabb(M, b, mn, mx);
+  else { mn[0] = mn[1] = mn[2] = INFINITY; mx[0] = mx[1] = mx[2] = -INFINITY; }
+  d.aabbMin[i] = make_float4(mn[0], mn[1], mn[2], __uint_as_float(d.layers[i]));
+  d.aabbMax[i] = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i));
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: fused TransformSystem + CullingSystem mask (+ world AABB), one launch over all entities in
+// Transform-pool dense order.
+//
+// Hierarchy without level barriers: an entity of depth <= kMaxChain walks its own parent chain
+// (link words, L1/L2-resident), finds the dirty ancestor nearest the root ("top"), and rebuilds
+// world = world'(parent(top)) * local(top) * ... * local(self) left to right -- exactly the products
+// TransformSystem's DFS performs (sc_ecs.cpp:178-209), so the result is bit-identical, while no
+// workgroup ever waits for another one.  Everything above `top` is clean, hence its stored matrix
+// is not written by anyone this tick and can be read race-free.
+// ------------------------------------------------------------------------------------------
+template <bool kCull, bool kAabb>
+__global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const TickParams p)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t begin = blockIdx.x * p.span;
+  const uint32_t end = (begin + p.span < p.n) ? begin + p.span : p.n;
+  const bool doXform = (p.flags & SC_TICK_XFORM) != 0;
+  const bool wantCand = (p.flags & SC_TICK_CULLED_LIST) != 0;
+  const bool hasDeep = (p.flags & kFlagHasDeep) != 0;
+
+  uint32_t visCount = 0, candCount = 0;      // wave-uniform running sums
+
+  for (uint32_t base = begin; base < end; base += kTile) {
+    const uint32_t i = base + threadIdx.x;
+    const bool active = i < p.n;
+    const uint32_t lk = active ? d.link[i] : ((kUnreachable << kDepthShift) | kNoParent);
+    const uint32_t depth = lk >> kDepthShift;
+    const bool chain = depth <= kMaxChain;
+
+    // ---- walk up: ancestors a[1..depth], top = dirty level nearest the root
+    uint32_t a[kMaxChain + 1];
+    a[0] = i;
+    int top = -1;
+    if (doXform && chain) {
+      if (dirtyBit(d.dirty, i)) top = 0;
+      uint32_t cur = lk;
+#pragma unroll
+      for (uint32_t k = 1; k <= kMaxChain; ++k) {
+        a[k] = i;
+        if (k <= depth) {
+          a[k] = cur & kParentMask;
+          cur = d.link[a[k]];
+          if (dirtyBit(d.dirty, a[k])) top = (int)k;
+        }
+      }
+    } else {
+#pragma unroll
+      for (uint32_t k = 1; k <= kMaxChain; ++k) a[k] = i;
+    }
+    const bool recompute = top >= 0;
+
+    Aff M;
+    if (recompute) {
+      const bool fromRoot = (uint32_t)top == depth;       // the chain's root itself is rebuilt: world = local
+      if (!fromRoot) {
+        // clean parent of the top dirty ancestor: its stored (possibly stale) matrix is the seed
+        const uint32_t seed = (top == 0) ? a[1] : (top == 1) ? a[2] : (top == 2) ? a[3] : a[4];
+        M = loadRows(d, seed);
+      }
+#pragma unroll
+      for (int lev = (int)kMaxChain; lev >= 0; --lev) {
+        if (lev <= top) {
+          const Aff L = loadLocal(d, a[lev]);
+          if (lev == top && fromRoot) M = L;
+          else M = mulAff(M, L);
+        }
+      }
+      storeRows(d, i, M);
+    } else if ((kCull || kAabb) && active) {
+      M = loadRows(d, i);
+    }
+
+    if (hasDeep) {
+      const unsigned long long rm = __ballot(recompute);
+      if (lane == 0 && (base + wave * 64u) < p.n) d.recomp[(base >> 6) + wave] = rm;
+    }
+
+    if (kCull || kAabb) {
+      const bool cand = active && (lk & kHasMesh);
+      const bool hb = active && (lk & kHasBounds);
+      BoundsCE b = {0, 0, 0, 0, 0, 0};
+      if (hb) b = loadBounds(d, i);
+
+      if (kCull) {
+        bool visible = cand;
+        if (cand && hb && !p.freeze && p.frustumValid) {
+          float c0, c1, c2;
+          visible = sphereVisible(M, b, p.fr, c0, c1, c2);
+        }
+        // deeper entities get their matrix (and their bit) from the level kernels
+        if (doXform && depth > kMaxChain && depth != kUnreachable) visible = false;
+        const unsigned long long vm = __ballot(visible);
+        const unsigned long long cm = __ballot(cand);
+        if (lane == 0 && (base + wave * 64u) < p.n) {
+          d.vis[(base >> 6) + wave] = vm;
+          if (wantCand) d.cand[(base >> 6) + wave] = cm;
+        }
+        visCount += (uint32_t)__popcll(vm);
+        candCount += (uint32_t)__popcll(cm);
+      }
+      if (kAabb && active) storeAabb(d, i, hb, M, b);
+    }
+  }
+
+  if (kCull) {
+    __shared__ uint32_t sVis[kTile / 64], sCand[kTile / 64];
+    if (lane == 0) { sVis[wave] = visCount; sCand[wave] = candCount; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      d.blockVis[blockIdx.x] = sVis[0] + sVis[1] + sVis[2] + sVis[3];
+      d.blockCand[blockIdx.x] = sCand[0] + sCand[1] + sCand[2] + sCand[3];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Level kernel for entities deeper than kMaxChain (rare): one launch per level, parents final.
+// nodeDirty = dirty || parent recomputed this tick (sc_ecs.cpp:184).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTile) void k_deep_level(const DeviceState d, const TickParams p,
+                                                      const uint32_t* __restrict__ list, uint32_t count)
+{
+  const uint32_t t = blockIdx.x * kTile + threadIdx.x;
+  if (t >= count) return;
+  const uint32_t i = list[t];
+  const uint32_t lk = d.link[i];
+  const uint32_t par = lk & kParentMask;
+  bool nodeDirty = false;
+  Aff M;
+  if (p.flags & SC_TICK_XFORM) {
+    nodeDirty = dirtyBit(d.dirty, i) || ((d.recomp[par >> 6] >> (par & 63u)) & 1ull);
+    if (nodeDirty) {
+      const Aff P = loadRows(d, par);
+      const Aff L = loadLocal(d, i);
+      M = mulAff(P, L);
+      storeRows(d, i, M);
+      atomicOr((unsigned long long*)&d.recomp[i >> 6], 1ull << (i & 63u));
+    }
+  }
+  if (!nodeDirty) M = loadRows(d, i);
+  const bool hb = (lk & kHasBounds) != 0;
+  BoundsCE b = {0, 0, 0, 0, 0, 0};
+  if (hb) b = loadBounds(d, i);
+  if (p.flags & SC_TICK_CULL) {
+    bool visible = (lk & kHasMesh) != 0;
+    if (visible && hb && !p.freeze && p.frustumValid) {
+      float c0, c1, c2;
+      visible = sphereVisible(M, b, p.fr, c0, c1, c2);
+    }
+    if (visible) {
+      atomicOr((unsigned long long*)&d.vis[i >> 6], 1ull << (i & 63u));
+      atomicAdd(&d.blockVis[i / p.span], 1u);
+    }
+  }
+  if (p.flags & SC_TICK_BROADPHASE) storeAabb(d, i, hb, M, b);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: ordered (stable) compaction of the visibility bits into CullingState::visible (and ::culled),
+// sc_world_partition.cpp:1273-1280, plus the end-of-tick dirty clear (sc_ecs.cpp:201).
+// Same span partition as K1: workgroup b owns entities [b*span, (b+1)*span); its output offset is
+// the sum of the preceding spans' counts; inside a tile each wave places its lanes by popcount.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t blockSum(uint32_t v, uint32_t* scratch)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+__global__ __launch_bounds__(kTile) void k_compact(const DeviceState d, const TickParams p)
+{
+  __shared__ uint32_t scratch[kTile / 64];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t begin = blockIdx.x * p.span;
+  const uint32_t end = (begin + p.span < p.n) ? begin + p.span : p.n;
+  const bool doCull = (p.flags & SC_TICK_CULL) != 0;
+  const bool doCulled = (p.flags & SC_TICK_CULLED_LIST) != 0;
+
+  if (doCull) {
+    uint32_t pv = 0, pc = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kTile) { pv += d.blockVis[j]; pc += d.blockCand[j]; }
+    uint32_t visBase = blockSum(pv, scratch);
+    uint32_t culBase = blockSum(pc, scratch) - visBase;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+      const uint32_t tv = visBase + d.blockVis[blockIdx.x];
+      const uint32_t tc = culBase + visBase + d.blockCand[blockIdx.x];
+      d.counters[0] = tv;            // CullingStats::visible
+      d.counters[1] = tc - tv;       // CullingStats::culled
+      d.counters[6] = tc;            // renderablesTotal
+    }
+    const uint32_t nWords = (p.n + 63u) >> 6;
+    for (uint32_t base = begin; base < end; base += kTile) {
+      const uint32_t w0 = base >> 6;
+      unsigned long long m[4], c[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        const bool ok = (w0 + k) < nWords;
+        m[k] = ok ? d.vis[w0 + k] : 0ull;
+        c[k] = (doCulled && ok) ? (d.cand[w0 + k] & ~m[k]) : 0ull;
+      }
+      uint32_t off = visBase, coff = culBase;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        if (k < wave) { off += (uint32_t)__popcll(m[k]); coff += (uint32_t)__popcll(c[k]); }
+      }
+      const unsigned long long mine = (wave == 0) ? m[0] : (wave == 1) ? m[1] : (wave == 2) ? m[2] : m[3];
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const uint32_t i = base + threadIdx.x;
+      if ((mine >> lane) & 1ull) d.visibleIdx[off + (uint32_t)__popcll(mine & below)] = i;
+      if (doCulled) {
+        const unsigned long long cm = (wave == 0) ? c[0] : (wave == 1) ? c[1] : (wave == 2) ? c[2] : c[3];
+        if ((cm >> lane) & 1ull) d.culledIdx[coff + (uint32_t)__popcll(cm & below)] = i;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) { visBase += (uint32_t)__popcll(m[k]); culBase += (uint32_t)__popcll(c[k]); }
+    }
+  }
+
+  if (p.flags & SC_TICK_XFORM) {
+    // Transform::dirty = false for every visited entity; entities in a cycle keep theirs
+    const uint32_t wBegin = begin >> 5, wEnd = (end + 31u) >> 5;
+    for (uint32_t w = wBegin + threadIdx.x; w < wEnd; w += kTile) d.dirty[w] &= d.unreach[w];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small producers / accessors
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTile) void k_nudge_roots_x(const DeviceState d, uint32_t n, float dx)
+{
+  const uint32_t i = blockIdx.x * kTile + threadIdx.x;
+  const bool root = i < n && (d.link[i] & kParentMask) == kNoParent && (d.link[i] >> kDepthShift) != kUnreachable;
+  if (root) d.px[i] = d.px[i] + dx;
+  const unsigned long long m = __ballot(root);
+  const uint32_t lane = threadIdx.x & 63u;
+  // a wave owns exactly the two dirty words of its 64 entities
+  if (lane == 0 && i < n) { d.dirty[i >> 5] |= (uint32_t)m; }
+  if (lane == 32 && i < n) { d.dirty[i >> 5] |= (uint32_t)(m >> 32); }
+}
+
+__global__ __launch_bounds__(kTile) void k_set_dirty_range(const DeviceState d, uint32_t first, uint32_t count)
+{
+  const uint32_t w = (first >> 5) + blockIdx.x * kTile + threadIdx.x;
+  const uint32_t last = first + count;            // exclusive
+  if ((w << 5) >= last) return;
+  const uint32_t lo = w << 5;
+  uint32_t mask = 0xFFFFFFFFu;
+  if (first > lo) mask &= 0xFFFFFFFFu << (first - lo);
+  if (last < lo + 32u) mask &= 0xFFFFFFFFu >> (lo + 32u - last);
+  d.dirty[w] |= mask;
+}
+
+__global__ __launch_bounds__(kTile) void k_set_dirty_indices(const DeviceState d, const uint32_t* __restrict__ idx, uint32_t count)
+{
+  const uint32_t t = blockIdx.x * kTile + threadIdx.x;
+  if (t < count) atomicOr(&d.dirty[idx[t] >> 5], 1u << (idx[t] & 31u));
+}
+
+__global__ __launch_bounds__(kTile) void k_gather_rows(const DeviceState d, const uint32_t* __restrict__ idx, uint32_t count, float* __restrict__ out12)
+{
+  const uint32_t t = blockIdx.x * kTile + threadIdx.x;
+  if (t >= count) return;
+  const uint32_t j = idx[t];
+  float4* o = reinterpret_cast<float4*>(out12) + 3u * (size_t)t;
+  o[0] = d.w0[j]; o[1] = d.w1[j]; o[2] = d.w2[j];
+}
+
+// RenderPrepStreamingSystem draw emission (sc_world_partition.cpp:1306-1329): the first `budget`
+// visible entities, in order, become DrawItem{entity, mesh, material, worldMatrix}.
+struct DrawItem80 { uint32_t dense, mesh, material, pad; float model[16]; };
+__global__ __launch_bounds__(kTile) void k_emit_draws(const DeviceState d, uint32_t budget, DrawItem80* __restrict__ items)
+{
+  const uint32_t visible = d.counters[0];
+  const uint32_t emitted = (budget > 0 && visible > budget) ? budget : visible;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { d.counters[4] = emitted; d.counters[5] = visible - emitted; }
+  for (uint32_t t = blockIdx.x * kTile + threadIdx.x; t < emitted; t += gridDim.x * kTile) {
+    const uint32_t j = d.visibleIdx[t];
+    const float4 a = d.w0[j], b = d.w1[j], c = d.w2[j];
+    float4* o = reinterpret_cast<float4*>(&items[t]);
+    o[0] = make_float4(__uint_as_float(j), __uint_as_float(d.meshId[j]), __uint_as_float(d.materialId[j]), 0.0f);
+    o[1] = make_float4(a.x, b.x, c.x, 0.0f);     // column 0
+    o[2] = make_float4(a.y, b.y, c.y, 0.0f);
+    o[3] = make_float4(a.z, b.z, c.z, 0.0f);
+    o[4] = make_float4(a.w, b.w, c.w, 1.0f);     // translation column
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
+{
+  const bool cull = (p.flags & SC_TICK_CULL) != 0, aabb = (p.flags & SC_TICK_BROADPHASE) != 0;
+  if (cull && aabb) hipLaunchKernelGGL((k_xform_cull<true, true>), dim3(grid), dim3(kTile), 0, s, d, p);
+  else if (cull)    hipLaunchKernelGGL((k_xform_cull<true, false>), dim3(grid), dim3(kTile), 0, s, d, p);
+  else if (aabb)    hipLaunchKernelGGL((k_xform_cull<false, true>), dim3(grid), dim3(kTile), 0, s, d, p);
+  else              hipLaunchKernelGGL((k_xform_cull<false, false>), dim3(grid), dim3(kTile), 0, s, d, p);
+}
+void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* list, uint32_t count, hipStream_t s)
+{
+  if (!count) return;
+  hipLaunchKernelGGL(k_deep_level, dim3((count + kTile - 1) / kTile), dim3(kTile), 0, s, d, p, list, count);
+}
+void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_compact, dim3(grid), dim3(kTile), 0, s, d, p);
+}
+void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s)
+{
+  if (!n) return;
+  hipLaunchKernelGGL(k_nudge_roots_x, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, dx);
+}
+void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, hipStream_t s)
+{
+  if (!count) return;
+  const uint32_t words = ((first + count + 31u) >> 5) - (first >> 5);
+  hipLaunchKernelGGL(k_set_dirty_range, dim3((words + kTile - 1) / kTile), dim3(kTile), 0, s, d, first, count);
+}
+void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s)
+{
+  if (!count) return;
+  hipLaunchKernelGGL(k_set_dirty_indices, dim3((count + kTile - 1) / kTile), dim3(kTile), 0, s, d, idx, count);
+}
+void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s)
+{
+  if (!count) return;
+  hipLaunchKernelGGL(k_gather_rows, dim3((count + kTile - 1) / kTile), dim3(kTile), 0, s, d, idx, count, out12);
+}
+void launchEmitDraws(const DeviceState& d, uint32_t budget, void* items, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_emit_draws, dim3(1024), dim3(kTile), 0, s, d, budget, (DrawItem80*)items);
+}
+
+} // namespace sctick

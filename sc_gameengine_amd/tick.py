@@ -1,0 +1,287 @@
+"""WorldTick -- thin Python host over the C ABI (libsc_tick.so) for tests and bench.py.
+
+It mirrors what the C++ adapter systems do (sc_gameengine_amd/host/sc_tick_systems.cpp): push entity
+state, set the frame's viewProj, run the tick, read results.  No CPU fallback, no oracle import.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def _f(a):
+    return a.ctypes.data_as(capi.F32P)
+
+
+def _u(a):
+    return a.ctypes.data_as(capi.U32P)
+
+
+def _c32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ---- host-side camera math (CameraSystem stays on the host, sc_ecs.cpp:213-272) ----------------
+def host_mat4_trs(pos, rot, scale):
+    p, r, s, o = _c32(pos), _c32(rot), _c32(scale), np.zeros(16, np.float32)
+    assert capi.load().scTickHostMat4Trs(_f(p), _f(r), _f(s), _f(o))
+    return o
+
+
+def host_mat4_mul(a, b):
+    a, b, o = _c32(a), _c32(b), np.zeros(16, np.float32)
+    assert capi.load().scTickHostMat4Mul(_f(a), _f(b), _f(o))
+    return o
+
+
+def host_mat4_inverse(a):
+    a, o = _c32(a), np.zeros(16, np.float32)
+    assert capi.load().scTickHostMat4Inverse(_f(a), _f(o))
+    return o
+
+
+def host_mat4_perspective(fov, aspect, zn, zf, flip):
+    o = np.zeros(16, np.float32)
+    assert capi.load().scTickHostMat4PerspectiveRhZo(float(fov), float(aspect), float(zn), float(zf), int(flip), _f(o))
+    return o
+
+
+def host_camera_view_proj(camera_world, fov_y_deg=60.0, aspect=16.0 / 9.0, near=0.1, far=1000.0):
+    m, o = _c32(camera_world), np.zeros(16, np.float32)
+    assert capi.load().scTickHostCameraViewProj(_f(m), float(fov_y_deg), float(aspect), float(near), float(far), _f(o))
+    return o
+
+
+def camera_view_proj(cam):
+    """viewProj of a root camera entity described by a SynthWorld camera dict."""
+    world = host_mat4_trs(cam["pos"], cam["rot"], (1.0, 1.0, 1.0))
+    return host_camera_view_proj(world, cam["fovY"], cam["aspect"], cam["nearZ"], cam["farZ"])
+
+
+class WorldTick:
+    def __init__(self, capacity, device=0, tile_origin=(0, 0), tile_sectors=(0, 0), sector_size=64.0,
+                 max_pairs=0, max_draws=0):
+        self.lib = capi.load()
+        d = capi.ContextDesc()
+        d.device_ordinal = device
+        d.capacity = capacity
+        d.tile_origin_x, d.tile_origin_z = tile_origin
+        d.tile_sectors_x, d.tile_sectors_z = tile_sectors
+        d.sector_size = sector_size
+        d.max_pairs = max_pairs
+        d.max_draws_budget = max_draws
+        self.ctx = self.lib.scTickCreateContext(C.byref(d))
+        if not self.ctx:
+            raise capi.ScTickError("scTickCreateContext failed: " + (self.lib.scTickGetLastError(None) or b"").decode())
+        self.capacity = capacity
+        self.n = 0
+
+    # ---- plumbing ----
+    def _ok(self, r, what):
+        if not r:
+            raise capi.ScTickError(f"{what}: " + (self.lib.scTickGetLastError(self.ctx) or b"").decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.scTickDestroyContext(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- state ----
+    @classmethod
+    def from_world(cls, w, device=0, broadphase=True, max_pairs=0, max_draws=0, capacity=None):
+        t = cls(capacity or max(w.n, 1), device=device,
+                tile_origin=w.origin if broadphase else (0, 0),
+                tile_sectors=w.sectors if broadphase else (0, 0),
+                max_pairs=max_pairs, max_draws=max_draws)
+        t.upload_world(w)
+        return t
+
+    def upload_world(self, w):
+        self.set_count(w.n)
+        if w.n == 0:
+            return
+        self.upload_locals(0, w.pos, w.rot, w.scale)
+        self.upload_bounds(0, w.bmin, w.bmax, w.has_bounds)
+        self.upload_render_meshes(0, w.has_mesh, w.mesh, w.material)
+        self.upload_layers(0, w.group, w.mask)
+        self.set_topology(w.parent)
+
+    def set_count(self, n):
+        self._ok(self.lib.scTickSetEntityCount(self.ctx, n), "scTickSetEntityCount")
+        self.n = n
+
+    def upload_locals(self, first, pos, rot, scale):
+        p, r, s = _c32(pos), _c32(rot), _c32(scale)
+        rep = np.zeros(len(p), np.uint8)
+        self._ok(self.lib.scTickUploadLocals(self.ctx, first, len(p), _f(p), _f(r), _f(s), rep.ctypes.data_as(capi.U8P)),
+                 "scTickUploadLocals")
+        return rep
+
+    def upload_positions(self, first, pos):
+        p = _c32(pos)
+        self._ok(self.lib.scTickUploadPositions(self.ctx, first, len(p), _f(p)), "scTickUploadPositions")
+
+    def upload_bounds(self, first, bmin, bmax, has=None):
+        a, b = _c32(bmin), _c32(bmax)
+        h = None if has is None else np.ascontiguousarray(has, np.uint8)
+        self._ok(self.lib.scTickUploadBounds(self.ctx, first, len(a), _f(a), _f(b),
+                                             None if h is None else h.ctypes.data_as(capi.U8P)), "scTickUploadBounds")
+
+    def upload_render_meshes(self, first, has, mesh, material):
+        h = np.ascontiguousarray(has, np.uint8)
+        m, t = np.ascontiguousarray(mesh, np.uint32), np.ascontiguousarray(material, np.uint32)
+        self._ok(self.lib.scTickUploadRenderMeshes(self.ctx, first, len(h), h.ctypes.data_as(capi.U8P), _u(m), _u(t)),
+                 "scTickUploadRenderMeshes")
+
+    def upload_layers(self, first, group, mask):
+        g, m = np.ascontiguousarray(group, np.uint32), np.ascontiguousarray(mask, np.uint32)
+        self._ok(self.lib.scTickUploadLayers(self.ctx, first, len(g), _u(g), _u(m)), "scTickUploadLayers")
+
+    def set_topology(self, parent):
+        p = np.ascontiguousarray(parent, np.int32)
+        self._ok(self.lib.scTickSetTopology(self.ctx, p.ctypes.data_as(capi.I32P), len(p)), "scTickSetTopology")
+
+    def mark_dirty(self, first, count):
+        self._ok(self.lib.scTickMarkDirty(self.ctx, first, count), "scTickMarkDirty")
+
+    def mark_dirty_indices(self, idx):
+        i = np.ascontiguousarray(idx, np.uint32)
+        self._ok(self.lib.scTickMarkDirtyIndices(self.ctx, _u(i), len(i)), "scTickMarkDirtyIndices")
+
+    def upload_world_matrices(self, first, m16):
+        m = _c32(m16)
+        self._ok(self.lib.scTickUploadWorldMatrices(self.ctx, first, len(m), _f(m)), "scTickUploadWorldMatrices")
+
+    # ---- frame inputs ----
+    def set_view_proj(self, vp):
+        v = _c32(vp)
+        self._ok(self.lib.scTickSetViewProj(self.ctx, _f(v)), "scTickSetViewProj")
+
+    def set_frustum_planes(self, planes, valid=True):
+        p = _c32(planes).reshape(24)
+        self._ok(self.lib.scTickSetFrustumPlanes(self.ctx, _f(p), 1 if valid else 0), "scTickSetFrustumPlanes")
+
+    def frustum_planes(self):
+        p, v = np.zeros(24, np.float32), C.c_int()
+        self._ok(self.lib.scTickGetFrustumPlanes(self.ctx, _f(p), C.byref(v)), "scTickGetFrustumPlanes")
+        return p.reshape(6, 4), v.value
+
+    def set_camera(self, cam):
+        vp = camera_view_proj(cam)
+        self.set_view_proj(vp)
+        return vp
+
+    def set_freeze_culling(self, on):
+        self._ok(self.lib.scTickSetFreezeCulling(self.ctx, 1 if on else 0), "scTickSetFreezeCulling")
+
+    # ---- tick ----
+    def run(self, flags=capi.XFORM | capi.CULL):
+        self._ok(self.lib.scTickRun(self.ctx, flags), "scTickRun")
+
+    def sync(self):
+        self._ok(self.lib.scTickSynchronize(self.ctx), "scTickSynchronize")
+
+    def nudge_roots_x(self, dx):
+        self._ok(self.lib.scTickNudgeRootsX(self.ctx, float(dx)), "scTickNudgeRootsX")
+
+    def set_profiling(self, on):
+        self._ok(self.lib.scTickSetProfiling(self.ctx, 1 if on else 0), "scTickSetProfiling")
+
+    def set_graph_mode(self, on):
+        self._ok(self.lib.scTickSetGraphMode(self.ctx, 1 if on else 0), "scTickSetGraphMode")
+
+    def kernel_times_ms(self, kernel):
+        cnt = C.c_uint32()
+        self._ok(self.lib.scTickGetKernelTimes(self.ctx, kernel, None, 0, C.byref(cnt)), "scTickGetKernelTimes")
+        out = np.zeros(cnt.value, np.float32)
+        if cnt.value:
+            self._ok(self.lib.scTickGetKernelTimes(self.ctx, kernel, _f(out), cnt.value, C.byref(cnt)), "scTickGetKernelTimes")
+        return out
+
+    # ---- results ----
+    def counts(self):
+        c = capi.Counts()
+        self._ok(self.lib.scTickGetCounts(self.ctx, C.byref(c)), "scTickGetCounts")
+        return c
+
+    def _index_list(self, fn, name):
+        cnt = C.c_uint32()
+        out = np.zeros(max(self.n, 1), np.uint32)
+        self._ok(fn(self.ctx, _u(out), len(out), C.byref(cnt)), name)
+        return out[:cnt.value].copy()
+
+    def visible(self):
+        return self._index_list(self.lib.scTickReadVisible, "scTickReadVisible")
+
+    def culled(self):
+        return self._index_list(self.lib.scTickReadCulled, "scTickReadCulled")
+
+    def visibility_bits(self):
+        nw = (self.n + 63) // 64
+        w = np.zeros(max(nw, 1), np.uint64)
+        self._ok(self.lib.scTickReadVisibilityBits(self.ctx, w.ctypes.data_as(capi.U64P), len(w)), "scTickReadVisibilityBits")
+        bits = np.unpackbits(w[:nw].view(np.uint8), bitorder="little")[:self.n]
+        return bits.astype(np.uint8)
+
+    def world_matrices(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.zeros((count, 16), np.float32)
+        self._ok(self.lib.scTickReadWorldMatrices(self.ctx, first, count, _f(out)), "scTickReadWorldMatrices")
+        return out
+
+    def world_matrices_indexed(self, idx):
+        i = np.ascontiguousarray(idx, np.uint32)
+        out = np.zeros((len(i), 16), np.float32)
+        self._ok(self.lib.scTickReadWorldMatricesIndexed(self.ctx, _u(i), len(i), _f(out)), "scTickReadWorldMatricesIndexed")
+        return out
+
+    def dirty(self):
+        out = np.zeros(self.n, np.uint8)
+        self._ok(self.lib.scTickReadDirty(self.ctx, 0, self.n, out.ctypes.data_as(capi.U8P)), "scTickReadDirty")
+        return out
+
+    def positions(self):
+        out = np.zeros((self.n, 3), np.float32)
+        self._ok(self.lib.scTickReadPositions(self.ctx, 0, self.n, _f(out)), "scTickReadPositions")
+        return out
+
+    def world_aabbs(self):
+        mn, mx = np.zeros((self.n, 3), np.float32), np.zeros((self.n, 3), np.float32)
+        self._ok(self.lib.scTickReadWorldAabbs(self.ctx, 0, self.n, _f(mn), _f(mx)), "scTickReadWorldAabbs")
+        return mn, mx
+
+    def pairs(self, cap=None):
+        cnt = C.c_uint32()
+        self._ok(self.lib.scTickReadPairs(self.ctx, None, 0, C.byref(cnt)), "scTickReadPairs")
+        n = cnt.value if cap is None else min(cap, cnt.value)
+        out = np.zeros((max(n, 1), 2), np.uint32)
+        if n:
+            self._ok(self.lib.scTickReadPairs(self.ctx, _u(out), n, C.byref(cnt)), "scTickReadPairs")
+        return out[:n].copy(), cnt.value
+
+    def draws(self):
+        cnt = C.c_uint32()
+        self._ok(self.lib.scTickReadDraws(self.ctx, None, 0, C.byref(cnt)), "scTickReadDraws")
+        buf = (capi.DrawItem * max(cnt.value, 1))()
+        if cnt.value:
+            self._ok(self.lib.scTickReadDraws(self.ctx, buf, cnt.value, C.byref(cnt)), "scTickReadDraws")
+        n = cnt.value
+        a = np.frombuffer(buf, dtype=np.uint8, count=80 * n).reshape(n, 80) if n else np.zeros((0, 80), np.uint8)
+        idx = a[:, 0:4].copy().view(np.uint32).ravel()
+        mesh = a[:, 4:8].copy().view(np.uint32).ravel()
+        mat = a[:, 8:12].copy().view(np.uint32).ravel()
+        model = a[:, 16:80].copy().view(np.float32).reshape(n, 16)
+        return idx, mesh, mat, model

@@ -1,0 +1,250 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the oracle on the same
+seeded inputs.  Bar: visibility lists / masks / indices bit-exact; world matrices equal as IEEE
+values element for element (only the sign of an exact zero may differ), which is far
+inside north_star's 1e-5 relative."""
+import numpy as np
+import pytest
+
+from sc_gameengine_amd import capi, synth_world as sw
+from sc_gameengine_amd.tick import WorldTick, camera_view_proj
+from tests import worlds
+
+pytestmark = pytest.mark.gpu
+
+XC = capi.XFORM | capi.CULL
+
+
+def assert_mats_equal(got, want):
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    assert got.shape == want.shape
+    if not np.array_equal(got, want):                     # IEEE equality: +0 == -0
+        bad = np.flatnonzero((got != want).any(axis=1))
+        rel = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+        raise AssertionError(f"{len(bad)} matrices differ, first {bad[:5]}, max rel {rel:g}")
+
+
+def run_and_compare(oracle, w, flags=XC, ticks=1, nudge=None, camera_entity=False):
+    """One world through both paths, compared after every tick; returns (tick, oracle world).
+
+    camera_entity=True also puts the camera into the device world (a Transform without RenderMesh or
+    Bounds at dense index n); the frame's viewProj then comes from the oracle's CameraSystem."""
+    ow = worlds.oracle_world(oracle, w, camera=True)
+    g = w if not camera_entity else sw.with_extra_entity(w, w.camera["pos"], w.camera["rot"])
+    t = WorldTick.from_world(g, broadphase=False)
+    fixed_vp = camera_view_proj(w.camera)
+    for k in range(ticks):
+        if nudge is not None and k > 0:
+            ow.nudge_roots_x(nudge)
+            t.nudge_roots_x(nudge)
+        ow.transform_system()
+        vp = ow.camera_system() if camera_entity else fixed_vp
+        ow.culling_system(view_proj=vp)
+        t.set_view_proj(vp)
+        t.run(flags)
+        n = g.n
+        assert_mats_equal(t.world_matrices(), ow.world_matrices()[:n])
+        assert np.array_equal(t.visible(), ow.visible())
+        c = t.counts()
+        assert c.visible == len(ow.visible()) and c.culled == len(ow.culled()) and c.renderables_total == len(ow.candidates())
+        assert np.array_equal(t.dirty(), ow.dirty()[:n])
+    return t, ow
+
+
+def test_config1_static_world(oracle):
+    w = sw.config("config1")
+    t, ow = run_and_compare(oracle, w)
+    # the frustum the library derived from viewProj is the oracle's, bit for bit
+    planes, valid = t.frustum_planes()
+    assert valid == 1 and np.array_equal(planes.view(np.uint32), ow.frustum_planes().view(np.uint32))
+    mask = np.zeros(w.n, np.uint8); mask[ow.candidates()] = ow.visibility_mask()
+    assert np.array_equal(t.visibility_bits(), mask)
+    assert 0 < t.counts().visible < w.n
+    t.close(); ow.close()
+
+
+def test_config2_hierarchy_static_then_moving_roots(oracle):
+    w = sw.generate(64, 64, 24)                      # config 2: 102 400 entities, depths 0/1/2
+    t, ow = run_and_compare(oracle, w, ticks=4, nudge=0.01)
+    # static regime: nothing dirty -> tick leaves every matrix as it is
+    before = t.world_matrices()
+    t.run(XC)
+    assert np.array_equal(before.view(np.uint32), t.world_matrices().view(np.uint32))
+    t.close(); ow.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1000, 4097])
+def test_ragged_sizes(oracle, n):
+    w = worlds.random_world(n, seed=100 + n, max_depth=4)
+    t, ow = run_and_compare(oracle, w)
+    t.close(); ow.close()
+
+
+def test_empty_world():
+    t = WorldTick(16)
+    t.set_count(0)
+    t.set_view_proj(np.eye(4, dtype=np.float32).ravel())
+    t.run(XC)
+    assert len(t.visible()) == 0 and t.counts().visible == 0
+    t.close()
+
+
+def test_random_forest_missing_components_zero_scales_forward_parents(oracle):
+    w = worlds.random_world(20000, seed=7, max_depth=4, p_no_bounds=0.2, p_no_mesh=0.2, zero_scales=50, forward_parents=True)
+    t, ow = run_and_compare(oracle, w, ticks=3, nudge=0.37, camera_entity=True)
+    got = t.positions()[:64]
+    want = np.array([list(ow.get_transform(int(e)).localPos) for e in ow.dense_entities()[:64]], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))          # the nudge is the same fp32 add
+    t.close(); ow.close()
+
+
+def test_deep_chains_use_level_kernels(oracle):
+    w = worlds.chain_world(40, branches=5, seed=11)            # depth 39 >> kMaxChain
+    t, ow = run_and_compare(oracle, w, ticks=3, nudge=0.5)
+    assert t.counts().max_depth == 39
+    t.close(); ow.close()
+
+
+def test_partial_dirty_sets(oracle):
+    w = worlds.random_world(5000, seed=13, max_depth=4)
+    ow = worlds.oracle_world(oracle, w)
+    t = WorldTick.from_world(w, broadphase=False)
+    vp = camera_view_proj(w.camera)
+    t.set_view_proj(vp)
+    ow.transform_system(); t.run(XC)
+    rng = np.random.default_rng(5)
+    for it in range(4):
+        # setLocalPosition on a random subset (marks exactly those dirty on both sides)
+        ids = np.sort(rng.choice(w.n, 300, replace=False)).astype(np.uint32)
+        newp = rng.uniform(-50, 50, (300, 3)).astype(np.float32)
+        ow.set_local_positions(ow.dense_entities()[ids], newp)
+        for k in range(300):
+            t.upload_positions(int(ids[k]), newp[k:k + 1])
+        ow.transform_system(); ow.culling_system(view_proj=vp)
+        t.run(XC)
+        assert_mats_equal(t.world_matrices(), ow.world_matrices()[:w.n])
+        assert np.array_equal(t.visible(), ow.visible())
+        # markDirty on children only, parents untouched
+        mids = np.flatnonzero(w.parent >= 0)[it * 50:(it + 1) * 50].astype(np.uint32)
+        ow.mark_dirty(ow.dense_entities()[mids]); t.mark_dirty_indices(mids)
+        ow.transform_system(); t.run(capi.XFORM)
+        assert_mats_equal(t.world_matrices(), ow.world_matrices()[:w.n])
+        assert not t.dirty().any()
+    t.close(); ow.close()
+
+
+def test_seeded_stale_world_matrices_are_used_for_clean_parents(oracle):
+    w = worlds.chain_world(4, branches=8, seed=17)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    t = WorldTick.from_world(w, broadphase=False)
+    ow.transform_system(); t.run(capi.XFORM)
+    # overwrite the stored matrix of the clean roots on both sides, then dirty only their children
+    rng = np.random.default_rng(3)
+    fake = np.tile(np.eye(4, dtype=np.float32).ravel(), (8, 1))
+    fake[:, 12:15] = rng.uniform(-5, 5, (8, 3)).astype(np.float32)
+    for k in range(8):
+        tr = ow.get_transform(int(ow.dense_entities()[k]))
+        for q in range(16):
+            tr.worldMatrix[q] = float(fake[k, q])
+    t.upload_world_matrices(0, fake)
+    kids = np.arange(8, 16, dtype=np.uint32)
+    ow.mark_dirty(ow.dense_entities()[kids]); t.mark_dirty_indices(kids)
+    ow.transform_system(); t.run(capi.XFORM)
+    assert_mats_equal(t.world_matrices(), ow.world_matrices())
+    t.close(); ow.close()
+
+
+def test_cycles_and_invalid_parents(oracle):
+    w = worlds.random_world(3000, seed=19, max_depth=3)
+    w.parent[100], w.parent[101], w.parent[102] = 101, 100, 101     # cycle + a tail below it
+    w.parent[200] = 200                                             # self parent
+    w.parent[201] = 999999                                          # out of range
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    # the oracle validates parents through entity handles: an out-of-range index is a dead entity
+    t = WorldTick.from_world(w, broadphase=False)
+    vp = camera_view_proj(w.camera)
+    t.set_view_proj(vp)
+    for _ in range(2):
+        ow.transform_system(); ow.culling_system(view_proj=vp)
+        t.run(XC)
+        assert_mats_equal(t.world_matrices(), ow.world_matrices())
+        assert np.array_equal(t.visible(), ow.visible())
+        assert np.array_equal(t.dirty(), ow.dirty())                # cycle members stay dirty
+    assert t.counts().unreachable >= 3
+    t.close(); ow.close()
+
+
+def test_freeze_culling_culled_list_and_draws(oracle):
+    w = worlds.random_world(6000, seed=23, p_no_bounds=0.15, p_no_mesh=0.25)
+    ow = worlds.oracle_world(oracle, w)
+    t = WorldTick.from_world(w, broadphase=False, max_draws=100)
+    vp = camera_view_proj(w.camera)
+    t.set_view_proj(vp)
+    ow.transform_system(); ow.culling_system(view_proj=vp)
+    t.run(XC | capi.CULLED_LIST | capi.DRAWS)
+    assert np.array_equal(t.visible(), ow.visible()) and np.array_equal(t.culled(), ow.culled())
+    ent, mesh, mat, model, dropped = ow.draw_items(max_draws=100)
+    idx, gmesh, gmat, gmodel = t.draws()
+    assert np.array_equal(idx, ent) and np.array_equal(gmesh, mesh) and np.array_equal(gmat, mat)
+    assert_mats_equal(gmodel, model)
+    c = t.counts()
+    assert c.draws_emitted == len(ent) and c.draws_dropped == dropped
+    assert_mats_equal(t.world_matrices_indexed(t.visible()[:500]), ow.world_matrices()[ow.visible()[:500]])
+    t.set_freeze_culling(True); ow.culling_system(view_proj=vp, freeze=True)
+    t.run(capi.CULL | capi.CULLED_LIST)
+    assert np.array_equal(t.visible(), ow.visible()) and len(t.culled()) == 0
+    t.close(); ow.close()
+
+
+def test_invalid_frustum_means_everything_visible():
+    w = worlds.random_world(1000, seed=29)
+    t = WorldTick.from_world(w, broadphase=False)
+    t.set_frustum_planes(np.zeros((6, 4), np.float32), valid=False)
+    t.run(XC)
+    assert np.array_equal(t.visible(), np.flatnonzero(w.has_mesh).astype(np.uint32))
+    t.close()
+
+
+def test_graph_mode_gives_identical_results(oracle):
+    w = sw.generate(32, 32, 15)
+    ow = worlds.oracle_world(oracle, w)
+    t = WorldTick.from_world(w, broadphase=False)
+    vp = camera_view_proj(w.camera)
+    t.set_view_proj(vp)
+    t.set_graph_mode(True)
+    for k in range(4):
+        if k:
+            ow.nudge_roots_x(0.01); t.nudge_roots_x(0.01)
+        ow.transform_system(); ow.culling_system(view_proj=vp)
+        t.run(XC)
+        assert_mats_equal(t.world_matrices(), ow.world_matrices()[:w.n])
+        assert np.array_equal(t.visible(), ow.visible())
+    t.close(); ow.close()
+
+
+def test_full_size_1m_properties():
+    """BASELINE config 3 size (1 048 576 entities): size-independent properties instead of the oracle."""
+    w = sw.config("config3")
+    t = WorldTick.from_world(w, broadphase=False)
+    t.set_camera(w.camera)
+    t.run(XC | capi.CULLED_LIST)
+    vis, cul = t.visible(), t.culled()
+    bits = t.visibility_bits()
+    assert (np.diff(vis.astype(np.int64)) > 0).all() and (np.diff(cul.astype(np.int64)) > 0).all()   # sorted = dense order
+    assert np.array_equal(np.flatnonzero(bits).astype(np.uint32), vis)                              # list == mask
+    assert len(vis) + len(cul) == w.n and 0 < len(vis) < w.n
+    assert not t.dirty().any()
+    m0 = t.world_matrices()
+    # idempotence: recompute-all (everything marked dirty) == dirty-propagation result
+    t.mark_dirty(0, w.n); t.run(XC)
+    assert np.array_equal(m0.view(np.uint32), t.world_matrices().view(np.uint32)) and np.array_equal(t.visible(), vis)
+    # roots carry their own translation; a child's matrix moves with its root under a root nudge
+    roots = np.flatnonzero(w.parent < 0)
+    assert np.array_equal(m0[roots, 12:15].view(np.uint32), w.pos[roots].view(np.uint32))
+    t.nudge_roots_x(0.25); t.run(XC)
+    m1 = t.world_matrices()
+    assert np.array_equal(m1[roots, 12], (w.pos[roots, 0] + np.float32(0.25)).astype(np.float32))
+    assert np.allclose(m1[:, 12] - m0[:, 12], 0.25, atol=2e-3) and np.array_equal(m1[:, :12], m0[:, :12])
+    # checksum of the visible list is reproducible run to run
+    t.run(XC)
+    assert np.array_equal(t.visible(), t.visible())
+    t.close()

@@ -1,0 +1,195 @@
+"""Behaviour of the oracle's systems (the unpinned part): the rules SURVEY.md section 3C/3E lists,
+and agreement with the second, independent numpy restatement (oracle/oracle_np.py)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as onp
+from sc_gameengine_amd import synth_world as sw
+from tests import worlds
+
+IDENT = np.eye(4, dtype=np.float32).ravel()
+
+
+def beq(a, b):
+    """equal as IEEE values (+0 == -0), element for element"""
+    return np.array_equal(np.asarray(a, np.float32), np.asarray(b, np.float32))
+
+
+def test_transform_hierarchy_matches_numpy_witness(oracle):
+    for seed, n in [(1, 257), (2, 1000), (3, 4096)]:
+        w = worlds.random_world(n, seed=seed, max_depth=6, zero_scales=5)
+        ow = worlds.oracle_world(oracle, w, camera=False)
+        ow.transform_system()
+        want, dirty, scale = onp.transform_system(w.pos, w.rot, w.scale, w.parent, np.ones(n, bool), np.tile(IDENT, (n, 1)))
+        assert np.array_equal(ow.world_matrices().view(np.uint32), want.view(np.uint32))   # bit for bit
+        assert not ow.dirty().any() and not dirty.any()
+        assert beq(ow.local_scales(), scale)
+        ow.close()
+
+
+def test_dirty_propagation_and_stale_parent(oracle):
+    w = worlds.chain_world(6, branches=2, seed=4)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    ow.transform_system()
+    m0 = ow.world_matrices()
+    # nothing dirty: a second tick changes nothing
+    ow.transform_system()
+    assert np.array_equal(ow.world_matrices().view(np.uint32), m0.view(np.uint32))
+    # change a mid-chain entity WITHOUT marking it: nothing moves (stale matrices are kept)
+    t = ow.get_transform(int(ow.dense_entities()[4]))
+    t.localPos[0] = 99.0
+    ow.transform_system()
+    assert np.array_equal(ow.world_matrices().view(np.uint32), m0.view(np.uint32))
+    # mark only its child dirty: the child is rebuilt from the parent's STORED (stale) matrix
+    ow.mark_dirty([int(ow.dense_entities()[6])])
+    ow.transform_system()
+    m1 = ow.world_matrices()
+    changed = np.flatnonzero((m1 != m0).any(axis=1))
+    assert set(changed) <= {6, 8, 10} and np.array_equal(m1[4].view(np.uint32), m0[4].view(np.uint32))
+    # now mark the mid entity: it and everything below it move, nothing above
+    ow.mark_dirty([int(ow.dense_entities()[4])])
+    ow.transform_system()
+    m2 = ow.world_matrices()
+    moved = set(np.flatnonzero((m2 != m1).any(axis=1)))
+    assert moved == {4, 6, 8, 10}
+    pos = w.pos.copy(); pos[4, 0] = 99.0
+    want, _, _ = onp.transform_system(pos, w.rot, w.scale, w.parent, np.ones(w.n, bool), np.tile(IDENT, (w.n, 1)))
+    assert np.array_equal(m2.view(np.uint32), want.view(np.uint32))
+    ow.close()
+
+
+def test_invalid_parent_detaches_and_marks_dirty(oracle):
+    w = worlds.random_world(64, seed=5, p_child=0.0)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    ents = ow.dense_entities()
+    ow.get_transform(int(ents[10])).parent = int(ents[3])
+    ow.get_transform(int(ents[11])).parent = int(ents[11])          # self parent
+    ow.get_transform(int(ents[12])).parent = 0x00ABCDEF             # never created
+    ow.transform_system()
+    ow.destroy(int(ents[3]))                                        # parent dies; swap-remove moves the last entity into slot 3
+    t10 = ow.get_transform(int(ents[10])); t10.dirty = 0
+    ow.transform_system()
+    par = {int(e): int(p) for e, p in zip(ow.dense_entities(), ow.parents())}
+    assert par[int(ents[10])] == 0xFFFFFFFF and par[int(ents[11])] == 0xFFFFFFFF and par[int(ents[12])] == 0xFFFFFFFF
+    # detached entity was rebuilt as a root
+    got = ow.get_transform(int(ents[10]))
+    assert beq(list(got.worldMatrix), oracle.mat4_trs(w.pos[10], w.rot[10], w.scale[10]))
+    assert list(ow.dense_entities()[:4] & 0xFFFFFF) == [0, 1, 2, 63]
+    ow.close()
+
+
+def test_cycle_members_are_never_updated(oracle):
+    w = worlds.random_world(16, seed=6, p_child=0.0)
+    w.parent[5], w.parent[6], w.parent[7] = 6, 5, 6          # 5 <-> 6 cycle, 7 hangs below it
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    ow.transform_system()
+    m, d = ow.world_matrices(), ow.dirty()
+    for k in (5, 6, 7):
+        assert beq(m[k], IDENT) and d[k] == 1                 # still the default matrix, still dirty
+    assert not d[[i for i in range(16) if i not in (5, 6, 7)]].any()
+    ow.close()
+
+
+def test_zero_scale_repair(oracle):
+    w = worlds.random_world(8, seed=7, p_child=0.0)
+    w.scale[2] = 0
+    w.scale[3] = (0, 1, 0)                                    # only all-zero is repaired
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    ow.transform_system()
+    s = ow.local_scales()
+    assert beq(s[2], (1, 1, 1)) and beq(s[3], (0, 1, 0))
+    ow.close()
+
+
+def test_camera_frustum_and_culling_match_numpy_witness(oracle):
+    for name in ("config1",):
+        w = sw.config(name)
+        ow = worlds.oracle_world(oracle, w)
+        ow.tick()
+        vp = np.array(ow.cam.viewProj[:], np.float32)
+        planes = onp.frustum_from_viewproj(vp)
+        assert np.array_equal(ow.frustum_planes().view(np.uint32), planes.view(np.uint32))
+        mats = ow.world_matrices()[:w.n]
+        mask = onp.cull(mats, w.bmin, w.bmax, w.has_bounds, planes)
+        assert np.array_equal(ow.visibility_mask(), mask)
+        assert np.array_equal(ow.visible(), np.flatnonzero(mask).astype(np.uint32))
+        assert 0 < len(ow.visible()) < w.n
+        assert len(ow.visible()) + len(ow.culled()) == len(ow.candidates()) == w.n
+        ow.close()
+
+
+def test_culling_rules(oracle):
+    w = worlds.random_world(500, seed=8, p_no_bounds=0.3, p_no_mesh=0.3)
+    ow = worlds.oracle_world(oracle, w)
+    ow.tick()
+    cand = ow.candidates()
+    assert np.array_equal(cand, np.flatnonzero(w.has_mesh).astype(np.uint32))       # dense order, RenderMesh only
+    vis = set(int(v) for v in ow.visible())
+    for i in np.flatnonzero(w.has_mesh & (1 - w.has_bounds)):
+        assert int(i) in vis                                                         # no Bounds => visible
+    # order of visible / culled is the candidates' order
+    assert list(ow.visible()) == sorted(vis) and list(ow.culled()) == sorted(int(c) for c in ow.culled())
+    ow.culling_system(freeze=True)
+    assert np.array_equal(ow.visible(), cand) and len(ow.culled()) == 0
+    ow.close()
+
+
+def test_draw_list_budget(oracle):
+    w = sw.config("config1")
+    ow = worlds.oracle_world(oracle, w)
+    ow.tick()
+    v = ow.visible()
+    ent, mesh, mat, model, dropped = ow.draw_items(max_draws=0)
+    assert np.array_equal(ent, v) and dropped == 0
+    assert np.array_equal(mesh, w.mesh[v]) and np.array_equal(mat, w.material[v])
+    assert np.array_equal(model.view(np.uint32), ow.world_matrices()[v].view(np.uint32))
+    ent2, _, _, _, dropped2 = ow.draw_items(max_draws=10)
+    assert np.array_equal(ent2, v[:10]) and dropped2 == len(v) - 10
+    ow.close()
+
+
+def test_world_to_sector(oracle):
+    assert oracle.world_to_sector(64.0, 0.0, 0.0) == (0, 0)
+    assert oracle.world_to_sector(64.0, -0.001, 63.999) == (-1, 0)
+    assert oracle.world_to_sector(64.0, 64.0, 128.0) == (1, 2)
+    assert oracle.world_to_sector(16.0, -16.0, -16.0001) == (-1, -2)
+
+
+def test_broadphase_grid_equals_bruteforce(oracle):
+    for seed in range(4):
+        w = worlds.random_world(700, seed=20 + seed, spread=60.0)
+        w.bmin[:20] *= 12.0                                   # a few large boxes spanning many cells
+        w.bmax[:20] *= 12.0
+        w.bmax[20:23] *= 4000.0                               # and three absurdly large ones
+        ow = worlds.oracle_world(oracle, w, camera=False)
+        ow.transform_system()
+        mn, mx = ow.world_aabbs()
+        wmn, wmx = onp.world_aabb(ow.world_matrices(), w.bmin, w.bmax)
+        hb = w.has_bounds.astype(bool)
+        assert np.array_equal(mn[hb].view(np.uint32), wmn[hb].view(np.uint32)) and np.array_equal(mx[hb].view(np.uint32), wmx[hb].view(np.uint32))
+        assert np.isinf(mn[~hb]).all()
+        bf = oracle.broadphase_bruteforce(mn, mx, w.group, w.mask)
+        for cell in (4.0, 16.0, 64.0):
+            assert np.array_equal(oracle.broadphase_grid(mn, mx, w.group, w.mask, cell), bf)
+        assert len(bf) > 10
+        # filter semantics: (gi & mj) && (gj & mi)
+        for i, j in bf[:200]:
+            assert (w.group[i] & w.mask[j]) and (w.group[j] & w.mask[i])
+        ow.close()
+
+
+@pytest.mark.parametrize("workers", [0, 3])
+def test_job_pool_gives_same_mask(oracle, workers):
+    w = sw.config("config1")
+    oracle.lib().orc_jobs_init(workers)
+    try:
+        ow = worlds.oracle_world(oracle, w)
+        ow.tick()
+        got = ow.visible().copy()
+        ow.close()
+    finally:
+        oracle.lib().orc_jobs_init(0)
+    ow = worlds.oracle_world(oracle, w)
+    ow.tick()
+    assert np.array_equal(got, ow.visible())
+    ow.close()
