@@ -27,13 +27,16 @@ TILE_GRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
 
 
 def algorithmic_bytes_per_entity(child_frac, stages):
-    """SURVEY.md 8d: xform 88 + 48*C/N; cull +24 (+4*V/N, written by the compaction kernel);
-    broadphase +128 (+8*P/N)."""
+    """Per-launch algorithmic bytes of the dominant kernel k_xform_cull:
+    xform 88 + 48*C/N (SURVEY 8d); cull +24 (bounds; the 4*V/N index list is written by k_compact);
+    broadphase +32 (the AABB record written into its sector bin; bounds are read once for both).
+    SURVEY 8d's further 96 B/entity of broadphase traffic (dense AABB array, sort scatter) do not
+    exist in this design -- boxes are binned directly -- and are NOT counted anywhere."""
     b = 88.0 + 48.0 * child_frac
-    if "cull" in stages:
+    if "cull" in stages or "broadphase" in stages:
         b += 24.0
     if "broadphase" in stages:
-        b += 128.0 - (24.0 if "cull" in stages else 0.0) + (24.0 if "cull" in stages else 0.0)
+        b += 32.0
     return b
 
 
@@ -74,6 +77,7 @@ def main():
     ap.add_argument("--sectors", type=int, default=TILE_SECTORS, help="tile side in sectors (default 256 = 1M entities per GPU)")
     ap.add_argument("--stages", default="auto", help="comma list of xform,cull,broadphase (auto = all that are built)")
     ap.add_argument("--graph", type=int, default=0, help="replay the frame from a hipGraph")
+    ap.add_argument("--sample", type=int, default=8, help="record HIP events on every n-th step (1 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -128,7 +132,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    t.set_profiling(True)
+    t.set_profiling(args.sample)          # HIP events on every n-th tick, inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -138,7 +142,7 @@ def main():
     k2 = t.kernel_times_ms(capi.K_COMPACT)
     kn = t.kernel_times_ms(capi.K_NUDGE)
     kp = t.kernel_times_ms(capi.K_PAIRS)
-    t.set_profiling(False)
+    t.set_profiling(0)
     counts = t.counts()
 
     if world_size > 1:
@@ -149,7 +153,7 @@ def main():
     if rank == 0:
         n_total = w.n * world_size
         child_frac = float((w.parent >= 0).mean())
-        bpe = algorithmic_bytes_per_entity(child_frac, [s for s in stages if s != "broadphase"])
+        bpe = algorithmic_bytes_per_entity(child_frac, stages)
         k1_ms = float(np.mean(k1)) if len(k1) else float("nan")
         achieved = (w.n * bpe) / (k1_ms * 1e-3) / 1e9 if len(k1) else None
         out = {
@@ -181,7 +185,7 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": None,
-                "bytes_per_entity": bpe, "avg_launch_ms": k1_ms,
+                "bytes_per_entity": bpe, "avg_launch_ms": k1_ms, "launches_timed": int(len(k1)),
                 "other_kernels_ms": {"k_compact": float(np.mean(k2)) if len(k2) else None,
                                      "k_nudge_roots_x": float(np.mean(kn)) if len(kn) else None,
                                      "k_pairs": float(np.mean(kp)) if len(kp) else None},

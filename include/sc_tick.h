@@ -50,6 +50,7 @@ enum {
   SC_TICK_BROADPHASE  = 1u << 2,   /* world AABBs + grid pair search */
   SC_TICK_CULLED_LIST = 1u << 3,   /* also build CullingState::culled */
   SC_TICK_DRAWS       = 1u << 4,   /* RenderPrepStreamingSystem draw list from the visible list */
+  SC_TICK_DENSE_AABBS = 1u << 5,   /* with BROADPHASE: also keep per-entity world AABBs for scTickReadWorldAabbs */
   SC_TICK_FULL        = SC_TICK_XFORM | SC_TICK_CULL | SC_TICK_BROADPHASE
 };
 
@@ -81,8 +82,8 @@ typedef struct ScTickCounts    /* CullingStats (sc_world_partition.h:334-339) + 
   uint32_t draws_dropped;
   uint32_t max_depth;          /* deepest hierarchy level after scTickSetTopology */
   uint32_t unreachable;        /* entities in or below a parent cycle (never updated, sc_ecs.cpp:173-210) */
-  uint32_t bin_overflow;       /* broadphase entities that did not fit a sector bin and took the slow list */
-  uint32_t reserved;
+  uint32_t bin_overflow;       /* broadphase boxes that found a sector bin full (they take the big list) */
+  uint32_t big_boxes;          /* boxes in the big list: larger than 2x2 sectors, outside the tile rectangle, or bin full */
 } ScTickCounts;
 
 typedef struct ScTickDrawItem  /* DrawItem, sc_ecs.h:159-165: 80 bytes, model at offset 16, column-major */
@@ -178,7 +179,8 @@ int scTickHostCameraViewProj(const float camera_world[16], float fov_y_degrees, 
                              float z_near, float z_far, float out_view_proj[16]);
 
 /* ---- measurement ---- */
-/* record HIP events around every kernel launch (on the context's stream) from now on / stop */
+/* record HIP events around the kernel launches (on the context's stream) of every `enable`-th tick
+ * from now on (1 = every tick; event records cost host time, so long runs sample); 0 = stop */
 int scTickSetProfiling(ScTickContext* ctx, int enable);
 /* durations (ms) of the launches of `kernel` recorded since profiling was enabled; synchronises */
 int scTickGetKernelTimes(ScTickContext* ctx, uint32_t kernel, float* ms, uint32_t capacity, uint32_t* count);

@@ -10,11 +10,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsc_tick.so")
 
 # scTickRun flags (include/sc_tick.h)
-XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS = 1, 2, 4, 8, 16
+XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS, DENSE_AABBS = 1, 2, 4, 8, 16, 32
 FULL = XFORM | CULL | BROADPHASE
 K_XFORM_CULL, K_COMPACT, K_PAIRS, K_NUDGE, K_COUNT = 0, 1, 2, 3, 4
 NO_PARENT = -1
-HAVE_PAIR_SEARCH = False      # flipped when the broadphase pair kernels are in the library
+HAVE_PAIR_SEARCH = True       # flipped when the broadphase pair kernels are in the library
 
 F32P = C.POINTER(C.c_float)
 U32P = C.POINTER(C.c_uint32)
@@ -34,7 +34,7 @@ class ContextDesc(C.Structure):
 class Counts(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "entities", "renderables_total", "visible", "culled", "pairs", "pairs_truncated",
-        "draws_emitted", "draws_dropped", "max_depth", "unreachable", "bin_overflow", "reserved")]
+        "draws_emitted", "draws_dropped", "max_depth", "unreachable", "bin_overflow", "big_boxes")]
 
 
 class DrawItem(C.Structure):

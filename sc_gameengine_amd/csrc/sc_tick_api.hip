@@ -48,7 +48,7 @@ struct ScTickContext
   int frustumValid = 0;
   int freeze = 0;
 
-  uint32_t spansWanted = 2048;
+  uint32_t spansWanted = 1536;
   uint32_t lastFlags = 0;
 
   // scratch device buffers for indexed read-back
@@ -57,15 +57,21 @@ struct ScTickContext
 
   // profiling
   bool profiling = false;
+  uint32_t profPeriod = 1;     // record events on every profPeriod-th tick only (event records are not free)
+  uint64_t tickIndex = 0;
   std::vector<EventPair> times[SC_TICK_K_COUNT];
   std::vector<EventPair> eventPool;
 
   // graph
   bool graphMode = false;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graphExec = nullptr;
-  TickParams graphParams{};
-  uint64_t topoEpoch = 0, graphEpoch = ~0ull;
+  hipGraph_t graph[2] = { nullptr, nullptr };          // one per broadphase tick parity
+  hipGraphExec_t graphExec[2] = { nullptr, nullptr };
+  TickParams graphParams[2]{};
+  uint64_t topoEpoch = 0, graphEpoch[2] = { ~0ull, ~0ull };
+
+  // broadphase
+  uint32_t sectors = 0, maxPairs = 0;
+  uint32_t parity = 0, lastParity = 0;
 };
 
 namespace {
@@ -257,7 +263,7 @@ EventPair takeEvents(ScTickContext* c)
 struct Scoped
 {
   ScTickContext* c; uint32_t k; EventPair p; bool on;
-  Scoped(ScTickContext* c_, uint32_t k_) : c(c_), k(k_), on(c_->profiling)
+  Scoped(ScTickContext* c_, uint32_t k_) : c(c_), k(k_), on(c_->profiling && (c_->tickIndex % c_->profPeriod) == 0)
   {
     if (on) { p = takeEvents(c); hipEventRecord(p.a, c->stream); }
   }
@@ -269,11 +275,20 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   std::memset(&p, 0, sizeof p);
   p.n = c->n;
   computeSpan(c, p.span, grid);
-  p.flags = flags & 0xFFFFu;
+  p.flags = flags & 0xFFFFu;        // SC_TICK_DENSE_AABBS == kFlagDenseAabbs
   if (c->levelOffsets.size() > 1 && (flags & SC_TICK_XFORM)) p.flags |= kFlagHasDeep;
   p.freeze = c->freeze ? 1u : 0u;
   p.frustumValid = c->frustumValid ? 1u : 0u;
   p.fr = c->frustum;
+  // the bin grid is the tile plus a ring of one sector: boxes that poke over the tile edge stay
+  // binnable, and on a multi-GPU world the ring is where a neighbour's border boxes land
+  p.binOx = (float)c->desc.tile_origin_x - 1.0f;
+  p.binOz = (float)c->desc.tile_origin_z - 1.0f;
+  p.invSector = 1.0f / c->desc.sector_size;                 // worldToSector, sc_world_partition.cpp:270
+  p.binSX = c->desc.tile_sectors_x ? c->desc.tile_sectors_x + 2u : 0u;
+  p.binSZ = c->desc.tile_sectors_x ? c->desc.tile_sectors_z + 2u : 0u;
+  p.parity = c->parity;
+  p.maxPairs = c->maxPairs;
 }
 
 void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool allowProfile)
@@ -296,14 +311,21 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     Scoped s(c, SC_TICK_K_COMPACT);
     launchCompact(c->d, p, grid, c->stream);
   }
+  if (flags & SC_TICK_BROADPHASE) {
+    Scoped s(c, SC_TICK_K_PAIRS);
+    launchPairs(c->d, p, c->stream);
+  }
   if ((flags & SC_TICK_DRAWS) && (flags & SC_TICK_CULL)) launchEmitDraws(c->d, c->desc.max_draws_budget, c->dDraws, c->stream);
   c->profiling = saved;
 }
 
-void dropGraph(ScTickContext* c)
+void dropGraph(ScTickContext* c, int q = -1)
 {
-  if (c->graphExec) { hipGraphExecDestroy(c->graphExec); c->graphExec = nullptr; }
-  if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+  for (int k = 0; k < 2; ++k) {
+    if (q >= 0 && k != q) continue;
+    if (c->graphExec[k]) { hipGraphExecDestroy(c->graphExec[k]); c->graphExec[k] = nullptr; }
+    if (c->graph[k]) { hipGraphDestroy(c->graph[k]); c->graph[k] = nullptr; }
+  }
 }
 
 void rowsToMat4(const float* r12, float* m16)
@@ -351,8 +373,16 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
           && dalloc(c, d.w0, N) && dalloc(c, d.w1, N) && dalloc(c, d.w2, N)
           && dalloc(c, d.vis, N / 64) && dalloc(c, d.cand, N / 64) && dalloc(c, d.recomp, N / 64)
           && dalloc(c, d.blockVis, N / kTile) && dalloc(c, d.blockCand, N / kTile)
-          && dalloc(c, d.visibleIdx, N) && dalloc(c, d.culledIdx, N) && dalloc(c, d.counters, 16)
+          && dalloc(c, d.visibleIdx, N) && dalloc(c, d.culledIdx, N) && dalloc(c, d.counters, 32)
           && dalloc(c, d.aabbMin, N) && dalloc(c, d.aabbMax, N);
+  c->sectors = desc->tile_sectors_x ? (desc->tile_sectors_x + 2u) * (desc->tile_sectors_z + 2u) : 0u;
+  c->maxPairs = desc->max_pairs ? desc->max_pairs : desc->capacity * 4u;
+  if (ok && c->sectors) {
+    if ((uint64_t)desc->tile_sectors_x * desc->tile_sectors_z > (1u << 24)) ok = fail(c, "tile rectangle too large");
+    ok = ok && dalloc(c, d.binCount, c->sectors) && dalloc(c, d.bins, (size_t)c->sectors * kBinCap * 2u, false)
+            && dalloc(c, d.bigList, N * 2u, false) && dalloc(c, d.bigBits[0], N / 32) && dalloc(c, d.bigBits[1], N / 32)
+            && dalloc(c, d.pairs, c->maxPairs, false);
+  }
   if (ok) { void* p = nullptr; e = hipMalloc(&p, N * sizeof(ScTickDrawItem)); if (e != hipSuccess) ok = fail(c, "hipMalloc draws", e); else { c->allocs.push_back(p); c->dDraws = p; } }
   if (ok) {
     // Transform{}: worldMatrix = identity, scale = 1, cos = 1 (sc_ecs.h:63-71)
@@ -582,20 +612,23 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   fillParams(c, flags, p, grid);
   c->lastFlags = flags;
 
+  const uint32_t q = (flags & SC_TICK_BROADPHASE) ? c->parity : 0u;
   if (c->graphMode && !c->profiling) {
-    const bool stale = !c->graphExec || c->graphEpoch != c->topoEpoch || std::memcmp(&p, &c->graphParams, sizeof p) != 0;
+    const bool stale = !c->graphExec[q] || c->graphEpoch[q] != c->topoEpoch || std::memcmp(&p, &c->graphParams[q], sizeof p) != 0;
     if (stale) {
-      dropGraph(c);
+      dropGraph(c, (int)q);
       HIP_OK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       enqueueStages(c, p, grid, false);
-      HIP_OK(c, hipStreamEndCapture(c->stream, &c->graph));
-      HIP_OK(c, hipGraphInstantiate(&c->graphExec, c->graph, nullptr, nullptr, 0));
-      c->graphParams = p; c->graphEpoch = c->topoEpoch;
+      HIP_OK(c, hipStreamEndCapture(c->stream, &c->graph[q]));
+      HIP_OK(c, hipGraphInstantiate(&c->graphExec[q], c->graph[q], nullptr, nullptr, 0));
+      c->graphParams[q] = p; c->graphEpoch[q] = c->topoEpoch;
     }
-    HIP_OK(c, hipGraphLaunch(c->graphExec, c->stream));
+    HIP_OK(c, hipGraphLaunch(c->graphExec[q], c->stream));
   } else {
     enqueueStages(c, p, grid, true);
   }
+  if (flags & SC_TICK_BROADPHASE) { c->lastParity = c->parity; c->parity ^= 1u; }
+  c->tickIndex++;
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, "kernel launch", e);
   return 1;
@@ -621,16 +654,18 @@ int scTickGetCounts(ScTickContext* c, ScTickCounts* out)
 {
   if (!c || !out) return c ? fail(c, "null argument") : 0;
   if (!bind(c)) return 0;
-  uint32_t k[16] = {};
+  uint32_t k[32] = {};
   if (!d2h(c, k, c->d.counters, sizeof k) || !sync(c)) return 0;
   std::memset(out, 0, sizeof *out);
+  const uint32_t* bp = k + kCtrPar + 8u * c->lastParity;
   out->entities = c->n;
   out->renderables_total = k[6];
   out->visible = k[0];
   out->culled = k[1];
-  out->pairs = k[2];
-  out->pairs_truncated = 0;
-  out->bin_overflow = k[3];
+  out->pairs = bp[kCtrPairs];
+  out->pairs_truncated = bp[kCtrPairs] > c->maxPairs ? 1u : 0u;
+  out->bin_overflow = bp[kCtrBinFull];
+  out->big_boxes = bp[kCtrBig];
   out->draws_emitted = k[4];
   out->draws_dropped = k[5];
   out->max_depth = c->maxDepth;
@@ -735,6 +770,8 @@ int scTickReadWorldAabbs(ScTickContext* c, uint32_t first, uint32_t count, float
 {
   if (!c || !min3 || !max3) return c ? fail(c, "null argument") : 0;
   if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if ((c->lastFlags & (SC_TICK_BROADPHASE | SC_TICK_DENSE_AABBS)) != (SC_TICK_BROADPHASE | SC_TICK_DENSE_AABBS))
+    return fail(c, "the last scTickRun did not request SC_TICK_BROADPHASE | SC_TICK_DENSE_AABBS");
   if (!count) return 1;
   std::vector<float4> a(count), b(count);
   if (!d2h(c, a.data(), c->d.aabbMin + first, (size_t)count * 16u) || !d2h(c, b.data(), c->d.aabbMax + first, (size_t)count * 16u) || !sync(c)) return 0;
@@ -748,9 +785,15 @@ int scTickReadWorldAabbs(ScTickContext* c, uint32_t first, uint32_t count, float
 int scTickReadPairs(ScTickContext* c, uint32_t* pairs2, uint32_t cap, uint32_t* count)
 {
   if (!c || !count) return c ? fail(c, "null argument") : 0;
-  (void)pairs2; (void)cap;
-  *count = 0;
-  return fail(c, "pair search not built yet");
+  if (!bind(c)) return 0;
+  if (!(c->lastFlags & SC_TICK_BROADPHASE)) return fail(c, "the last scTickRun did not request SC_TICK_BROADPHASE");
+  uint32_t k[32] = {};
+  if (!d2h(c, k, c->d.counters, sizeof k) || !sync(c)) return 0;
+  const uint32_t total = k[kCtrPar + 8u * c->lastParity + kCtrPairs];
+  *count = total;
+  const uint32_t take = std::min(std::min(total, c->maxPairs), cap);
+  if (take && pairs2) { if (!d2h(c, pairs2, c->d.pairs, (size_t)take * 8u) || !sync(c)) return 0; }
+  return 1;
 }
 
 int scTickReadDraws(ScTickContext* c, ScTickDrawItem* items, uint32_t cap, uint32_t* count)
@@ -775,6 +818,8 @@ int scTickSetProfiling(ScTickContext* c, int enable)
     for (auto& v : c->times) { for (auto& p : v) c->eventPool.push_back(p); v.clear(); }
   }
   c->profiling = enable != 0;
+  c->profPeriod = enable > 1 ? (uint32_t)enable : 1u;
+  c->tickIndex = 0;
   return 1;
 }
 

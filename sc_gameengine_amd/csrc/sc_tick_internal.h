@@ -49,8 +49,18 @@ struct DeviceState {
   uint32_t* culledIdx;
   uint32_t* counters;       // [0] visible total, [1] culled total, [2] pairs, [3] bin overflow, [4] draws, [5] dropped
   // broadphase
-  float4 *aabbMin, *aabbMax;   // world AABB, .w of min carries the packed layers (as bits)
+  float4 *aabbMin, *aabbMax;   // dense-order world AABBs (debug / read-back only: SC_TICK_DENSE_AABBS)
+  uint32_t* binCount;          // records per sector bin (self-cleaning: the pair kernel zeroes what it read)
+  float4* bins;                // [sector][kBinCap][2]: (min.xyz, layers) (max.xyz, id | primary<<31)
+  float4* bigList;             // [cap][2] boxes that cannot be binned (too large, outside the rect, bin full)
+  uint32_t* bigBits[2];        // per-entity "is in the big list" bit, double-buffered by tick parity
+  uint2* pairs;                // (a, b) dense indices, a < b
 };
+
+constexpr uint32_t kBinCap = 64;          // one wave lane per record of a bin
+constexpr uint32_t kPrimary = 0x80000000u;
+// counters[]: 0 visible, 1 culled, 4 draws, 5 dropped, 6 renderables; per tick parity q: 8+8q+{0 pairs, 1 big, 2 bin-full}
+constexpr uint32_t kCtrPar = 8, kCtrPairs = 0, kCtrBig = 1, kCtrBinFull = 2;
 
 struct TickParams {
   uint32_t n;               // entities
@@ -59,13 +69,20 @@ struct TickParams {
   uint32_t freeze;          // CullingState::freezeCulling
   uint32_t frustumValid;
   Frustum6 fr;
+  // broadphase grid: sectors [binOx, binOx+binSX) x [binOz, binOz+binSZ), keyed like worldToSector
+  float binOx, binOz, invSector;
+  uint32_t binSX, binSZ;
+  uint32_t parity;          // tick parity: selects the counter set and bigBits buffer
+  uint32_t maxPairs;
 };
 constexpr uint32_t kFlagHasDeep = 1u << 16;   // write recomp bits for the level kernels
+constexpr uint32_t kFlagDenseAabbs = 1u << 5; // == SC_TICK_DENSE_AABBS
 
 // launchers (sc_tick_kernels.hip)
 void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
+void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s);
 void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, hipStream_t s);
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);

@@ -130,13 +130,134 @@ __device__ __forceinline__ void worldAabb(const Aff& M, const BoundsCE& b, float
   mx[0] = c0 + h0; mx[1] = c1 + h1; mx[2] = c2 + h2;
 }
 
-__device__ __forceinline__ void storeAabb(const DeviceState& d, uint32_t i, bool hasBounds, const Aff& M, const BoundsCE& b)
+// ------------------------------------------------------------------------------------------
+// Broadphase binning.  A box is entered into every sector its xz range
+// [floor(min*inv), floor(max*inv)] touches (worldToSector arithmetic, sc_world_partition.cpp:268-275)
+// when that is at most 2x2 sectors inside the grid rectangle; a pair is later reported only from
+// the sector holding the low corner of the two boxes' intersection, so every bin is self-contained:
+// no halo, no duplicate.  Anything else (larger, outside the rectangle, bin full) goes to the
+// "big" list, which the pair kernel tests against everything.
+// ------------------------------------------------------------------------------------------
+struct BinPlan { bool collide, big; float x0, z0; uint32_t nx, nz; };
+
+__device__ __forceinline__ BinPlan planBins(const TickParams& p, const float mn[3], const float mx[3])
+{
+  BinPlan b; b.collide = false; b.big = false; b.x0 = b.z0 = 0.0f; b.nx = b.nz = 0;
+  // a NaN bound overlaps nothing under the closed-interval test: no collider
+  if (!(mn[0] == mn[0] && mn[1] == mn[1] && mn[2] == mn[2] && mx[0] == mx[0] && mx[1] == mx[1] && mx[2] == mx[2])) return b;
+  b.collide = true;
+  const float x0 = floorf(mn[0] * p.invSector) - p.binOx, x1 = floorf(mx[0] * p.invSector) - p.binOx;
+  const float z0 = floorf(mn[2] * p.invSector) - p.binOz, z1 = floorf(mx[2] * p.invSector) - p.binOz;
+  const float nx = x1 - x0 + 1.0f, nz = z1 - z0 + 1.0f;
+  const bool ok = x0 >= 0.0f && z0 >= 0.0f && x1 < (float)p.binSX && z1 < (float)p.binSZ &&
+                  nx >= 1.0f && nx <= 2.0f && nz >= 1.0f && nz <= 2.0f;
+  if (!ok) { b.big = true; return b; }
+  b.x0 = x0; b.z0 = z0; b.nx = (uint32_t)nx; b.nz = (uint32_t)nz;
+  return b;
+}
+
+__device__ __forceinline__ void appendBig(const DeviceState& d, const TickParams& p, const float4& rmin, const float4& rmax)
+{
+  const uint32_t slot = atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBig], 1u);
+  d.bigList[2u * (size_t)slot] = rmin;
+  d.bigList[2u * (size_t)slot + 1u] = rmax;
+}
+
+// One insertion round for the whole wave (must be called by all 64 lanes).  Consecutive lanes that
+// target the same sector form a run; the run's first lane reserves the slots with ONE atomic.
+__device__ __forceinline__ void binInsertWave(const DeviceState& d, bool want, uint32_t sector,
+                                              const float4& rmin, const float4& rmax, bool& binFull)
+{
+  const unsigned long long act = __ballot(want);
+  if (!act) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t key = want ? sector : 0xFFFFFFFFu;
+  const uint32_t prev = __shfl_up(key, 1, 64);
+  const bool head = want && (lane == 0 || prev != key);
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long upto = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
+  const uint32_t myHead = (63u - (uint32_t)__clzll(heads & upto)) & 63u;
+  const unsigned long long above = (myHead == 63u) ? 0ull : ~((2ull << myHead) - 1ull);
+  const unsigned long long ends = (heads | ~act) & above;
+  const uint32_t runEnd = ends ? (uint32_t)__ffsll((long long)ends) - 1u : 64u;
+  uint32_t base = 0;
+  if (head) base = atomicAdd(&d.binCount[sector], runEnd - lane);
+  base = __shfl(base, myHead, 64);
+  if (want) {
+    const uint32_t slot = base + (lane - myHead);
+    if (slot < kBinCap) {
+      float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
+      r[0] = rmin; r[1] = rmax;
+    } else binFull = true;
+  }
+}
+
+// Whole-wave broadphase step for one entity per lane: world AABB -> bins / big list.
+__device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickParams& p, uint32_t i, bool collider,
+                                              const Aff& M, const BoundsCE& b)
+{
+  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  BinPlan plan; plan.collide = false; plan.big = false; plan.x0 = plan.z0 = 0.0f; plan.nx = plan.nz = 0;
+  float4 rmin = make_float4(0, 0, 0, 0), rmax = make_float4(0, 0, 0, 0);
+  if (collider) {
+    worldAabb(M, b, mn, mx);
+    plan = planBins(p, mn, mx);
+    rmin = make_float4(mn[0], mn[1], mn[2], __uint_as_float(d.layers[i]));
+    rmax = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i));
+    if (p.flags & kFlagDenseAabbs) { d.aabbMin[i] = rmin; d.aabbMax[i] = rmax; }
+  } else if ((p.flags & kFlagDenseAabbs) && i < p.n) {
+    d.aabbMin[i] = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
+    d.aabbMax[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, __uint_as_float(i));
+  }
+  const bool binned = plan.collide && !plan.big;
+  bool binFull = false;
+  const uint32_t sx = (uint32_t)plan.x0, sz = (uint32_t)plan.z0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint32_t dx = k & 1u, dz = k >> 1;
+    const bool want = binned && dx < plan.nx && dz < plan.nz;
+    float4 rm = rmax;
+    if (k == 0) rm.w = __uint_as_float(i | kPrimary);        // exactly one primary copy per box
+    binInsertWave(d, want, (sz + dz) * p.binSX + (sx + dx), rmin, rm, binFull);
+  }
+  if (plan.collide && plan.big) appendBig(d, p, rmin, rmax);
+  if (binFull) {
+    // partially binned: flag it so the pair kernel ignores its copies, and hand it to the big list once
+    const uint32_t bit = 1u << (i & 31u);
+    const uint32_t old = atomicOr(&d.bigBits[p.parity][i >> 5], bit);
+    if (!(old & bit)) { appendBig(d, p, rmin, rmax); atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBinFull], 1u); }
+  }
+}
+
+// Same for a single lane (level kernels: entities of one level are scattered, no runs to aggregate).
+__device__ __forceinline__ void binEntitySingle(const DeviceState& d, const TickParams& p, uint32_t i, const Aff& M, const BoundsCE& b)
 {
   float mn[3], mx[3];
-  if (hasBounds) worldAabb(M, b, mn, mx);
-  else { mn[0] = mn[1] = mn[2] = INFINITY; mx[0] = mx[1] = mx[2] = -INFINITY; }
-  d.aabbMin[i] = make_float4(mn[0], mn[1], mn[2], __uint_as_float(d.layers[i]));
-  d.aabbMax[i] = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i));
+  worldAabb(M, b, mn, mx);
+  const BinPlan plan = planBins(p, mn, mx);
+  const float4 rmin = make_float4(mn[0], mn[1], mn[2], __uint_as_float(d.layers[i]));
+  float4 rmax = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i));
+  if (p.flags & kFlagDenseAabbs) { d.aabbMin[i] = rmin; d.aabbMax[i] = rmax; }
+  if (!plan.collide) return;
+  if (plan.big) { appendBig(d, p, rmin, rmax); return; }
+  bool binFull = false;
+  const uint32_t sx = (uint32_t)plan.x0, sz = (uint32_t)plan.z0;
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint32_t dx = k & 1u, dz = k >> 1;
+    if (!(dx < plan.nx && dz < plan.nz)) continue;
+    const uint32_t sector = (sz + dz) * p.binSX + (sx + dx);
+    const uint32_t slot = atomicAdd(&d.binCount[sector], 1u);
+    if (slot < kBinCap) {
+      float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
+      float4 rm = rmax; if (k == 0) rm.w = __uint_as_float(i | kPrimary);
+      r[0] = rmin; r[1] = rm;
+    } else binFull = true;
+  }
+  if (binFull) {
+    const uint32_t bit = 1u << (i & 31u);
+    const uint32_t old = atomicOr(&d.bigBits[p.parity][i >> 5], bit);
+    if (!(old & bit)) { appendBig(d, p, rmin, rmax); atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBinFull], 1u); }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -241,7 +362,11 @@ __global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const
         visCount += (uint32_t)__popcll(vm);
         candCount += (uint32_t)__popcll(cm);
       }
-      if (kAabb && active) storeAabb(d, i, hb, M, b);
+      if (kAabb) {
+        // deeper entities are binned by the level kernels once their matrix is final
+        const bool collider = hb && !(doXform && depth > kMaxChain && depth != kUnreachable);
+        binEntityWave(d, p, i, collider, M, b);
+      }
     }
   }
 
@@ -295,7 +420,13 @@ __global__ __launch_bounds__(kTile) void k_deep_level(const DeviceState d, const
       atomicAdd(&d.blockVis[i / p.span], 1u);
     }
   }
-  if (p.flags & SC_TICK_BROADPHASE) storeAabb(d, i, hb, M, b);
+  if (p.flags & SC_TICK_BROADPHASE) {
+    if (hb) binEntitySingle(d, p, i, M, b);
+    else if (p.flags & kFlagDenseAabbs) {
+      d.aabbMin[i] = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
+      d.aabbMax[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, __uint_as_float(i));
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -369,6 +500,131 @@ __global__ __launch_bounds__(kTile) void k_compact(const DeviceState d, const Ti
     // Transform::dirty = false for every visited entity; entities in a cycle keep theirs
     const uint32_t wBegin = begin >> 5, wEnd = (end + 31u) >> 5;
     for (uint32_t w = wBegin + threadIdx.x; w < wEnd; w += kTile) d.dirty[w] &= d.unreach[w];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: pair search.  One wave per sector bin (grid-stride): the bin's <= 64 records become an LDS
+// tile (lane i stages record i), the n(n-1)/2 record pairs are spread over the 64 lanes, each lane
+// reads its two records from LDS and applies: not the same box, closed-interval overlap on three
+// axes, Bullet's group/mask filter, and "this sector holds the low corner of the intersection".
+// Big boxes are tested against the bin's primary records here too, and against each other.
+// The bin counter is zeroed by the wave that consumed it (self-cleaning for the next tick).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool boxesOverlap(const float4& amin, const float4& amax, const float4& bmin, const float4& bmax)
+{
+  return amin.x <= bmax.x && bmin.x <= amax.x && amin.y <= bmax.y && bmin.y <= amax.y && amin.z <= bmax.z && bmin.z <= amax.z;
+}
+__device__ __forceinline__ bool filterPass(uint32_t la, uint32_t lb)
+{
+  // (a.group & b.mask) && (b.group & a.mask); layers = group | mask << 16
+  return ((la & 0xFFFFu) & (lb >> 16)) != 0u && ((lb & 0xFFFFu) & (la >> 16)) != 0u;
+}
+
+// wave-aggregated append to the pair list; every lane of the wave must call it
+__device__ __forceinline__ void emitPair(const DeviceState& d, const TickParams& p, bool hit, uint32_t ia, uint32_t ib)
+{
+  const unsigned long long m = __ballot(hit);
+  if (!m) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrPairs], (uint32_t)__popcll(m));
+  base = __shfl(base, leader, 64);
+  if (hit) {
+    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (slot < p.maxPairs) d.pairs[slot] = make_uint2(ia < ib ? ia : ib, ia < ib ? ib : ia);
+  }
+}
+
+__global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const TickParams p)
+{
+  __shared__ float4 tile[kTile / 64][2 * kBinCap];        // 2 KiB per wave
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t waveGlobal = blockIdx.x * (kTile / 64) + wave;
+  const uint32_t totalWaves = gridDim.x * (kTile / 64);
+  const uint32_t sectors = p.binSX * p.binSZ;
+  const uint32_t ctr = kCtrPar + 8u * p.parity;
+  const uint32_t nbig = d.counters[ctr + kCtrBig];
+  const uint32_t* bigBits = d.bigBits[p.parity];
+  float4* T = tile[wave];
+
+  // next tick's counter set and big bits start clean
+  if (blockIdx.x == 0 && threadIdx.x < 8) d.counters[kCtrPar + 8u * (p.parity ^ 1u) + threadIdx.x] = 0u;
+  {
+    const uint32_t words = (p.n + 31u) >> 5;
+    uint32_t* nextBits = d.bigBits[p.parity ^ 1u];
+    for (uint32_t w = blockIdx.x * kTile + threadIdx.x; w < words; w += gridDim.x * kTile) nextBits[w] = 0u;
+  }
+
+  for (uint32_t s = waveGlobal; s < sectors; s += totalWaves) {
+    uint32_t n = d.binCount[s];
+    if (n == 0 && nbig == 0) continue;
+    if (n > kBinCap) n = kBinCap;
+    if (lane == 0) d.binCount[s] = 0u;
+    float4 rmin = make_float4(0, 0, 0, 0), rmax = make_float4(0, 0, 0, 0);
+    bool valid = lane < n;
+    if (valid) {
+      const float4* r = d.bins + 2u * ((size_t)s * kBinCap + lane);
+      rmin = r[0]; rmax = r[1];
+      if (nbig) {                                            // partially binned boxes live in the big list
+        const uint32_t id = __float_as_uint(rmax.w) & ~kPrimary;
+        if ((bigBits[id >> 5] >> (id & 31u)) & 1u) valid = false;
+      }
+    }
+    T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
+    __builtin_amdgcn_wave_barrier();
+    const float secX = (float)(s % p.binSX), secZ = (float)(s / p.binSX);
+    const unsigned long long validMask = __ballot(valid);
+
+    const uint32_t npairs = n * (n - 1u) / 2u;
+    for (uint32_t q = lane; q < ((npairs + 63u) & ~63u); q += 64u) {
+      bool hit = false;
+      uint32_t ia = 0, ib = 0;
+      if (q < npairs) {
+        // q -> (i, j), 0 <= j < i < n, q = i(i-1)/2 + j
+        uint32_t i = (uint32_t)((1.0f + sqrtf(8.0f * (float)q + 1.0f)) * 0.5f);
+        while (i * (i - 1u) / 2u > q) --i;
+        while ((i + 1u) * i / 2u <= q) ++i;
+        const uint32_t j = q - i * (i - 1u) / 2u;
+        if (((validMask >> i) & 1ull) && ((validMask >> j) & 1ull)) {
+          const float4 amin = T[2u * i], amax = T[2u * i + 1u], bmin = T[2u * j], bmax = T[2u * j + 1u];
+          ia = __float_as_uint(amax.w) & ~kPrimary; ib = __float_as_uint(bmax.w) & ~kPrimary;
+          if (ia != ib && boxesOverlap(amin, amax, bmin, bmax) && filterPass(__float_as_uint(amin.w), __float_as_uint(bmin.w))) {
+            const float lx = amin.x > bmin.x ? amin.x : bmin.x, lz = amin.z > bmin.z ? amin.z : bmin.z;
+            hit = (floorf(lx * p.invSector) - p.binOx) == secX && (floorf(lz * p.invSector) - p.binOz) == secZ;
+          }
+        }
+      }
+      emitPair(d, p, hit, ia, ib);
+    }
+
+    // big boxes against this bin's primary records (each binned box has exactly one primary copy)
+    const bool mine = valid && (__float_as_uint(rmax.w) & kPrimary);
+    const uint32_t myId = __float_as_uint(rmax.w) & ~kPrimary;
+    for (uint32_t b = 0; b < nbig; ++b) {
+      const float4 gmin = d.bigList[2u * (size_t)b], gmax = d.bigList[2u * (size_t)b + 1u];
+      const uint32_t gid = __float_as_uint(gmax.w);
+      const bool hit = mine && boxesOverlap(rmin, rmax, gmin, gmax) && filterPass(__float_as_uint(rmin.w), __float_as_uint(gmin.w));
+      emitPair(d, p, hit, myId, gid);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // big boxes against each other: wave w takes big b = w, w + totalWaves, ...; lanes sweep the partners after b
+  for (uint32_t b = waveGlobal; b < nbig; b += totalWaves) {
+    const float4 gmin = d.bigList[2u * (size_t)b], gmax = d.bigList[2u * (size_t)b + 1u];
+    for (uint32_t j0 = b + 1u; j0 < nbig; j0 += 64u) {
+      const uint32_t j = j0 + lane;
+      bool hit = false; uint32_t jid = 0;
+      if (j < nbig) {
+        const float4 hmin = d.bigList[2u * (size_t)j], hmax = d.bigList[2u * (size_t)j + 1u];
+        jid = __float_as_uint(hmax.w);
+        hit = boxesOverlap(gmin, gmax, hmin, hmax) && filterPass(__float_as_uint(gmin.w), __float_as_uint(hmin.w));
+      }
+      emitPair(d, p, hit, __float_as_uint(gmax.w), jid);
+    }
   }
 }
 
@@ -453,6 +709,14 @@ void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* 
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
 {
   hipLaunchKernelGGL(k_compact, dim3(grid), dim3(kTile), 0, s, d, p);
+}
+void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s)
+{
+  const uint32_t sectors = p.binSX * p.binSZ;
+  if (!sectors) return;
+  uint32_t grid = (sectors + 3u) / 4u;
+  if (grid > 2048u) grid = 2048u;
+  hipLaunchKernelGGL(k_pairs, dim3(grid), dim3(kTile), 0, s, d, p);
 }
 void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s)
 {

@@ -75,6 +75,7 @@ class WorldTick:
         if not self.ctx:
             raise capi.ScTickError("scTickCreateContext failed: " + (self.lib.scTickGetLastError(None) or b"").decode())
         self.capacity = capacity
+        self.max_pairs = max_pairs if max_pairs else capacity * 4
         self.n = 0
 
     # ---- plumbing ----
@@ -197,8 +198,9 @@ class WorldTick:
     def nudge_roots_x(self, dx):
         self._ok(self.lib.scTickNudgeRootsX(self.ctx, float(dx)), "scTickNudgeRootsX")
 
-    def set_profiling(self, on):
-        self._ok(self.lib.scTickSetProfiling(self.ctx, 1 if on else 0), "scTickSetProfiling")
+    def set_profiling(self, period):
+        """0 = off, n = record HIP events on every n-th tick"""
+        self._ok(self.lib.scTickSetProfiling(self.ctx, int(period)), "scTickSetProfiling")
 
     def set_graph_mode(self, on):
         self._ok(self.lib.scTickSetGraphMode(self.ctx, 1 if on else 0), "scTickSetGraphMode")
@@ -266,7 +268,8 @@ class WorldTick:
     def pairs(self, cap=None):
         cnt = C.c_uint32()
         self._ok(self.lib.scTickReadPairs(self.ctx, None, 0, C.byref(cnt)), "scTickReadPairs")
-        n = cnt.value if cap is None else min(cap, cnt.value)
+        n = min(cnt.value, self.max_pairs)              # the list holds at most max_pairs; cnt is the number found
+        n = n if cap is None else min(cap, n)
         out = np.zeros((max(n, 1), 2), np.uint32)
         if n:
             self._ok(self.lib.scTickReadPairs(self.ctx, _u(out), n, C.byref(cnt)), "scTickReadPairs")

@@ -1,0 +1,146 @@
+"""GPU broadphase against the oracle's brute force / grid (own spec):
+the pair SET must be identical; world AABBs must equal the oracle's as IEEE values."""
+import numpy as np
+import pytest
+
+from sc_gameengine_amd import capi, synth_world as sw
+from sc_gameengine_amd.tick import WorldTick
+from tests import worlds
+
+pytestmark = pytest.mark.gpu
+FLAGS = capi.XFORM | capi.BROADPHASE | capi.DENSE_AABBS
+
+
+def sorted_pairs(p):
+    p = np.asarray(p, np.uint32).reshape(-1, 2)
+    if len(p) == 0:
+        return p
+    k = p[:, 0].astype(np.uint64) << np.uint64(32) | p[:, 1].astype(np.uint64)
+    return p[np.argsort(k)]
+
+
+def gpu_vs_oracle(oracle, w, brute=True, cell=64.0, flags=FLAGS, ticks=1, nudge=None, max_pairs=0):
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    t = WorldTick.from_world(w, broadphase=True, max_pairs=max_pairs)
+    for k in range(ticks):
+        if nudge is not None and k:
+            ow.nudge_roots_x(nudge); t.nudge_roots_x(nudge)
+        ow.transform_system()
+        t.run(flags)
+        mn, mx = ow.world_aabbs()
+        gmn, gmx = t.world_aabbs()
+        assert np.array_equal(gmn, mn) and np.array_equal(gmx, mx)            # IEEE equality, inf for "no Bounds"
+        want = oracle.broadphase_bruteforce(mn, mx, w.group, w.mask) if brute else oracle.broadphase_grid(mn, mx, w.group, w.mask, cell)
+        got, total = t.pairs()
+        assert total == len(want), f"pair count {total} != {len(want)}"
+        assert np.array_equal(sorted_pairs(got), want)
+        assert (got[:, 0] < got[:, 1]).all() if len(got) else True
+    return t, ow
+
+
+def test_random_world_mixed_layers(oracle):
+    w = worlds.random_world(3000, seed=31, spread=150.0, max_depth=3)
+    t, ow = gpu_vs_oracle(oracle, w, ticks=3, nudge=0.7)
+    c = t.counts()
+    assert c.pairs > 50 and c.pairs_truncated == 0
+    t.close(); ow.close()
+
+
+def test_big_boxes_and_outside_rect(oracle):
+    w = worlds.random_world(2500, seed=32, spread=700.0, max_depth=2)      # rect is +-512 m: many boxes fall outside it
+    w.bmin[:40] *= 30.0; w.bmax[:40] *= 30.0                               # larger than 2x2 sectors
+    t, ow = gpu_vs_oracle(oracle, w)
+    c = t.counts()
+    assert c.big_boxes > 100 and c.pairs > 0
+    t.close(); ow.close()
+
+
+def test_bin_overflow_takes_the_slow_path(oracle):
+    w = worlds.random_world(1500, seed=33, spread=300.0, p_child=0.0)
+    w.pos[:300] = np.float32([10.0, 0.0, 10.0]) + np.random.default_rng(1).uniform(-8, 8, (300, 3)).astype(np.float32)  # 300 boxes in one sector
+    t, ow = gpu_vs_oracle(oracle, w)
+    c = t.counts()
+    assert c.bin_overflow > 200 and c.pairs > 1000
+    t.close(); ow.close()
+
+
+def test_deep_chains_broadphase(oracle):
+    w = worlds.chain_world(12, branches=20, seed=34)
+    w.pos[:20] = np.random.default_rng(2).uniform(-100, 100, (20, 3)).astype(np.float32)
+    t, ow = gpu_vs_oracle(oracle, w, ticks=2, nudge=1.5)
+    t.close(); ow.close()
+
+
+def test_synthworld_with_dynamic_layer_vs_cpu_grid(oracle):
+    w = sw.generate(32, 32, 15)                                   # 16 384 entities
+    dyn = (np.arange(w.n) % 5) == 2
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    t, ow = gpu_vs_oracle(oracle, w, brute=False, cell=16.0, ticks=3, nudge=0.5)
+    assert t.counts().big_boxes == 0 and t.counts().pairs > 100        # edge slabs land in the ring, not the big list
+    t.close(); ow.close()
+
+
+def test_all_static_world_reports_no_pairs(oracle):
+    w = sw.generate(16, 16, 15)                                   # static props: group 2 / mask 1 never pass the filter
+    t, ow = gpu_vs_oracle(oracle, w, brute=False, cell=16.0)
+    assert t.counts().pairs == 0
+    t.close(); ow.close()
+
+
+def test_pair_list_truncation_is_reported(oracle):
+    w = worlds.random_world(2000, seed=35, spread=40.0, p_child=0.0)
+    w.group[:] = 1; w.mask[:] = 0xFFFFFFFF
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    ow.transform_system()
+    mn, mx = ow.world_aabbs()
+    want = oracle.broadphase_bruteforce(mn, mx, w.group, w.mask)
+    t = WorldTick.from_world(w, broadphase=True, max_pairs=100)
+    t.run(capi.XFORM | capi.BROADPHASE)
+    got, total = t.pairs()
+    c = t.counts()
+    assert total == len(want) > 100 and len(got) == 100 and c.pairs_truncated == 1
+    wantset = set(map(tuple, want.tolist()))
+    assert all(tuple(p) in wantset for p in got.tolist())
+    t.close(); ow.close()
+
+
+def test_full_tick_all_stages_together(oracle):
+    from sc_gameengine_amd.tick import camera_view_proj
+    w = sw.generate(24, 24, 15)
+    dyn = (np.arange(w.n) % 7) == 3
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    ow = worlds.oracle_world(oracle, w)
+    t = WorldTick.from_world(w, broadphase=True)
+    vp = camera_view_proj(w.camera)
+    t.set_view_proj(vp)
+    for k in range(3):
+        if k:
+            ow.nudge_roots_x(0.3); t.nudge_roots_x(0.3)
+        ow.transform_system(); ow.culling_system(view_proj=vp)
+        t.run(capi.FULL)
+        assert np.array_equal(t.visible(), ow.visible())
+        assert np.array_equal(t.world_matrices(), ow.world_matrices()[:w.n])
+        mn, mx = ow.world_aabbs()
+        want = oracle.broadphase_grid(mn[:w.n], mx[:w.n], w.group, w.mask, 16.0)
+        got, total = t.pairs()
+        assert total == len(want) and np.array_equal(sorted_pairs(got), want)
+    t.close(); ow.close()
+
+
+def test_full_size_1m_pairs_match_cpu_grid(oracle):
+    w = sw.config("config3")
+    dyn = (np.arange(w.n) % 16) == 4                              # one prop per sector is dynamic
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    t = WorldTick.from_world(w, broadphase=True)
+    t.run(FLAGS)
+    gmn, gmx = t.world_aabbs()
+    want = oracle.broadphase_grid(gmn, gmx, w.group, w.mask, 64.0)   # the oracle's search on the device's boxes
+    got, total = t.pairs()
+    assert total == len(want) and np.array_equal(sorted_pairs(got), want)
+    # second tick: the self-cleaning bins and the parity-switched counters give the same answer again
+    t.run(capi.XFORM | capi.BROADPHASE)
+    got2, total2 = t.pairs()
+    assert total2 == total and np.array_equal(sorted_pairs(got2), want)
+    c = t.counts()
+    assert c.big_boxes == 0 and c.bin_overflow == 0
+    t.close()
