@@ -539,7 +539,8 @@ __device__ __forceinline__ void emitPair(const DeviceState& d, const TickParams&
 
 __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const TickParams p)
 {
-  __shared__ float4 tile[kTile / 64][2 * kBinCap];        // 2 KiB per wave
+  __shared__ float4 tile[kTile / 64][2 * kBinCap];        // 2 KiB per wave: the bin as an LDS tile
+  __shared__ uint16_t pairTab[kBinCap * (kBinCap - 1) / 2]; // q -> (i << 8 | j), 0 <= j < i < 64
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t waveGlobal = blockIdx.x * (kTile / 64) + wave;
@@ -550,6 +551,10 @@ __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const Tick
   const uint32_t* bigBits = d.bigBits[p.parity];
   float4* T = tile[wave];
 
+  // triangular pair table, built once per workgroup (row i starts at i(i-1)/2)
+  for (uint32_t i = 1u + threadIdx.x / 64u * 16u; i < kBinCap && i < 17u + threadIdx.x / 64u * 16u; ++i)
+    for (uint32_t j = lane; j < i; j += 64u) pairTab[i * (i - 1u) / 2u + j] = (uint16_t)(i << 8 | j);
+
   // next tick's counter set and big bits start clean
   if (blockIdx.x == 0 && threadIdx.x < 8) d.counters[kCtrPar + 8u * (p.parity ^ 1u) + threadIdx.x] = 0u;
   {
@@ -557,59 +562,84 @@ __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const Tick
     uint32_t* nextBits = d.bigBits[p.parity ^ 1u];
     for (uint32_t w = blockIdx.x * kTile + threadIdx.x; w < words; w += gridDim.x * kTile) nextBits[w] = 0u;
   }
+  __syncthreads();
 
-  for (uint32_t s = waveGlobal; s < sectors; s += totalWaves) {
-    uint32_t n = d.binCount[s];
-    if (n == 0 && nbig == 0) continue;
-    if (n > kBinCap) n = kBinCap;
-    if (lane == 0) d.binCount[s] = 0u;
+  // a wave visits sectors waveGlobal, +totalWaves, ...; their counts are fetched 64 at a time (lane k
+  // holds the k-th) and zeroed at once: this wave is the only consumer of those bins this tick
+  for (uint32_t chunk = waveGlobal; chunk < sectors; chunk += 64u * totalWaves) {
+    const uint32_t mySector = chunk + lane * totalWaves;
+    uint32_t myCount = 0;
+    if (mySector < sectors) { myCount = d.binCount[mySector]; if (myCount) d.binCount[mySector] = 0u; }
+    if (myCount > kBinCap) myCount = kBinCap;
+    const unsigned long long work = __ballot(myCount != 0u);
+    if (!work) continue;
+
+    // software pipeline: records of the next non-empty sector are in flight while this one is tested
+    int it = __ffsll((long long)work) - 1;
+    uint32_t n = __shfl(myCount, it, 64);
     float4 rmin = make_float4(0, 0, 0, 0), rmax = make_float4(0, 0, 0, 0);
-    bool valid = lane < n;
-    if (valid) {
-      const float4* r = d.bins + 2u * ((size_t)s * kBinCap + lane);
+    if (lane < n) {
+      const float4* r = d.bins + 2u * ((size_t)(chunk + (uint32_t)it * totalWaves) * kBinCap + lane);
       rmin = r[0]; rmax = r[1];
-      if (nbig) {                                            // partially binned boxes live in the big list
+    }
+    unsigned long long rest = work & ~(1ull << it);
+    while (it >= 0) {
+      const uint32_t s = chunk + (uint32_t)it * totalWaves;
+      const int itNext = rest ? __ffsll((long long)rest) - 1 : -1;
+      uint32_t nNext = 0;
+      float4 nmin = make_float4(0, 0, 0, 0), nmax = make_float4(0, 0, 0, 0);
+      if (itNext >= 0) {
+        rest &= ~(1ull << itNext);
+        nNext = __shfl(myCount, itNext, 64);
+        if (lane < nNext) {
+          const float4* r = d.bins + 2u * ((size_t)(chunk + (uint32_t)itNext * totalWaves) * kBinCap + lane);
+          nmin = r[0]; nmax = r[1];
+        }
+      }
+
+      bool valid = lane < n;
+      if (valid && nbig) {                                   // partially binned boxes live in the big list
         const uint32_t id = __float_as_uint(rmax.w) & ~kPrimary;
         if ((bigBits[id >> 5] >> (id & 31u)) & 1u) valid = false;
       }
-    }
-    T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
-    __builtin_amdgcn_wave_barrier();
-    const float secX = (float)(s % p.binSX), secZ = (float)(s / p.binSX);
-    const unsigned long long validMask = __ballot(valid);
+      T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
+      __builtin_amdgcn_wave_barrier();
+      const float secX = (float)(s % p.binSX), secZ = (float)(s / p.binSX);
+      const unsigned long long validMask = __ballot(valid);
 
-    const uint32_t npairs = n * (n - 1u) / 2u;
-    for (uint32_t q = lane; q < ((npairs + 63u) & ~63u); q += 64u) {
-      bool hit = false;
-      uint32_t ia = 0, ib = 0;
-      if (q < npairs) {
-        // q -> (i, j), 0 <= j < i < n, q = i(i-1)/2 + j
-        uint32_t i = (uint32_t)((1.0f + sqrtf(8.0f * (float)q + 1.0f)) * 0.5f);
-        while (i * (i - 1u) / 2u > q) --i;
-        while ((i + 1u) * i / 2u <= q) ++i;
-        const uint32_t j = q - i * (i - 1u) / 2u;
-        if (((validMask >> i) & 1ull) && ((validMask >> j) & 1ull)) {
-          const float4 amin = T[2u * i], amax = T[2u * i + 1u], bmin = T[2u * j], bmax = T[2u * j + 1u];
-          ia = __float_as_uint(amax.w) & ~kPrimary; ib = __float_as_uint(bmax.w) & ~kPrimary;
-          if (ia != ib && boxesOverlap(amin, amax, bmin, bmax) && filterPass(__float_as_uint(amin.w), __float_as_uint(bmin.w))) {
-            const float lx = amin.x > bmin.x ? amin.x : bmin.x, lz = amin.z > bmin.z ? amin.z : bmin.z;
-            hit = (floorf(lx * p.invSector) - p.binOx) == secX && (floorf(lz * p.invSector) - p.binOz) == secZ;
+      const uint32_t npairs = n * (n - 1u) / 2u;
+      for (uint32_t q0 = 0; q0 < npairs; q0 += 64u) {
+        const uint32_t q = q0 + lane;
+        bool hit = false;
+        uint32_t ia = 0, ib = 0;
+        if (q < npairs) {
+          const uint32_t ij = pairTab[q];
+          const uint32_t i = ij >> 8, j = ij & 255u;
+          if ((validMask >> i) & (validMask >> j) & 1ull) {
+            const float4 amin = T[2u * i], amax = T[2u * i + 1u], bmin = T[2u * j], bmax = T[2u * j + 1u];
+            if (boxesOverlap(amin, amax, bmin, bmax) && filterPass(__float_as_uint(amin.w), __float_as_uint(bmin.w))) {
+              ia = __float_as_uint(amax.w) & ~kPrimary; ib = __float_as_uint(bmax.w) & ~kPrimary;
+              const float lx = amin.x > bmin.x ? amin.x : bmin.x, lz = amin.z > bmin.z ? amin.z : bmin.z;
+              hit = ia != ib && (floorf(lx * p.invSector) - p.binOx) == secX && (floorf(lz * p.invSector) - p.binOz) == secZ;
+            }
           }
         }
+        emitPair(d, p, hit, ia, ib);
       }
-      emitPair(d, p, hit, ia, ib);
-    }
 
-    // big boxes against this bin's primary records (each binned box has exactly one primary copy)
-    const bool mine = valid && (__float_as_uint(rmax.w) & kPrimary);
-    const uint32_t myId = __float_as_uint(rmax.w) & ~kPrimary;
-    for (uint32_t b = 0; b < nbig; ++b) {
-      const float4 gmin = d.bigList[2u * (size_t)b], gmax = d.bigList[2u * (size_t)b + 1u];
-      const uint32_t gid = __float_as_uint(gmax.w);
-      const bool hit = mine && boxesOverlap(rmin, rmax, gmin, gmax) && filterPass(__float_as_uint(rmin.w), __float_as_uint(gmin.w));
-      emitPair(d, p, hit, myId, gid);
+      // big boxes against this bin's primary records (each binned box has exactly one primary copy)
+      if (nbig) {
+        const bool mine = valid && (__float_as_uint(rmax.w) & kPrimary);
+        const uint32_t myId = __float_as_uint(rmax.w) & ~kPrimary;
+        for (uint32_t b = 0; b < nbig; ++b) {
+          const float4 gmin = d.bigList[2u * (size_t)b], gmax = d.bigList[2u * (size_t)b + 1u];
+          const bool hit = mine && boxesOverlap(rmin, rmax, gmin, gmax) && filterPass(__float_as_uint(rmin.w), __float_as_uint(gmin.w));
+          emitPair(d, p, hit, myId, __float_as_uint(gmax.w));
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      it = itNext; n = nNext; rmin = nmin; rmax = nmax;
     }
-    __builtin_amdgcn_wave_barrier();
   }
 
   // big boxes against each other: wave w takes big b = w, w + totalWaves, ...; lanes sweep the partners after b
