@@ -130,6 +130,9 @@ int scTickSetTopology(ScTickContext* ctx, const int32_t* parent_dense_index, uin
 /* markDirty (sc_ecs.h:73-76) */
 int scTickMarkDirty(ScTickContext* ctx, uint32_t first, uint32_t count);
 int scTickMarkDirtyIndices(ScTickContext* ctx, const uint32_t* dense_indices, uint32_t count);
+/* set Transform::dirty of a range to exactly these values (1 = dirty); used when a host ECS re-syncs
+ * its whole state after the pool's dense order changed (sc_ecs.h:240-262 swap-remove) */
+int scTickSetDirtyFlags(ScTickContext* ctx, uint32_t first, uint32_t count, const uint8_t* dirty);
 /* seed Transform::worldMatrix (column-major Mat4, must be affine: row 3 == 0,0,0,1) */
 int scTickUploadWorldMatrices(ScTickContext* ctx, uint32_t first, uint32_t count, const float* mat16);
 
@@ -142,6 +145,8 @@ int scTickSetFrustumPlanes(ScTickContext* ctx, const float planes24[24], int val
 int scTickGetFrustumPlanes(ScTickContext* ctx, float planes24[24], int* valid);
 /* CullingState::freezeCulling (sc_world_partition.cpp:1227-1233) */
 int scTickSetFreezeCulling(ScTickContext* ctx, int freeze);
+/* WorldStreamingBudgets::maxDrawsBudget for the next SC_TICK_DRAWS (overrides the create-time value; 0 = unlimited) */
+int scTickSetDrawBudget(ScTickContext* ctx, uint32_t max_draws);
 
 /* ---- the tick ---- */
 int scTickRun(ScTickContext* ctx, uint32_t flags);       /* queues the stages; returns at once */

@@ -59,6 +59,8 @@ SYMBOLS = {
     "scTickMarkDirty": (C.c_int, [_CTX, C.c_uint32, C.c_uint32]),
     "scTickMarkDirtyIndices": (C.c_int, [_CTX, U32P, C.c_uint32]),
     "scTickUploadWorldMatrices": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
+    "scTickSetDirtyFlags": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P]),
+    "scTickSetDrawBudget": (C.c_int, [_CTX, C.c_uint32]),
     "scTickSetViewProj": (C.c_int, [_CTX, F32P]),
     "scTickSetFrustumPlanes": (C.c_int, [_CTX, F32P, C.c_int]),
     "scTickGetFrustumPlanes": (C.c_int, [_CTX, F32P, C.POINTER(C.c_int)]),

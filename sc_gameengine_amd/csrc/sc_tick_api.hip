@@ -315,7 +315,7 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     Scoped s(c, SC_TICK_K_PAIRS);
     launchPairs(c->d, p, c->stream);
   }
-  if ((flags & SC_TICK_DRAWS) && (flags & SC_TICK_CULL)) launchEmitDraws(c->d, c->desc.max_draws_budget, c->dDraws, c->stream);
+  if (flags & SC_TICK_DRAWS) launchEmitDraws(c->d, c->desc.max_draws_budget, c->dDraws, c->stream);
   c->profiling = saved;
 }
 
@@ -535,6 +535,31 @@ int scTickMarkDirtyIndices(ScTickContext* c, const uint32_t* idx, uint32_t count
   if (!h2d(c, c->dIdx, idx, (size_t)count * 4u)) return 0;
   launchSetDirtyIndices(c->d, c->dIdx, count, c->stream);
   return sync(c) ? 1 : 0;
+}
+
+int scTickSetDirtyFlags(ScTickContext* c, uint32_t first, uint32_t count, const uint8_t* flags)
+{
+  if (!c || !flags) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!count) return 1;
+  // read-modify-write of the covered words on the host: exact flags for [first, first+count)
+  const uint32_t w0 = first >> 5, w1 = (first + count + 31u) >> 5;
+  std::vector<uint32_t> words(w1 - w0);
+  if (!d2h(c, words.data(), c->d.dirty + w0, words.size() * 4u) || !sync(c)) return 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    const uint32_t g = first + i, bit = 1u << (g & 31u);
+    uint32_t& w = words[(g >> 5) - w0];
+    w = flags[i] ? (w | bit) : (w & ~bit);
+  }
+  if (!h2d(c, c->d.dirty + w0, words.data(), words.size() * 4u)) return 0;
+  return sync(c) ? 1 : 0;
+}
+
+int scTickSetDrawBudget(ScTickContext* c, uint32_t maxDraws)
+{
+  if (!c) return 0;
+  c->desc.max_draws_budget = maxDraws;
+  return 1;
 }
 
 int scTickUploadWorldMatrices(ScTickContext* c, uint32_t first, uint32_t count, const float* m16)
