@@ -23,7 +23,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 TILE_SECTORS = 256
 PROPS = 15
-TILE_GRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
 
 
 def algorithmic_bytes_per_entity(child_frac, stages):
@@ -83,7 +82,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from sc_gameengine_amd import capi, synth_world as sw
+    from sc_gameengine_amd import capi, synth_world as sw, tiles
     from sc_gameengine_amd.tick import WorldTick, camera_view_proj
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,7 +95,8 @@ def main():
     if world_size > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    tx, tz = TILE_GRID.get(world_size, (world_size, 1))
+    grid = tiles.tile_grid(world_size)
+    tx, tz = grid
     S = args.sectors
     origin = ((rank % tx) * S, (rank // tx) * S)
     w = sw.generate(S, S, PROPS, hierarchy=True, origin=origin)
@@ -118,9 +118,22 @@ def main():
     t.set_view_proj(camera_view_proj(cam))
     t.set_graph_mode(bool(args.graph))
 
+    # N > 1: the broadphase's border boxes are the one exchange on the path.  The context runs on
+    # torch's current stream so the RCCL send/recv group is stream-ordered with the kernels around it
+    # (no host synchronisation inside a step).
+    borders = None
+    if world_size > 1 and (flags & capi.BROADPHASE):
+        t.set_stream(torch.cuda.current_stream().cuda_stream)
+        borders = tiles.BorderBuffers(t, rank, grid, torch.device("cuda", local_rank))
+
     def step():
         t.nudge_roots_x(0.01)
-        t.run(flags)
+        if borders is None:
+            t.run(flags)
+        else:
+            t.run(flags | capi.SPLIT_PAIRS)       # ... bins filled, border messages packed
+            borders.exchange()                    # neighbour send/recv over RCCL (xGMI)
+            t.run_pairs()                         # merge what arrived, pair search
 
     def fence():
         t.sync()
@@ -178,6 +191,7 @@ def main():
                 "visible": int(counts.visible),
                 "pairs": int(counts.pairs),
                 "graph": bool(args.graph),
+                "exchange": ("border AABBs, RCCL send/recv to <=8 neighbour tiles per step" if borders is not None else "none"),
                 "resident": "device SoA authoritative; no per-step host transfer",
             },
             "roofline": {

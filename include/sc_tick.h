@@ -51,6 +51,8 @@ enum {
   SC_TICK_CULLED_LIST = 1u << 3,   /* also build CullingState::culled */
   SC_TICK_DRAWS       = 1u << 4,   /* RenderPrepStreamingSystem draw list from the visible list */
   SC_TICK_DENSE_AABBS = 1u << 5,   /* with BROADPHASE: also keep per-entity world AABBs for scTickReadWorldAabbs */
+  SC_TICK_SPLIT_PAIRS = 1u << 6,   /* with BROADPHASE on a multi-GPU tile: stop after filling the bins and packing the
+                                      border messages; the caller exchanges them and calls scTickRunPairs */
   SC_TICK_FULL        = SC_TICK_XFORM | SC_TICK_CULL | SC_TICK_BROADPHASE
 };
 
@@ -154,6 +156,24 @@ int scTickSynchronize(ScTickContext* ctx);
 /* upstream producer of SynthWorld's dirty regime (ii): localPos.x += dx on every root, marked dirty
  * (the device-side analogue of PhysicsSyncSystem's transform writes, sc_physics.cpp:1167-1186) */
 int scTickNudgeRootsX(ScTickContext* ctx, float dx);
+
+/* ---- multi-GPU tiles (one context per GPU, one process per GPU) ----
+ * The world is cut into equal rectangular tiles of sectors; each context owns one (ScTickContextDesc
+ * tile_*).  Transform and culling need no exchange.  The broadphase needs the boxes that reach over a
+ * tile edge: after scTickRun(... | SC_TICK_BROADPHASE | SC_TICK_SPLIT_PAIRS) the message for each
+ * existing neighbour sits in the bound send buffer; the caller moves send[d] of this rank into
+ * recv[7-d] of the neighbour in direction d (RCCL send/recv, or a peer copy) on the context's stream
+ * and then calls scTickRunPairs.  Directions: d = 0..7 for (dx,dz) = (-1,-1) (0,-1) (1,-1) (-1,0)
+ * (1,0) (-1,1) (0,1) (1,1).  Pair ids are rank << 24 | dense index. */
+int scTickSetTile(ScTickContext* ctx, uint32_t rank, uint32_t neighbour_mask);
+/* size in bytes of the fixed-capacity border message of direction d (same on both sides of an edge) */
+uint32_t scTickBorderBytes(ScTickContext* ctx, uint32_t direction);
+/* caller-owned device buffers (e.g. torch tensors) of at least scTickBorderBytes(d) bytes each */
+int scTickBindBorderBuffers(ScTickContext* ctx, uint32_t direction, void* send_device_ptr, void* recv_device_ptr);
+int scTickRunPairs(ScTickContext* ctx);
+/* run all device work of this context on a stream the caller owns (hipStream_t), e.g. the stream its
+ * RCCL calls are ordered on; NULL returns to the context's own stream */
+int scTickSetStream(ScTickContext* ctx, void* hip_stream);
 
 /* ---- results (each synchronises the stream) ---- */
 int scTickGetCounts(ScTickContext* ctx, ScTickCounts* out);

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsc_tick.so")
 
 # scTickRun flags (include/sc_tick.h)
-XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS, DENSE_AABBS = 1, 2, 4, 8, 16, 32
+XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS, DENSE_AABBS, SPLIT_PAIRS = 1, 2, 4, 8, 16, 32, 64
 FULL = XFORM | CULL | BROADPHASE
 K_XFORM_CULL, K_COMPACT, K_PAIRS, K_NUDGE, K_COUNT = 0, 1, 2, 3, 4
 NO_PARENT = -1
@@ -61,6 +61,11 @@ SYMBOLS = {
     "scTickUploadWorldMatrices": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
     "scTickSetDirtyFlags": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P]),
     "scTickSetDrawBudget": (C.c_int, [_CTX, C.c_uint32]),
+    "scTickSetTile": (C.c_int, [_CTX, C.c_uint32, C.c_uint32]),
+    "scTickBorderBytes": (C.c_uint32, [_CTX, C.c_uint32]),
+    "scTickBindBorderBuffers": (C.c_int, [_CTX, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "scTickRunPairs": (C.c_int, [_CTX]),
+    "scTickSetStream": (C.c_int, [_CTX, C.c_void_p]),
     "scTickSetViewProj": (C.c_int, [_CTX, F32P]),
     "scTickSetFrustumPlanes": (C.c_int, [_CTX, F32P, C.c_int]),
     "scTickGetFrustumPlanes": (C.c_int, [_CTX, F32P, C.POINTER(C.c_int)]),

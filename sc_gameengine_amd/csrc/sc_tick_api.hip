@@ -72,6 +72,10 @@ struct ScTickContext
   // broadphase
   uint32_t sectors = 0, maxPairs = 0;
   uint32_t parity = 0, lastParity = 0;
+  uint32_t rank = 0, neighbourMask = 0;
+  bool pairsPending = false;
+  TickParams pendingParams{};
+  hipStream_t ownStream = nullptr;
 };
 
 namespace {
@@ -289,6 +293,8 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.binSZ = c->desc.tile_sectors_x ? c->desc.tile_sectors_z + 2u : 0u;
   p.parity = c->parity;
   p.maxPairs = c->maxPairs;
+  p.rankBits = c->rank << 24;
+  p.neighbourMask = c->neighbourMask;
 }
 
 void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool allowProfile)
@@ -312,8 +318,8 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     launchCompact(c->d, p, grid, c->stream);
   }
   if (flags & SC_TICK_BROADPHASE) {
-    Scoped s(c, SC_TICK_K_PAIRS);
-    launchPairs(c->d, p, c->stream);
+    if (flags & SC_TICK_SPLIT_PAIRS) launchBorderPack(c->d, p, c->stream);      // the caller exchanges, then scTickRunPairs
+    else { Scoped s(c, SC_TICK_K_PAIRS); launchPairs(c->d, p, c->stream); }
   }
   if (flags & SC_TICK_DRAWS) launchEmitDraws(c->d, c->desc.max_draws_budget, c->dDraws, c->stream);
   c->profiling = saved;
@@ -360,7 +366,7 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
   if (const char* s = std::getenv("SC_TICK_SPANS")) { const int v = std::atoi(s); if (v > 0) c->spansWanted = (uint32_t)v; }
 
   bool ok = bind(c);
-  if (ok) { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) ok = fail(c, "hipStreamCreate", e); }
+  if (ok) { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) ok = fail(c, "hipStreamCreate", e); c->ownStream = c->stream; }
   DeviceState& d = c->d;
   const size_t N = c->cap;
   ok = ok && dalloc(c, d.px, N) && dalloc(c, d.py, N) && dalloc(c, d.pz, N)
@@ -403,6 +409,7 @@ void scTickDestroyContext(ScTickContext* c)
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  c->stream = c->ownStream;
   dropGraph(c);
   for (auto& v : c->times) for (auto& p : v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : c->eventPool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -652,10 +659,62 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   } else {
     enqueueStages(c, p, grid, true);
   }
-  if (flags & SC_TICK_BROADPHASE) { c->lastParity = c->parity; c->parity ^= 1u; }
+  if (flags & SC_TICK_BROADPHASE) {
+    if (flags & SC_TICK_SPLIT_PAIRS) { c->pairsPending = true; c->pendingParams = p; }
+    else { c->lastParity = c->parity; c->parity ^= 1u; }
+  }
   c->tickIndex++;
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, "kernel launch", e);
+  return 1;
+}
+
+int scTickRunPairs(ScTickContext* c)
+{
+  if (!c) return 0;
+  if (!bind(c)) return 0;
+  if (!c->pairsPending) return fail(c, "scTickRunPairs without a preceding scTickRun(... | SC_TICK_BROADPHASE | SC_TICK_SPLIT_PAIRS)");
+  launchBorderMerge(c->d, c->pendingParams, c->stream);
+  {
+    Scoped s(c, SC_TICK_K_PAIRS);
+    launchPairs(c->d, c->pendingParams, c->stream);
+  }
+  c->pairsPending = false;
+  c->lastParity = c->parity; c->parity ^= 1u;
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, "kernel launch", e);
+  return 1;
+}
+
+int scTickSetTile(ScTickContext* c, uint32_t rank, uint32_t neighbourMask)
+{
+  if (!c) return 0;
+  if (rank > 127u) return fail(c, "rank must be < 128 (7 id bits)");
+  c->rank = rank;
+  c->neighbourMask = neighbourMask & 0xFFu;
+  return 1;
+}
+
+uint32_t scTickBorderBytes(ScTickContext* c, uint32_t dir)
+{
+  if (!c || dir > 7u || !c->desc.tile_sectors_x) return 0;
+  return borderWords(dir, c->desc.tile_sectors_x, c->desc.tile_sectors_z) * 4u;
+}
+
+int scTickBindBorderBuffers(ScTickContext* c, uint32_t dir, void* send, void* recv)
+{
+  if (!c || dir > 7u) return c ? fail(c, "bad direction") : 0;
+  c->d.borderSend[dir] = static_cast<uint32_t*>(send);
+  c->d.borderRecv[dir] = static_cast<uint32_t*>(recv);
+  return 1;
+}
+
+int scTickSetStream(ScTickContext* c, void* stream)
+{
+  if (!c) return 0;
+  if (!bind(c) || !sync(c)) return 0;
+  dropGraph(c);
+  c->stream = stream ? static_cast<hipStream_t>(stream) : c->ownStream;
   return 1;
 }
 

@@ -54,8 +54,16 @@ struct DeviceState {
   float4* bins;                // [sector][kBinCap][2]: (min.xyz, layers) (max.xyz, id | primary<<31)
   float4* bigList;             // [cap][2] boxes that cannot be binned (too large, outside the rect, bin full)
   uint32_t* bigBits[2];        // per-entity "is in the big list" bit, double-buffered by tick parity
-  uint2* pairs;                // (a, b) dense indices, a < b
+  uint2* pairs;                // (a, b) ids, a < b; id = rank << 24 | dense index
+  // multi-GPU border exchange: one message per neighbour direction (caller-owned device buffers)
+  uint32_t* borderSend[8];
+  uint32_t* borderRecv[8];
 };
+
+// Border message layout (uint32 words): [0] records, [1] overflow flag, [2..2+L) per-bin counts,
+// then records (8 words each) packed bin after bin.  L = sectors on that ring side.
+constexpr uint32_t kBorderHeader = 2;
+constexpr uint32_t kBorderRecsPerBin = 16;    // capacity = L * kBorderRecsPerBin records per message
 
 constexpr uint32_t kBinCap = 64;          // one wave lane per record of a bin
 constexpr uint32_t kPrimary = 0x80000000u;
@@ -74,7 +82,17 @@ struct TickParams {
   uint32_t binSX, binSZ;
   uint32_t parity;          // tick parity: selects the counter set and bigBits buffer
   uint32_t maxPairs;
+  uint32_t rankBits;        // rank << 24, OR-ed into every box id
+  uint32_t neighbourMask;   // bit d set: a neighbour tile exists in direction d (its ring side is foreign)
 };
+// neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d
+__host__ __device__ inline void borderDir(uint32_t d, int& dx, int& dz) { const uint32_t k = d < 4 ? d : d + 1; dx = (int)(k % 3) - 1; dz = (int)(k / 3) - 1; }
+// side messages span the whole ring side including its two end cells (used when no tile exists past them)
+__host__ __device__ inline uint32_t borderLen(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { int dx, dz; borderDir(d, dx, dz); return (dx != 0 && dz != 0) ? 1u : (dx == 0 ? coreSX + 2u : coreSZ + 2u); }
+__host__ __device__ inline uint32_t borderDirOf(int dx, int dz) { const uint32_t k9 = (uint32_t)((dz + 1) * 3 + (dx + 1)); return k9 < 4 ? k9 : k9 - 1u; }
+// hasNb(p, dx, dz): a tile exists one step in that direction
+__host__ __device__ inline bool hasNb(const TickParams& p, int dx, int dz) { return (p.neighbourMask >> borderDirOf(dx, dz)) & 1u; }
+__host__ __device__ inline uint32_t borderWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { const uint32_t L = borderLen(d, coreSX, coreSZ); return kBorderHeader + L + L * kBorderRecsPerBin * 8u; }
 constexpr uint32_t kFlagHasDeep = 1u << 16;   // write recomp bits for the level kernels
 constexpr uint32_t kFlagDenseAabbs = 1u << 5; // == SC_TICK_DENSE_AABBS
 
@@ -83,6 +101,8 @@ void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, h
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s);
+void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s);
+void launchBorderMerge(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s);
 void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, hipStream_t s);
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);

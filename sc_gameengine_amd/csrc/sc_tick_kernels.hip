@@ -203,7 +203,7 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
     worldAabb(M, b, mn, mx);
     plan = planBins(p, mn, mx);
     rmin = make_float4(mn[0], mn[1], mn[2], __uint_as_float(d.layers[i]));
-    rmax = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i));
+    rmax = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i | p.rankBits));
     if (p.flags & kFlagDenseAabbs) { d.aabbMin[i] = rmin; d.aabbMax[i] = rmax; }
   } else if ((p.flags & kFlagDenseAabbs) && i < p.n) {
     d.aabbMin[i] = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
@@ -217,7 +217,7 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
     const uint32_t dx = k & 1u, dz = k >> 1;
     const bool want = binned && dx < plan.nx && dz < plan.nz;
     float4 rm = rmax;
-    if (k == 0) rm.w = __uint_as_float(i | kPrimary);        // exactly one primary copy per box
+    if (k == 0) rm.w = __uint_as_float(i | p.rankBits | kPrimary);   // exactly one primary copy per box
     binInsertWave(d, want, (sz + dz) * p.binSX + (sx + dx), rmin, rm, binFull);
   }
   if (plan.collide && plan.big) appendBig(d, p, rmin, rmax);
@@ -236,7 +236,7 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
   worldAabb(M, b, mn, mx);
   const BinPlan plan = planBins(p, mn, mx);
   const float4 rmin = make_float4(mn[0], mn[1], mn[2], __uint_as_float(d.layers[i]));
-  float4 rmax = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i));
+  float4 rmax = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i | p.rankBits));
   if (p.flags & kFlagDenseAabbs) { d.aabbMin[i] = rmin; d.aabbMax[i] = rmax; }
   if (!plan.collide) return;
   if (plan.big) { appendBig(d, p, rmin, rmax); return; }
@@ -249,7 +249,7 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
     const uint32_t slot = atomicAdd(&d.binCount[sector], 1u);
     if (slot < kBinCap) {
       float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
-      float4 rm = rmax; if (k == 0) rm.w = __uint_as_float(i | kPrimary);
+      float4 rm = rmax; if (k == 0) rm.w = __uint_as_float(i | p.rankBits | kPrimary);
       r[0] = rmin; r[1] = rm;
     } else binFull = true;
   }
@@ -600,7 +600,14 @@ __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const Tick
       bool valid = lane < n;
       if (valid && nbig) {                                   // partially binned boxes live in the big list
         const uint32_t id = __float_as_uint(rmax.w) & ~kPrimary;
-        if ((bigBits[id >> 5] >> (id & 31u)) & 1u) valid = false;
+        if ((id & ~kParentMask) == p.rankBits && ((bigBits[(id & kParentMask) >> 5] >> (id & 31u)) & 1u)) valid = false;
+      }
+      // a ring sector on a side where a neighbour tile exists belongs to that neighbour: it reports the
+      // pairs whose low corner lies there (it received these boxes through the border exchange)
+      {
+        const uint32_t gx = s % p.binSX, gz = s / p.binSX;
+        const int dx = gx == 0 ? -1 : (gx == p.binSX - 1u ? 1 : 0), dz = gz == 0 ? -1 : (gz == p.binSZ - 1u ? 1 : 0);
+        if ((dx != 0 && hasNb(p, dx, 0)) || (dz != 0 && hasNb(p, 0, dz))) valid = false;   // nearest tile is not this one
       }
       T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
       __builtin_amdgcn_wave_barrier();
@@ -655,6 +662,114 @@ __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const Tick
       }
       emitPair(d, p, hit, __float_as_uint(gmax.w), jid);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Border exchange (multi-GPU tiles).  After the fused kernel the ring bins of this tile hold exactly
+// the boxes that reach into a neighbour's sectors.  k_border_pack turns each ring side that has a
+// neighbour into one fixed-capacity message (per-bin counts + records packed bin after bin);
+// k_border_merge appends what the neighbours sent into this tile's core-edge bins.  One workgroup
+// per direction; a ring side is at most a few hundred bins.
+// ------------------------------------------------------------------------------------------
+// Ownership of ring sectors: a sector outside this tile's core belongs to the tile nearest to it
+// (world coordinates clamped into the world), so an out-of-world ring cell next to a neighbour's
+// column is that neighbour's.  hasNb(dx,dz): a tile exists one step that way.
+
+// ring cell l of side (dx,dz) in this tile's bin grid; *send tells whether this tile hands it to that neighbour
+__device__ __forceinline__ uint32_t ringCell(const TickParams& p, int dx, int dz, uint32_t l, bool* send)
+{
+  const uint32_t coreSX = p.binSX - 2u, coreSZ = p.binSZ - 2u;
+  uint32_t gx, gz;
+  if (dx != 0 && dz != 0) { gx = dx < 0 ? 0u : coreSX + 1u; gz = dz < 0 ? 0u : coreSZ + 1u; *send = true; }
+  else if (dx != 0) {
+    gx = dx < 0 ? 0u : coreSX + 1u; gz = l;
+    *send = (l >= 1u && l <= coreSZ) || (l == 0u && !hasNb(p, 0, -1)) || (l == coreSZ + 1u && !hasNb(p, 0, 1));
+  } else {
+    gz = dz < 0 ? 0u : coreSZ + 1u; gx = l;
+    *send = (l >= 1u && l <= coreSX) || (l == 0u && !hasNb(p, -1, 0)) || (l == coreSX + 1u && !hasNb(p, 1, 0));
+  }
+  return gz * p.binSX + gx;
+}
+// where cell l of the message received from the neighbour in direction (dx,dz) lands in this tile's grid
+__device__ __forceinline__ uint32_t landingCell(const TickParams& p, int dx, int dz, uint32_t l)
+{
+  const uint32_t coreSX = p.binSX - 2u, coreSZ = p.binSZ - 2u;
+  uint32_t gx, gz;
+  if (dx != 0 && dz != 0) { gx = dx < 0 ? 1u : coreSX; gz = dz < 0 ? 1u : coreSZ; }
+  else if (dx != 0) { gx = dx < 0 ? 1u : coreSX; gz = l; }
+  else { gz = dz < 0 ? 1u : coreSZ; gx = l; }
+  return gz * p.binSX + gx;
+}
+
+__global__ __launch_bounds__(kTile) void k_border_pack(const DeviceState d, const TickParams p)
+{
+  __shared__ uint32_t sOff[kTile + 1];
+  const uint32_t dir = blockIdx.x;
+  if (!((p.neighbourMask >> dir) & 1u) || !d.borderSend[dir]) return;
+  int dx, dz; borderDir(dir, dx, dz);
+  const uint32_t L = borderLen(dir, p.binSX - 2u, p.binSZ - 2u);
+  uint32_t* msg = d.borderSend[dir];
+  const uint32_t cap = L * kBorderRecsPerBin;
+  // exclusive scan of the side's bin counts, kTile bins at a time (carry across chunks)
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < L; base += kTile) {
+    const uint32_t l = base + threadIdx.x;
+    uint32_t c = 0, cell = 0;
+    if (l < L) {
+      bool send = false;
+      cell = ringCell(p, dx, dz, l, &send);
+      if (send) { c = d.binCount[cell]; if (c > kBinCap) c = kBinCap; }
+    }
+    sOff[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = carry; for (uint32_t t = 0; t < kTile; ++t) { const uint32_t v = sOff[t]; sOff[t] = run; run += v; } sOff[kTile] = run; }
+    __syncthreads();
+    if (l < L) {
+      const uint32_t off = sOff[threadIdx.x];
+      const uint32_t take = (off + c <= cap) ? c : (off < cap ? cap - off : 0u);
+      msg[kBorderHeader + l] = take;
+      const float4* src = d.bins + 2u * ((size_t)cell * kBinCap);
+      float4* dst = reinterpret_cast<float4*>(msg + kBorderHeader + L) + 2u * (size_t)off;
+      for (uint32_t r = 0; r < take; ++r) { dst[2u * r] = src[2u * r]; dst[2u * r + 1u] = src[2u * r + 1u]; }
+    }
+    carry = sOff[kTile];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { msg[0] = carry < cap ? carry : cap; msg[1] = carry > cap ? 1u : 0u; }
+}
+
+__global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, const TickParams p)
+{
+  __shared__ uint32_t sOff[kTile + 1];
+  const uint32_t dir = blockIdx.x;                       // the neighbour in direction dir sent borderRecv[dir]
+  if (!((p.neighbourMask >> dir) & 1u) || !d.borderRecv[dir]) return;
+  int dx, dz; borderDir(dir, dx, dz);
+  const uint32_t L = borderLen(dir, p.binSX - 2u, p.binSZ - 2u);
+  const uint32_t* msg = d.borderRecv[dir];
+  if (threadIdx.x == 0 && msg[1]) atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBinFull], 1u);   // sender ran out of message space
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < L; base += kTile) {
+    const uint32_t l = base + threadIdx.x;
+    const uint32_t c = l < L ? msg[kBorderHeader + l] : 0u;
+    sOff[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = carry; for (uint32_t t = 0; t < kTile; ++t) { const uint32_t v = sOff[t]; sOff[t] = run; run += v; } sOff[kTile] = run; }
+    __syncthreads();
+    if (l < L && c) {
+      // the sender's ring cell l on its side (-dx,-dz) is this tile's cell l along its own side (dx,dz)
+      const uint32_t sector = landingCell(p, dx, dz, l);
+      const uint32_t slot0 = atomicAdd(&d.binCount[sector], c);
+      const float4* src = reinterpret_cast<const float4*>(msg + kBorderHeader + L) + 2u * (size_t)sOff[threadIdx.x];
+      for (uint32_t r = 0; r < c; ++r) {
+        if (slot0 + r < kBinCap) {
+          float4* dst = d.bins + 2u * ((size_t)sector * kBinCap + slot0 + r);
+          dst[0] = src[2u * r]; dst[1] = src[2u * r + 1u];
+        } else atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBinFull], 1u);
+      }
+    }
+    carry = sOff[kTile];
+    __syncthreads();
   }
 }
 
@@ -747,6 +862,16 @@ void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s)
   uint32_t grid = (sectors + 3u) / 4u;
   if (grid > 2048u) grid = 2048u;
   hipLaunchKernelGGL(k_pairs, dim3(grid), dim3(kTile), 0, s, d, p);
+}
+void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s)
+{
+  if (!p.neighbourMask) return;
+  hipLaunchKernelGGL(k_border_pack, dim3(8), dim3(kTile), 0, s, d, p);
+}
+void launchBorderMerge(const DeviceState& d, const TickParams& p, hipStream_t s)
+{
+  if (!p.neighbourMask) return;
+  hipLaunchKernelGGL(k_border_merge, dim3(8), dim3(kTile), 0, s, d, p);
 }
 void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s)
 {

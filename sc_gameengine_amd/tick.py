@@ -198,6 +198,22 @@ class WorldTick:
     def nudge_roots_x(self, dx):
         self._ok(self.lib.scTickNudgeRootsX(self.ctx, float(dx)), "scTickNudgeRootsX")
 
+    # ---- multi-GPU tiles ----
+    def set_tile(self, rank, neighbour_mask):
+        self._ok(self.lib.scTickSetTile(self.ctx, rank, neighbour_mask), "scTickSetTile")
+
+    def border_bytes(self, direction):
+        return int(self.lib.scTickBorderBytes(self.ctx, direction))
+
+    def bind_border(self, direction, send_ptr, recv_ptr):
+        self._ok(self.lib.scTickBindBorderBuffers(self.ctx, direction, send_ptr, recv_ptr), "scTickBindBorderBuffers")
+
+    def run_pairs(self):
+        self._ok(self.lib.scTickRunPairs(self.ctx), "scTickRunPairs")
+
+    def set_stream(self, hip_stream):
+        self._ok(self.lib.scTickSetStream(self.ctx, hip_stream), "scTickSetStream")
+
     def set_profiling(self, period):
         """0 = off, n = record HIP events on every n-th tick"""
         self._ok(self.lib.scTickSetProfiling(self.ctx, int(period)), "scTickSetProfiling")
