@@ -39,6 +39,22 @@ def algorithmic_bytes_per_entity(child_frac, stages):
     return b
 
 
+def pmc_traffic(stages, entities_per_gpu):
+    """HBM bytes per k_xform_cull launch from the committed rocprofv3 PMC passes (tools/pmc_session.sh ->
+    profiles/pmc_traffic.json): FETCH_SIZE and WRITE_SIZE collected in separate passes and calibrated on
+    known-byte copy kernels of the same access widths (FETCH_SIZE under-counts 2x on gfx950).  None when
+    no profile of this exact workload is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    cfg = d.get("bench_config", {})
+    if sorted(cfg.get("stages", [])) != sorted(stages) or cfg.get("entities_per_gpu") != entities_per_gpu:
+        return None
+    return d.get("kernels", {}).get("k_xform_cull", {}).get("hbm_bytes_per_launch")
+
+
 def cpu_baseline(world, ticks=20, warm=3):
     """Reference-faithful CPU tick (oracle port), timed on this host: Transform + Camera + Culling,
     hardware_concurrency()-1 workers as the sandbox does (src/sandbox/src/main.cpp:52-54)."""
@@ -78,6 +94,8 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="replay the frame from a hipGraph")
     ap.add_argument("--sample", type=int, default=8, help="record HIP events on every n-th step (1 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -91,9 +109,14 @@ def main():
     if world_size != args.gpus:
         if world_size == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world_size > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     grid = tiles.tile_grid(world_size)
     tx, tz = grid
@@ -159,7 +182,7 @@ def main():
     counts = t.counts()
 
     if world_size > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -193,12 +216,14 @@ def main():
                 "graph": bool(args.graph),
                 "exchange": ("border AABBs, RCCL send/recv to <=8 neighbour tiles per step" if borders is not None else "none"),
                 "resident": "device SoA authoritative; no per-step host transfer",
+                "backend": args.backend if world_size > 1 else None,
+                "rehearsal_same_device": bool(args.same_device),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_xform_cull",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": None,
+                "traffic": pmc_traffic(stages, w.n),
                 "bytes_per_entity": bpe, "avg_launch_ms": k1_ms, "launches_timed": int(len(k1)),
                 "other_kernels_ms": {"k_compact": float(np.mean(k2)) if len(k2) else None,
                                      "k_nudge_roots_x": float(np.mean(kn)) if len(kn) else None,

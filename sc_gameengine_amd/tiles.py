@@ -47,6 +47,12 @@ def exchange(send, recv, rank, grid, group=None):
     nb = neighbours(rank, grid)
     if not nb:
         return
+    staged = None
+    if dist.get_backend(group) == "gloo" and next(iter(send.values())).is_cuda:
+        # rehearsal transport (no RCCL, e.g. several ranks on one GPU): stage through host memory
+        staged = recv
+        send = {d: send[d].cpu() for d in nb}
+        recv = {d: staged[d].cpu() for d in nb}
     ops = []
     for d in sorted(nb):
         ops.append(dist.P2POp(dist.isend, send[d], nb[d], group=group, tag=d))
@@ -54,6 +60,9 @@ def exchange(send, recv, rank, grid, group=None):
         ops.append(dist.P2POp(dist.irecv, recv[d], nb[d], group=group, tag=7 - d))
     for w in dist.batch_isend_irecv(ops):
         w.wait()
+    if staged is not None:
+        for d in nb:
+            staged[d].copy_(recv[d])
 
 
 class BorderBuffers:
