@@ -227,7 +227,7 @@ def main():
                 "bytes_per_entity": bpe, "avg_launch_ms": k1_ms, "launches_timed": int(len(k1)),
                 "other_kernels_ms": {"k_compact": float(np.mean(k2)) if len(k2) else None,
                                      "k_nudge_roots_x": float(np.mean(kn)) if len(kn) else None,
-                                     "k_pairs": float(np.mean(kp)) if len(kp) else None},
+                                     "k_compact_pairs (one launch)" if not len(k2) else "k_pairs": float(np.mean(kp)) if len(kp) else None},
             },
         }
         if world_size == 1 and not args.no_cpu_baseline:

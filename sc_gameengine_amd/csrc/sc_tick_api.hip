@@ -37,7 +37,7 @@ struct ScTickContext
 
   // host mirrors needed to (re)build link words
   std::vector<int32_t> hParent;
-  std::vector<uint8_t> hFlags;       // bit0 has mesh, bit1 has bounds
+  std::vector<uint8_t> hFlags;       // bit0 has mesh, bit1 has bounds, bits 2..4 rotation about X/Y/Z trivial (sin 0, cos 1)
   bool linksStale = true;
   uint32_t maxDepth = 0, unreachable = 0;
   std::vector<uint32_t> levelOffsets;   // offsets into dLevelList for depth kMaxChain+1, +2, ...
@@ -49,6 +49,7 @@ struct ScTickContext
   int freeze = 0;
 
   uint32_t spansWanted = 1536;
+  uint32_t variant = 0;       // SC_TICK_VARIANT: bit0 = chain-walk K1 instead of the wave-cooperative one
   uint32_t lastFlags = 0;
 
   // scratch device buffers for indexed read-back
@@ -215,7 +216,8 @@ void rebuildLinks(ScTickContext* c, std::vector<uint32_t>& link, std::vector<uin
       }
     }
     const uint32_t p = (par[i] == SC_TICK_NO_PARENT) ? kNoParent : (uint32_t)par[i];
-    link[i] = p | ((c->hFlags[i] & 1u) ? kHasMesh : 0u) | ((c->hFlags[i] & 2u) ? kHasBounds : 0u) | (dfield << kDepthShift);
+    link[i] = p | ((c->hFlags[i] & 1u) ? kHasMesh : 0u) | ((c->hFlags[i] & 2u) ? kHasBounds : 0u) | (dfield << kDepthShift) |
+              ((c->hFlags[i] & 4u) ? kRotTrivialX : 0u) | ((c->hFlags[i] & 8u) ? kRotTrivialY : 0u) | ((c->hFlags[i] & 16u) ? kRotTrivialZ : 0u);
   }
 }
 
@@ -295,6 +297,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.maxPairs = c->maxPairs;
   p.rankBits = c->rank << 24;
   p.neighbourMask = c->neighbourMask;
+  p.variant = c->variant;
 }
 
 void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool allowProfile)
@@ -313,13 +316,21 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
       launchDeepLevel(c->d, p, c->dLevelList + b, e - b, c->stream);
     }
   }
-  if (flags & (SC_TICK_XFORM | SC_TICK_CULL)) {
-    Scoped s(c, SC_TICK_K_COMPACT);
-    launchCompact(c->d, p, grid, c->stream);
-  }
-  if (flags & SC_TICK_BROADPHASE) {
-    if (flags & SC_TICK_SPLIT_PAIRS) launchBorderPack(c->d, p, c->stream);      // the caller exchanges, then scTickRunPairs
-    else { Scoped s(c, SC_TICK_K_PAIRS); launchPairs(c->d, p, c->stream); }
+  const bool needCompact = (flags & (SC_TICK_XFORM | SC_TICK_CULL)) != 0;
+  const bool pairsNow = (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS);
+  if (needCompact && pairsNow && !(c->variant & 8u)) {
+    // both depend only on the fused kernel: one launch, workgroups split by role (timed as K_PAIRS)
+    Scoped s(c, SC_TICK_K_PAIRS);
+    launchCompactPairs(c->d, p, grid, c->stream);
+  } else {
+    if (needCompact) {
+      Scoped s(c, SC_TICK_K_COMPACT);
+      launchCompact(c->d, p, grid, c->stream);
+    }
+    if (flags & SC_TICK_BROADPHASE) {
+      if (flags & SC_TICK_SPLIT_PAIRS) launchBorderPack(c->d, p, c->stream);      // the caller exchanges, then scTickRunPairs
+      else { Scoped s(c, SC_TICK_K_PAIRS); launchPairs(c->d, p, c->stream); }
+    }
   }
   if (flags & SC_TICK_DRAWS) launchEmitDraws(c->d, c->desc.max_draws_budget, c->dDraws, c->stream);
   c->profiling = saved;
@@ -364,19 +375,28 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
   if (c->desc.sector_size <= 0.001f) c->desc.sector_size = 64.0f;     // WorldPartition::configure, sc_world_partition.cpp:222-223
   c->cap = ((desc->capacity + kTile - 1) / kTile) * kTile;
   if (const char* s = std::getenv("SC_TICK_SPANS")) { const int v = std::atoi(s); if (v > 0) c->spansWanted = (uint32_t)v; }
+  if (const char* s = std::getenv("SC_TICK_VARIANT")) c->variant = (uint32_t)std::atoi(s);
 
   bool ok = bind(c);
   if (ok) { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) ok = fail(c, "hipStreamCreate", e); c->ownStream = c->stream; }
   DeviceState& d = c->d;
   const size_t N = c->cap;
-  ok = ok && dalloc(c, d.px, N) && dalloc(c, d.py, N) && dalloc(c, d.pz, N)
-          && dalloc(c, d.rsx, N) && dalloc(c, d.rcx, N) && dalloc(c, d.rsy, N) && dalloc(c, d.rcy, N) && dalloc(c, d.rsz, N) && dalloc(c, d.rcz, N)
-          && dalloc(c, d.sx, N) && dalloc(c, d.sy, N) && dalloc(c, d.sz, N)
-          && dalloc(c, d.link, N) && dalloc(c, d.dirty, N / 32) && dalloc(c, d.unreach, N / 32)
-          && dalloc(c, d.bminx, N) && dalloc(c, d.bminy, N) && dalloc(c, d.bminz, N)
-          && dalloc(c, d.bmaxx, N) && dalloc(c, d.bmaxy, N) && dalloc(c, d.bmaxz, N)
-          && dalloc(c, d.meshId, N) && dalloc(c, d.materialId, N) && dalloc(c, d.layers, N)
-          && dalloc(c, d.w0, N) && dalloc(c, d.w1, N) && dalloc(c, d.w2, N)
+  // one slab for every 4-byte stream, one for the matrix rows (see Stream in sc_tick_internal.h)
+  float* fslab = nullptr; float4* rslab = nullptr;
+  ok = ok && dalloc(c, fslab, (size_t)kStreamCount * N) && dalloc(c, rslab, 3 * N);
+  if (ok) {
+    auto F = [&](uint32_t k) { return fslab + (size_t)k * N; };
+    d.fslab = reinterpret_cast<const char*>(fslab); d.rslab = reinterpret_cast<char*>(rslab);
+    d.capBytes = (uint32_t)(N * 4u); d.capBytes16 = (uint32_t)(N * 16u);
+    d.px = F(kPX); d.py = F(kPY); d.pz = F(kPZ);
+    d.rsx = F(kRSX); d.rcx = F(kRCX); d.rsy = F(kRSY); d.rcy = F(kRCY); d.rsz = F(kRSZ); d.rcz = F(kRCZ);
+    d.sx = F(kSX); d.sy = F(kSY); d.sz = F(kSZ);
+    d.bminx = F(kBMINX); d.bminy = F(kBMINY); d.bminz = F(kBMINZ); d.bmaxx = F(kBMAXX); d.bmaxy = F(kBMAXY); d.bmaxz = F(kBMAXZ);
+    d.link = reinterpret_cast<uint32_t*>(F(kLINK)); d.layers = reinterpret_cast<uint32_t*>(F(kLAYERS));
+    d.meshId = reinterpret_cast<uint32_t*>(F(kMESH)); d.materialId = reinterpret_cast<uint32_t*>(F(kMATERIAL));
+    d.w0 = rslab; d.w1 = rslab + N; d.w2 = rslab + 2 * N;
+  }
+  ok = ok && dalloc(c, d.dirty, N / 32) && dalloc(c, d.unreach, N / 32)
           && dalloc(c, d.vis, N / 64) && dalloc(c, d.cand, N / 64) && dalloc(c, d.recomp, N / 64)
           && dalloc(c, d.blockVis, N / kTile) && dalloc(c, d.blockCand, N / kTile)
           && dalloc(c, d.visibleIdx, N) && dalloc(c, d.culledIdx, N) && dalloc(c, d.counters, 32)
@@ -385,7 +405,7 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
   c->maxPairs = desc->max_pairs ? desc->max_pairs : desc->capacity * 4u;
   if (ok && c->sectors) {
     if ((uint64_t)desc->tile_sectors_x * desc->tile_sectors_z > (1u << 24)) ok = fail(c, "tile rectangle too large");
-    ok = ok && dalloc(c, d.binCount, c->sectors) && dalloc(c, d.bins, (size_t)c->sectors * kBinCap * 2u, false)
+    ok = ok && dalloc(c, d.binCount, c->sectors) && dalloc(c, d.binLayers, c->sectors) && dalloc(c, d.bins, (size_t)c->sectors * kBinCap * 2u, false)
             && dalloc(c, d.bigList, N * 2u, false) && dalloc(c, d.bigBits[0], N / 32) && dalloc(c, d.bigBits[1], N / 32)
             && dalloc(c, d.pairs, c->maxPairs, false);
   }
@@ -445,6 +465,11 @@ int scTickUploadLocals(ScTickContext* c, uint32_t first, uint32_t count, const f
     if (rep) { a = b = z = 1.0f; }
     if (repaired) repaired[i] = rep ? 1 : 0;
     k[3 * (size_t)i] = a; k[3 * (size_t)i + 1] = b; k[3 * (size_t)i + 2] = z;
+    // an axis whose sin/cos came out as exactly (0, 1) need not be streamed by the kernels (link-word flag)
+    const uint8_t triv = (uint8_t)(((s[0][i] == 0.0f && s[1][i] == 1.0f) ? 4u : 0u) | ((s[2][i] == 0.0f && s[3][i] == 1.0f) ? 8u : 0u) |
+                                   ((s[4][i] == 0.0f && s[5][i] == 1.0f) ? 16u : 0u));
+    uint8_t& f = c->hFlags[first + i];
+    if ((f & 28u) != triv) { f = (uint8_t)((f & ~28u) | triv); c->linksStale = true; }
   }
   DeviceState& d = c->d;
   float* dst[6] = { d.rsx, d.rcx, d.rsy, d.rcy, d.rsz, d.rcz };

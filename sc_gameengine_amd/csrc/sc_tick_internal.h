@@ -9,23 +9,40 @@ namespace sctick {
 //   bits  0..23  dense index of the parent (kNoParent = root)          Transform::parent
 //   bit   24     has RenderMesh  (culling candidate)                   sc_world_partition.cpp:1206-1210
 //   bit   25     has Bounds                                            sc_world_partition.cpp:1252-1263
-//   bits 26..31  hierarchy depth: 0..kMaxChain exact, kDeep.. = handled by level kernels,
+//   bits 26..28  hierarchy depth: 0..kMaxChain exact, kDeep = deeper (handled by level kernels),
 //                kUnreachable = in/below a parent cycle (never visited, sc_ecs.cpp:173-210)
+//   bits 29..31  rotation about X / Y / Z is trivial: the uploaded sin is exactly 0 and cos exactly 1
+//                (angle 0), so the kernel substitutes the constants instead of streaming them
 constexpr uint32_t kParentMask  = 0x00FFFFFFu;
 constexpr uint32_t kNoParent    = 0x00FFFFFFu;
 constexpr uint32_t kHasMesh     = 1u << 24;
 constexpr uint32_t kHasBounds   = 1u << 25;
 constexpr uint32_t kDepthShift  = 26;
-constexpr uint32_t kMaxChain    = 4;      // ancestors the fused kernel walks itself
-constexpr uint32_t kDeep        = 62;     // depth > kMaxChain: level kernels
-constexpr uint32_t kUnreachable = 63;
+constexpr uint32_t kDepthMask   = 7u;
+constexpr uint32_t kMaxChain    = 3;      // ancestors the fused kernel walks itself
+constexpr uint32_t kDeep        = 5;      // depth > kMaxChain: level kernels
+constexpr uint32_t kUnreachable = 7;
+constexpr uint32_t kRotTrivialX = 1u << 29, kRotTrivialY = 1u << 30, kRotTrivialZ = 1u << 31;
+__host__ __device__ inline uint32_t linkDepth(uint32_t lk) { return (lk >> kDepthShift) & kDepthMask; }
 
 constexpr uint32_t kTile = 256;           // entities per workgroup pass (4 waves of 64)
 
 struct Frustum6 { float p[6][4]; };       // (nx, ny, nz, d) x 6, Frustum (sc_world_partition.h:39-43)
 
+// All 4-byte per-entity streams live in ONE slab, stream k at byte offset k * capBytes, so a kernel
+// addresses every stream from a single base (one SGPR pair, 32-bit lane offsets) instead of keeping
+// thirty pointers live in scalar registers.  The world-matrix rows form a second slab of float4.
+enum Stream : uint32_t {
+  kPX, kPY, kPZ, kRSX, kRCX, kRSY, kRCY, kRSZ, kRCZ, kSX, kSY, kSZ,
+  kBMINX, kBMINY, kBMINZ, kBMAXX, kBMAXY, kBMAXZ, kLINK, kLAYERS, kMESH, kMATERIAL, kStreamCount
+};
+
 // Device SoA state of one context.  All arrays are sized to `cap` (padded to kTile).
 struct DeviceState {
+  const char* fslab;        // kStreamCount streams x cap x 4 B
+  char* rslab;              // 3 row streams x cap x 16 B (w0, w1, w2)
+  uint32_t capBytes;        // cap * 4
+  uint32_t capBytes16;      // cap * 16
   // inputs: Transform locals (sc_ecs.h:63-71); rotation kept as host-libm sin/cos of the Euler angles
   float *px, *py, *pz;
   float *rsx, *rcx, *rsy, *rcy, *rsz, *rcz;
@@ -51,6 +68,7 @@ struct DeviceState {
   // broadphase
   float4 *aabbMin, *aabbMax;   // dense-order world AABBs (debug / read-back only: SC_TICK_DENSE_AABBS)
   uint32_t* binCount;          // records per sector bin (self-cleaning: the pair kernel zeroes what it read)
+  uint32_t* binLayers;         // OR of the records' (group | mask << 16) per bin: lets the pair kernel skip a bin unread
   float4* bins;                // [sector][kBinCap][2]: (min.xyz, layers) (max.xyz, id | primary<<31)
   float4* bigList;             // [cap][2] boxes that cannot be binned (too large, outside the rect, bin full)
   uint32_t* bigBits[2];        // per-entity "is in the big list" bit, double-buffered by tick parity
@@ -84,6 +102,7 @@ struct TickParams {
   uint32_t maxPairs;
   uint32_t rankBits;        // rank << 24, OR-ed into every box id
   uint32_t neighbourMask;   // bit d set: a neighbour tile exists in direction d (its ring side is foreign)
+  uint32_t variant;         // kernel variant selector (A/B tuning; 0 = default)
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d
 __host__ __device__ inline void borderDir(uint32_t d, int& dx, int& dz) { const uint32_t k = d < 4 ? d : d + 1; dx = (int)(k % 3) - 1; dz = (int)(k / 3) - 1; }
@@ -101,6 +120,7 @@ void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, h
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s);
+void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s);
 void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchBorderMerge(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s);

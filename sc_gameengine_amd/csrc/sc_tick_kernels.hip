@@ -24,17 +24,39 @@ __device__ __forceinline__ bool dirtyBit(const uint32_t* __restrict__ bits, uint
   return (bits[i >> 5] >> (i & 31u)) & 1u;
 }
 
+// slab accessors: base + (stream * capBytes + i * 4) with 32-bit offsets (saddr + voffset addressing)
+__device__ __forceinline__ float ldF(const DeviceState& d, uint32_t stream, uint32_t i)
+{
+  return *reinterpret_cast<const float*>(d.fslab + (stream * d.capBytes + i * 4u));
+}
+__device__ __forceinline__ uint32_t ldU(const DeviceState& d, uint32_t stream, uint32_t i)
+{
+  return *reinterpret_cast<const uint32_t*>(d.fslab + (stream * d.capBytes + i * 4u));
+}
+__device__ __forceinline__ float4 ldRow(const DeviceState& d, uint32_t row, uint32_t i)
+{
+  return *reinterpret_cast<const float4*>(d.rslab + (row * d.capBytes16 + i * 16u));
+}
+__device__ __forceinline__ void stRow(const DeviceState& d, uint32_t row, uint32_t i, const float4& v)
+{
+  *reinterpret_cast<float4*>(d.rslab + (row * d.capBytes16 + i * 16u)) = v;
+}
+
 // local = T * (R * S) with R = (Rz * Ry) * Rx  (sc_math.cpp:100-142).
 // The reference forms it with four full 4x4 products; multiplying by the exact 0 / 1 entries of
 // T, S and the axis rotations contributes +-0 terms or x*1, so the non-zero results below are the
 // same fp32 values (each sum keeps the reference's left-to-right order); only the sign of an
 // exact zero can differ.
-__device__ __forceinline__ Aff loadLocal(const DeviceState& d, uint32_t j)
+// lkj = link word of entity j: its kRotTrivial* bits say which axes were uploaded with sin == 0 and
+// cos == 1 exactly; those constants then replace the loads (same values, same arithmetic, same bits).
+__device__ __forceinline__ Aff loadLocal(const DeviceState& d, uint32_t j, uint32_t lkj)
 {
-  const float sx = d.rsx[j], cx = d.rcx[j];
-  const float sy = d.rsy[j], cy = d.rcy[j];
-  const float sz = d.rsz[j], cz = d.rcz[j];
-  const float kx = d.sx[j], ky = d.sy[j], kz = d.sz[j];
+  const uint32_t triv = lkj >> 29;                      // bit0 X, bit1 Y, bit2 Z
+  float sx = 0.0f, cx = 1.0f, sy = 0.0f, cy = 1.0f, sz = 0.0f, cz = 1.0f;
+  if (!(triv & 1u)) { sx = ldF(d, kRSX, j); cx = ldF(d, kRCX, j); }
+  if (!(triv & 2u)) { sy = ldF(d, kRSY, j); cy = ldF(d, kRCY, j); }
+  if (!(triv & 4u)) { sz = ldF(d, kRSZ, j); cz = ldF(d, kRCZ, j); }
+  const float kx = ldF(d, kSX, j), ky = ldF(d, kSY, j), kz = ldF(d, kSZ, j);
   // A = Rz * Ry
   const float a00 = cz * cy, a10 = sz * cy, a20 = -sy;
   const float a01 = -sz,     a11 = cz;                 // a21 = 0
@@ -44,9 +66,9 @@ __device__ __forceinline__ Aff loadLocal(const DeviceState& d, uint32_t j)
   const float r01 = a01 * cx + a02 * sx, r11 = a11 * cx + a12 * sx, r21 = a22 * sx;
   const float r02 = a01 * nsx + a02 * cx, r12 = a11 * nsx + a12 * cx, r22 = a22 * cx;
   Aff L;
-  L.r0[0] = a00 * kx; L.r0[1] = r01 * ky; L.r0[2] = r02 * kz; L.r0[3] = d.px[j];
-  L.r1[0] = a10 * kx; L.r1[1] = r11 * ky; L.r1[2] = r12 * kz; L.r1[3] = d.py[j];
-  L.r2[0] = a20 * kx; L.r2[1] = r21 * ky; L.r2[2] = r22 * kz; L.r2[3] = d.pz[j];
+  L.r0[0] = a00 * kx; L.r0[1] = r01 * ky; L.r0[2] = r02 * kz; L.r0[3] = ldF(d, kPX, j);
+  L.r1[0] = a10 * kx; L.r1[1] = r11 * ky; L.r1[2] = r12 * kz; L.r1[3] = ldF(d, kPY, j);
+  L.r2[0] = a20 * kx; L.r2[1] = r21 * ky; L.r2[2] = r22 * kz; L.r2[3] = ldF(d, kPZ, j);
   return L;
 }
 
@@ -68,7 +90,7 @@ __device__ __forceinline__ Aff mulAff(const Aff& P, const Aff& L)
 
 __device__ __forceinline__ Aff loadRows(const DeviceState& d, uint32_t j)
 {
-  const float4 a = d.w0[j], b = d.w1[j], c = d.w2[j];
+  const float4 a = ldRow(d, 0, j), b = ldRow(d, 1, j), c = ldRow(d, 2, j);
   Aff M;
   M.r0[0] = a.x; M.r0[1] = a.y; M.r0[2] = a.z; M.r0[3] = a.w;
   M.r1[0] = b.x; M.r1[1] = b.y; M.r1[2] = b.z; M.r1[3] = b.w;
@@ -77,16 +99,16 @@ __device__ __forceinline__ Aff loadRows(const DeviceState& d, uint32_t j)
 }
 __device__ __forceinline__ void storeRows(const DeviceState& d, uint32_t j, const Aff& M)
 {
-  d.w0[j] = make_float4(M.r0[0], M.r0[1], M.r0[2], M.r0[3]);
-  d.w1[j] = make_float4(M.r1[0], M.r1[1], M.r1[2], M.r1[3]);
-  d.w2[j] = make_float4(M.r2[0], M.r2[1], M.r2[2], M.r2[3]);
+  stRow(d, 0, j, make_float4(M.r0[0], M.r0[1], M.r0[2], M.r0[3]));
+  stRow(d, 1, j, make_float4(M.r1[0], M.r1[1], M.r1[2], M.r1[3]));
+  stRow(d, 2, j, make_float4(M.r2[0], M.r2[1], M.r2[2], M.r2[3]));
 }
 
 struct BoundsCE { float cx, cy, cz, ex, ey, ez; };
 __device__ __forceinline__ BoundsCE loadBounds(const DeviceState& d, uint32_t j)
 {
-  const float x0 = d.bminx[j], y0 = d.bminy[j], z0 = d.bminz[j];
-  const float x1 = d.bmaxx[j], y1 = d.bmaxy[j], z1 = d.bmaxz[j];
+  const float x0 = ldF(d, kBMINX, j), y0 = ldF(d, kBMINY, j), z0 = ldF(d, kBMINZ, j);
+  const float x1 = ldF(d, kBMAXX, j), y1 = ldF(d, kBMAXY, j), z1 = ldF(d, kBMAXZ, j);
   BoundsCE b;
   b.cx = (x0 + x1) * 0.5f; b.cy = (y0 + y1) * 0.5f; b.cz = (z0 + z1) * 0.5f;
   b.ex = (x1 - x0) * 0.5f; b.ey = (y1 - y0) * 0.5f; b.ez = (z1 - z0) * 0.5f;
@@ -180,8 +202,19 @@ __device__ __forceinline__ void binInsertWave(const DeviceState& d, bool want, u
   const unsigned long long above = (myHead == 63u) ? 0ull : ~((2ull << myHead) - 1ull);
   const unsigned long long ends = (heads | ~act) & above;
   const uint32_t runEnd = ends ? (uint32_t)__ffsll((long long)ends) - 1u : 64u;
+  // OR of the run's collision layers for the head lane.  Runs are almost always uniform (one layer
+  // word): one cross-lane read decides; only a wave with a mixed run pays the segmented OR.
+  uint32_t lay = want ? __float_as_uint(rmin.w) : 0u;
+  const uint32_t headLay = (uint32_t)__shfl((int)lay, (int)myHead, 64);
+  if (__ballot(want && headLay != lay)) {
+#pragma unroll
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+      const uint32_t other = (uint32_t)__shfl_down((int)lay, o, 64);
+      if (want && lane + o < runEnd) lay |= other;
+    }
+  }
   uint32_t base = 0;
-  if (head) base = atomicAdd(&d.binCount[sector], runEnd - lane);
+  if (head) { base = atomicAdd(&d.binCount[sector], runEnd - lane); atomicOr(&d.binLayers[sector], lay); }
   base = __shfl(base, myHead, 64);
   if (want) {
     const uint32_t slot = base + (lane - myHead);
@@ -202,7 +235,7 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
   if (collider) {
     worldAabb(M, b, mn, mx);
     plan = planBins(p, mn, mx);
-    rmin = make_float4(mn[0], mn[1], mn[2], __uint_as_float(d.layers[i]));
+    rmin = make_float4(mn[0], mn[1], mn[2], __uint_as_float(ldU(d, kLAYERS, i)));
     rmax = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i | p.rankBits));
     if (p.flags & kFlagDenseAabbs) { d.aabbMin[i] = rmin; d.aabbMax[i] = rmax; }
   } else if ((p.flags & kFlagDenseAabbs) && i < p.n) {
@@ -235,7 +268,7 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
   float mn[3], mx[3];
   worldAabb(M, b, mn, mx);
   const BinPlan plan = planBins(p, mn, mx);
-  const float4 rmin = make_float4(mn[0], mn[1], mn[2], __uint_as_float(d.layers[i]));
+  const float4 rmin = make_float4(mn[0], mn[1], mn[2], __uint_as_float(ldU(d, kLAYERS, i)));
   float4 rmax = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i | p.rankBits));
   if (p.flags & kFlagDenseAabbs) { d.aabbMin[i] = rmin; d.aabbMax[i] = rmax; }
   if (!plan.collide) return;
@@ -247,6 +280,7 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
     if (!(dx < plan.nx && dz < plan.nz)) continue;
     const uint32_t sector = (sz + dz) * p.binSX + (sx + dx);
     const uint32_t slot = atomicAdd(&d.binCount[sector], 1u);
+    atomicOr(&d.binLayers[sector], __float_as_uint(rmin.w));
     if (slot < kBinCap) {
       float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
       float4 rm = rmax; if (k == 0) rm.w = __uint_as_float(i | p.rankBits | kPrimary);
@@ -271,8 +305,18 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
 // workgroup ever waits for another one.  Everything above `top` is clean, hence its stored matrix
 // is not written by anyone this tick and can be read race-free.
 // ------------------------------------------------------------------------------------------
+template <bool kCull, bool kAabb, bool kEarly>
+__device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p);
+
 template <bool kCull, bool kAabb>
-__global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const TickParams p)
+__global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, false>(d, p); }
+
+// same body with the loads that depend only on the index (bounds) issued before the hierarchy walk
+template <bool kCull, bool kAabb>
+__global__ __launch_bounds__(kTile) void k_xform_cull_early(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, true>(d, p); }
+
+template <bool kCull, bool kAabb, bool kEarly>
+__device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p)
 {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
@@ -287,12 +331,19 @@ __global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const
   for (uint32_t base = begin; base < end; base += kTile) {
     const uint32_t i = base + threadIdx.x;
     const bool active = i < p.n;
-    const uint32_t lk = active ? d.link[i] : ((kUnreachable << kDepthShift) | kNoParent);
-    const uint32_t depth = lk >> kDepthShift;
+    const uint32_t lk = active ? ldU(d, kLINK, i) : ((kUnreachable << kDepthShift) | kNoParent);
+    const uint32_t depth = linkDepth(lk);
     const bool chain = depth <= kMaxChain;
+    // loads that depend on nothing but the index are issued first (they cannot be hoisted by the
+    // compiler across the matrix stores below: the SoA pointers may alias as far as it knows)
+    const bool candE = active && (lk & kHasMesh);
+    const bool hbE = active && (lk & kHasBounds);
+    BoundsCE bE = {0, 0, 0, 0, 0, 0};
+    if ((kCull || kAabb) && kEarly && hbE) bE = loadBounds(d, i);
 
     // ---- walk up: ancestors a[1..depth], top = dirty level nearest the root
-    uint32_t a[kMaxChain + 1];
+    uint32_t a[kMaxChain + 1];                         // ancestors
+    uint32_t rotFlags = lk >> 29;                      // 3 rotation-triviality bits per level, level k at bits 3k..3k+2
     a[0] = i;
     int top = -1;
     if (doXform && chain) {
@@ -303,7 +354,8 @@ __global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const
         a[k] = i;
         if (k <= depth) {
           a[k] = cur & kParentMask;
-          cur = d.link[a[k]];
+          cur = ldU(d, kLINK, a[k]);
+          rotFlags |= (cur >> 29) << (3u * k);
           if (dirtyBit(d.dirty, a[k])) top = (int)k;
         }
       }
@@ -318,13 +370,13 @@ __global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const
       const bool fromRoot = (uint32_t)top == depth;       // the chain's root itself is rebuilt: world = local
       if (!fromRoot) {
         // clean parent of the top dirty ancestor: its stored (possibly stale) matrix is the seed
-        const uint32_t seed = (top == 0) ? a[1] : (top == 1) ? a[2] : (top == 2) ? a[3] : a[4];
+        const uint32_t seed = (top == 0) ? a[1] : (top == 1) ? a[2] : a[3];
         M = loadRows(d, seed);
       }
 #pragma unroll
       for (int lev = (int)kMaxChain; lev >= 0; --lev) {
         if (lev <= top) {
-          const Aff L = loadLocal(d, a[lev]);
+          const Aff L = loadLocal(d, a[lev], (rotFlags >> (3 * lev)) << 29);
           if (lev == top && fromRoot) M = L;
           else M = mulAff(M, L);
         }
@@ -340,10 +392,10 @@ __global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const
     }
 
     if (kCull || kAabb) {
-      const bool cand = active && (lk & kHasMesh);
-      const bool hb = active && (lk & kHasBounds);
-      BoundsCE b = {0, 0, 0, 0, 0, 0};
-      if (hb) b = loadBounds(d, i);
+      const bool cand = candE;
+      const bool hb = hbE;
+      BoundsCE b = bE;
+      if (!kEarly && hb) b = loadBounds(d, i);
 
       if (kCull) {
         bool visible = cand;
@@ -382,6 +434,172 @@ __global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const
 }
 
 // ------------------------------------------------------------------------------------------
+// K1, wave-cooperative variant (experimental, SC_TICK_VARIANT bit 0; measured slower: 85-94 VGPRs).  Same results as k_xform_cull, fewer dependent memory
+// phases and no redundant ancestor work:
+//   phase A  link word + dirty word of the own entity                         (1 memory round trip)
+//   phase B  own locals (whenever the wave holds a dirty entity), bounds, or the stored rows
+//   resolve  a child whose parent sits in the SAME WAVE takes the parent's freshly built matrix with
+//            12 cross-lane reads (ds_bpermute), level by level -- parents are final before children
+//            because a child's depth is its parent's + 1.  world = parent * local is the very product
+//            TransformSystem's DFS forms, so the bits are the same.
+//   Only lanes whose parent lives outside the wave walk the chain through memory as k_xform_cull does.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ Aff shflAff(const Aff& M, uint32_t srcLane)
+{
+  Aff P;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    P.r0[k] = __shfl(M.r0[k], (int)srcLane, 64);
+    P.r1[k] = __shfl(M.r1[k], (int)srcLane, 64);
+    P.r2[k] = __shfl(M.r2[k], (int)srcLane, 64);
+  }
+  return P;
+}
+
+template <bool kCull, bool kAabb>
+__global__ __launch_bounds__(kTile) void k_xform_cull_coop(const DeviceState d, const TickParams p)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t begin = blockIdx.x * p.span;
+  const uint32_t end = (begin + p.span < p.n) ? begin + p.span : p.n;
+  const bool doXform = (p.flags & SC_TICK_XFORM) != 0;
+  const bool wantCand = (p.flags & SC_TICK_CULLED_LIST) != 0;
+  const bool hasDeep = (p.flags & kFlagHasDeep) != 0;
+
+  uint32_t visCount = 0, candCount = 0;
+
+  for (uint32_t base = begin; base < end; base += kTile) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t waveBase = base + wave * 64u;
+    const bool active = i < p.n;
+
+    // ---- phase A
+    const uint32_t lk = active ? ldU(d, kLINK, i) : ((kUnreachable << kDepthShift) | kNoParent);
+    const uint32_t dword = (doXform && active) ? d.dirty[i >> 5] : 0u;
+    const uint32_t depth = linkDepth(lk);
+    const uint32_t par = lk & kParentMask;
+    const bool chain = doXform && depth <= kMaxChain;
+    const bool selfDirty = chain && ((dword >> (i & 31u)) & 1u);
+    const uint32_t parLane = par - waveBase;                    // < 64 iff the parent is in this wave
+    const bool inWave = chain && depth >= 1u && parLane < 64u;
+    const bool slow = chain && depth >= 1u && !inWave;
+    const bool waveDirty = __ballot(selfDirty) != 0ull;
+    const bool cand = active && (lk & kHasMesh);
+    const bool hb = active && (lk & kHasBounds);
+
+    // ---- phase B loads that depend on nothing else
+    Aff L; bool haveL = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { L.r0[k] = 0.0f; L.r1[k] = 0.0f; L.r2[k] = 0.0f; }
+    if (waveDirty && chain) { L = loadLocal(d, i, lk); haveL = true; }
+    BoundsCE b = {0, 0, 0, 0, 0, 0};
+    if ((kCull || kAabb) && hb) b = loadBounds(d, i);
+
+    // ---- nodeDirty: own flag, chain walk for out-of-wave parents, then in-wave propagation by level
+    bool nd = selfDirty;
+    uint32_t a[kMaxChain + 1];
+    uint32_t rotFlags = lk >> 29;
+    int top = selfDirty ? 0 : -1;
+#pragma unroll
+    for (uint32_t k = 0; k <= kMaxChain; ++k) a[k] = i;
+    if (slow) {
+      uint32_t cur = lk;
+#pragma unroll
+      for (uint32_t k = 1; k <= kMaxChain; ++k) {
+        if (k <= depth) {
+          a[k] = cur & kParentMask;
+          cur = ldU(d, kLINK, a[k]);
+          rotFlags |= (cur >> 29) << (3u * k);
+          if (dirtyBit(d.dirty, a[k])) top = (int)k;
+        }
+      }
+      nd = top >= 0;
+    }
+#pragma unroll
+    for (uint32_t lev = 1; lev <= kMaxChain; ++lev) {
+      const bool mine = inWave && depth == lev;
+      if (!__ballot(mine)) continue;
+      const int pnd = __shfl((int)nd, (int)(parLane & 63u), 64);
+      if (mine) nd = nd || (pnd != 0);
+    }
+
+    // ---- matrices
+    Aff M;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { M.r0[k] = 0.0f; M.r1[k] = 0.0f; M.r2[k] = 0.0f; }
+    if (nd && !haveL) L = loadLocal(d, i, lk);                  // a clean wave reached through an outside ancestor
+    if (nd && depth == 0u) M = L;
+    if (nd && slow) {
+      const bool fromRoot = (uint32_t)top == depth;
+      if (!fromRoot) {
+        const uint32_t seed = (top == 0) ? a[1] : (top == 1) ? a[2] : a[3];
+        M = loadRows(d, seed);
+      }
+#pragma unroll
+      for (int lev = (int)kMaxChain; lev >= 0; --lev) {
+        if (lev <= top) {
+          const Aff Ll = (lev == 0) ? L : loadLocal(d, a[lev], (rotFlags >> (3 * lev)) << 29);
+          if (lev == top && fromRoot) M = Ll;
+          else M = mulAff(M, Ll);
+        }
+      }
+    }
+    if (!nd && (kCull || kAabb) && active) M = loadRows(d, i);
+#pragma unroll
+    for (uint32_t lev = 1; lev <= kMaxChain; ++lev) {
+      const bool mine = inWave && depth == lev && nd;
+      if (!__ballot(mine)) continue;
+      const int pnd = __shfl((int)nd, (int)(parLane & 63u), 64);
+      Aff P = shflAff(M, parLane & 63u);
+      if (mine) {
+        if (!pnd) P = loadRows(d, par);                         // clean parent: its stored (possibly stale) matrix
+        M = mulAff(P, L);
+      }
+    }
+    if (nd) storeRows(d, i, M);
+
+    if (hasDeep) {
+      const unsigned long long rm = __ballot(nd);
+      if (lane == 0 && waveBase < p.n) d.recomp[(base >> 6) + wave] = rm;
+    }
+
+    if (kCull || kAabb) {
+      if (kCull) {
+        bool visible = cand;
+        if (cand && hb && !p.freeze && p.frustumValid) {
+          float c0, c1, c2;
+          visible = sphereVisible(M, b, p.fr, c0, c1, c2);
+        }
+        if (doXform && depth > kMaxChain && depth != kUnreachable) visible = false;   // level kernels own these
+        const unsigned long long vm = __ballot(visible);
+        const unsigned long long cm = __ballot(cand);
+        if (lane == 0 && waveBase < p.n) {
+          d.vis[(base >> 6) + wave] = vm;
+          if (wantCand) d.cand[(base >> 6) + wave] = cm;
+        }
+        visCount += (uint32_t)__popcll(vm);
+        candCount += (uint32_t)__popcll(cm);
+      }
+      if (kAabb) {
+        const bool collider = hb && !(doXform && depth > kMaxChain && depth != kUnreachable);
+        binEntityWave(d, p, i, collider, M, b);
+      }
+    }
+  }
+
+  if (kCull) {
+    __shared__ uint32_t sVis[kTile / 64], sCand[kTile / 64];
+    if (lane == 0) { sVis[wave] = visCount; sCand[wave] = candCount; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      d.blockVis[blockIdx.x] = sVis[0] + sVis[1] + sVis[2] + sVis[3];
+      d.blockCand[blockIdx.x] = sCand[0] + sCand[1] + sCand[2] + sCand[3];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Level kernel for entities deeper than kMaxChain (rare): one launch per level, parents final.
 // nodeDirty = dirty || parent recomputed this tick (sc_ecs.cpp:184).
 // ------------------------------------------------------------------------------------------
@@ -391,7 +609,7 @@ __global__ __launch_bounds__(kTile) void k_deep_level(const DeviceState d, const
   const uint32_t t = blockIdx.x * kTile + threadIdx.x;
   if (t >= count) return;
   const uint32_t i = list[t];
-  const uint32_t lk = d.link[i];
+  const uint32_t lk = ldU(d, kLINK, i);
   const uint32_t par = lk & kParentMask;
   bool nodeDirty = false;
   Aff M;
@@ -399,7 +617,7 @@ __global__ __launch_bounds__(kTile) void k_deep_level(const DeviceState d, const
     nodeDirty = dirtyBit(d.dirty, i) || ((d.recomp[par >> 6] >> (par & 63u)) & 1ull);
     if (nodeDirty) {
       const Aff P = loadRows(d, par);
-      const Aff L = loadLocal(d, i);
+      const Aff L = loadLocal(d, i, lk);
       M = mulAff(P, L);
       storeRows(d, i, M);
       atomicOr((unsigned long long*)&d.recomp[i >> 6], 1ull << (i & 63u));
@@ -446,24 +664,23 @@ __device__ __forceinline__ uint32_t blockSum(uint32_t v, uint32_t* scratch)
   return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
-__global__ __launch_bounds__(kTile) void k_compact(const DeviceState d, const TickParams p)
+__device__ __forceinline__ void compactBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks, uint32_t* scratch)
 {
-  __shared__ uint32_t scratch[kTile / 64];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t begin = blockIdx.x * p.span;
+  const uint32_t begin = bid * p.span;
   const uint32_t end = (begin + p.span < p.n) ? begin + p.span : p.n;
   const bool doCull = (p.flags & SC_TICK_CULL) != 0;
   const bool doCulled = (p.flags & SC_TICK_CULLED_LIST) != 0;
 
   if (doCull) {
     uint32_t pv = 0, pc = 0;
-    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kTile) { pv += d.blockVis[j]; pc += d.blockCand[j]; }
+    for (uint32_t j = threadIdx.x; j < bid; j += kTile) { pv += d.blockVis[j]; pc += d.blockCand[j]; }
     uint32_t visBase = blockSum(pv, scratch);
     uint32_t culBase = blockSum(pc, scratch) - visBase;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-      const uint32_t tv = visBase + d.blockVis[blockIdx.x];
-      const uint32_t tc = culBase + visBase + d.blockCand[blockIdx.x];
+    if (bid == nblocks - 1 && threadIdx.x == 0) {
+      const uint32_t tv = visBase + d.blockVis[bid];
+      const uint32_t tc = culBase + visBase + d.blockCand[bid];
       d.counters[0] = tv;            // CullingStats::visible
       d.counters[1] = tc - tv;       // CullingStats::culled
       d.counters[6] = tc;            // renderablesTotal
@@ -503,6 +720,12 @@ __global__ __launch_bounds__(kTile) void k_compact(const DeviceState d, const Ti
   }
 }
 
+__global__ __launch_bounds__(kTile) void k_compact(const DeviceState d, const TickParams p)
+{
+  __shared__ uint32_t scratch[kTile / 64];
+  compactBody(d, p, blockIdx.x, gridDim.x, scratch);
+}
+
 // ------------------------------------------------------------------------------------------
 // K3: pair search.  One wave per sector bin (grid-stride): the bin's <= 64 records become an LDS
 // tile (lane i stages record i), the n(n-1)/2 record pairs are spread over the 64 lanes, each lane
@@ -537,14 +760,14 @@ __device__ __forceinline__ void emitPair(const DeviceState& d, const TickParams&
   }
 }
 
-__global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const TickParams p)
+constexpr uint32_t kPairTabSize = kBinCap * (kBinCap - 1) / 2;
+__device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks,
+                                          float4 (*tile)[2 * kBinCap], uint16_t* pairTab)
 {
-  __shared__ float4 tile[kTile / 64][2 * kBinCap];        // 2 KiB per wave: the bin as an LDS tile
-  __shared__ uint16_t pairTab[kBinCap * (kBinCap - 1) / 2]; // q -> (i << 8 | j), 0 <= j < i < 64
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t waveGlobal = blockIdx.x * (kTile / 64) + wave;
-  const uint32_t totalWaves = gridDim.x * (kTile / 64);
+  const uint32_t waveGlobal = bid * (kTile / 64) + wave;
+  const uint32_t totalWaves = nblocks * (kTile / 64);
   const uint32_t sectors = p.binSX * p.binSZ;
   const uint32_t ctr = kCtrPar + 8u * p.parity;
   const uint32_t nbig = d.counters[ctr + kCtrBig];
@@ -556,11 +779,11 @@ __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const Tick
     for (uint32_t j = lane; j < i; j += 64u) pairTab[i * (i - 1u) / 2u + j] = (uint16_t)(i << 8 | j);
 
   // next tick's counter set and big bits start clean
-  if (blockIdx.x == 0 && threadIdx.x < 8) d.counters[kCtrPar + 8u * (p.parity ^ 1u) + threadIdx.x] = 0u;
+  if (bid == 0 && threadIdx.x < 8) d.counters[kCtrPar + 8u * (p.parity ^ 1u) + threadIdx.x] = 0u;
   {
     const uint32_t words = (p.n + 31u) >> 5;
     uint32_t* nextBits = d.bigBits[p.parity ^ 1u];
-    for (uint32_t w = blockIdx.x * kTile + threadIdx.x; w < words; w += gridDim.x * kTile) nextBits[w] = 0u;
+    for (uint32_t w = bid * kTile + threadIdx.x; w < words; w += nblocks * kTile) nextBits[w] = 0u;
   }
   __syncthreads();
 
@@ -569,7 +792,15 @@ __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const Tick
   for (uint32_t chunk = waveGlobal; chunk < sectors; chunk += 64u * totalWaves) {
     const uint32_t mySector = chunk + lane * totalWaves;
     uint32_t myCount = 0;
-    if (mySector < sectors) { myCount = d.binCount[mySector]; if (myCount) d.binCount[mySector] = 0u; }
+    if (mySector < sectors) {
+      myCount = d.binCount[mySector];
+      if (myCount) {
+        const uint32_t lay = d.binLayers[mySector];
+        d.binCount[mySector] = 0u; d.binLayers[mySector] = 0u;
+        // no record of this bin can pass the group/mask filter against another one: nothing to read
+        if (nbig == 0u && ((lay & 0xFFFFu) & (lay >> 16)) == 0u) myCount = 0u;
+      }
+    }
     if (myCount > kBinCap) myCount = kBinCap;
     const unsigned long long work = __ballot(myCount != 0u);
     if (!work) continue;
@@ -609,29 +840,44 @@ __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const Tick
         const int dx = gx == 0 ? -1 : (gx == p.binSX - 1u ? 1 : 0), dz = gz == 0 ? -1 : (gz == p.binSZ - 1u ? 1 : 0);
         if ((dx != 0 && hasNb(p, dx, 0)) || (dz != 0 && hasNb(p, 0, dz))) valid = false;   // nearest tile is not this one
       }
-      T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
-      __builtin_amdgcn_wave_barrier();
+      // Filter first (integer, cheap): like btDbvtBroadphase, which keeps static bodies in a separate set
+      // and never tests fixed-vs-fixed, a record that cannot pass (a.group & b.mask) && (b.group & a.mask)
+      // against ANY other record of this bin is dropped before the box tests, and a bin without a single
+      // admissible record (e.g. only static props: group 2 / mask 1) is skipped altogether.  The reported
+      // pair set is unchanged -- the filter is part of the pair predicate either way.
+      uint32_t lay = valid ? __float_as_uint(rmin.w) : 0u;
+      uint32_t all = lay;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) all |= (uint32_t)__shfl_xor((int)all, o, 64);
+      const bool admissible = valid && ((lay & 0xFFFFu) & (all >> 16)) != 0u && ((all & 0xFFFFu) & (lay >> 16)) != 0u;
+      const unsigned long long validMask = __ballot(admissible);
+      const bool anyPairs = __popcll(validMask) >= 2;
       const float secX = (float)(s % p.binSX), secZ = (float)(s / p.binSX);
-      const unsigned long long validMask = __ballot(valid);
-
-      const uint32_t npairs = n * (n - 1u) / 2u;
-      for (uint32_t q0 = 0; q0 < npairs; q0 += 64u) {
-        const uint32_t q = q0 + lane;
-        bool hit = false;
-        uint32_t ia = 0, ib = 0;
-        if (q < npairs) {
-          const uint32_t ij = pairTab[q];
-          const uint32_t i = ij >> 8, j = ij & 255u;
-          if ((validMask >> i) & (validMask >> j) & 1ull) {
-            const float4 amin = T[2u * i], amax = T[2u * i + 1u], bmin = T[2u * j], bmax = T[2u * j + 1u];
-            if (boxesOverlap(amin, amax, bmin, bmax) && filterPass(__float_as_uint(amin.w), __float_as_uint(bmin.w))) {
-              ia = __float_as_uint(amax.w) & ~kPrimary; ib = __float_as_uint(bmax.w) & ~kPrimary;
-              const float lx = amin.x > bmin.x ? amin.x : bmin.x, lz = amin.z > bmin.z ? amin.z : bmin.z;
-              hit = ia != ib && (floorf(lx * p.invSector) - p.binOx) == secX && (floorf(lz * p.invSector) - p.binOz) == secZ;
+      if (anyPairs) {
+        T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t npairs = n * (n - 1u) / 2u;
+        for (uint32_t q0 = 0; q0 < npairs; q0 += 64u) {
+          const uint32_t q = q0 + lane;
+          bool hit = false;
+          uint32_t ia = 0, ib = 0;
+          if (q < npairs) {
+            const uint32_t ij = pairTab[q];
+            const uint32_t i = ij >> 8, j = ij & 255u;
+            if ((validMask >> i) & (validMask >> j) & 1ull) {
+              const float4 amin = T[2u * i], bmin = T[2u * j];
+              if (filterPass(__float_as_uint(amin.w), __float_as_uint(bmin.w))) {
+                const float4 amax = T[2u * i + 1u], bmax = T[2u * j + 1u];
+                if (boxesOverlap(amin, amax, bmin, bmax)) {
+                  ia = __float_as_uint(amax.w) & ~kPrimary; ib = __float_as_uint(bmax.w) & ~kPrimary;
+                  const float lx = amin.x > bmin.x ? amin.x : bmin.x, lz = amin.z > bmin.z ? amin.z : bmin.z;
+                  hit = ia != ib && (floorf(lx * p.invSector) - p.binOx) == secX && (floorf(lz * p.invSector) - p.binOz) == secZ;
+                }
+              }
             }
           }
+          emitPair(d, p, hit, ia, ib);
         }
-        emitPair(d, p, hit, ia, ib);
       }
 
       // big boxes against this bin's primary records (each binned box has exactly one primary copy)
@@ -663,6 +909,23 @@ __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const Tick
       emitPair(d, p, hit, __float_as_uint(gmax.w), jid);
     }
   }
+}
+
+__global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const TickParams p)
+{
+  __shared__ float4 tile[kTile / 64][2 * kBinCap];        // 2 KiB per wave: the bin as an LDS tile
+  __shared__ uint16_t pairTab[kPairTabSize];              // q -> (i << 8 | j), 0 <= j < i < 64
+  pairsBody(d, p, blockIdx.x, gridDim.x, tile, pairTab);
+}
+
+// compaction and pair search both depend only on the fused kernel: one launch, workgroups split by role
+__global__ __launch_bounds__(kTile) void k_compact_pairs(const DeviceState d, const TickParams p, uint32_t compactBlocks)
+{
+  __shared__ float4 tile[kTile / 64][2 * kBinCap];
+  __shared__ uint16_t pairTab[kPairTabSize];
+  __shared__ uint32_t scratch[kTile / 64];
+  if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, scratch);
+  else pairsBody(d, p, blockIdx.x - compactBlocks, gridDim.x - compactBlocks, tile, pairTab);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -762,6 +1025,7 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
       const uint32_t slot0 = atomicAdd(&d.binCount[sector], c);
       const float4* src = reinterpret_cast<const float4*>(msg + kBorderHeader + L) + 2u * (size_t)sOff[threadIdx.x];
       for (uint32_t r = 0; r < c; ++r) {
+        atomicOr(&d.binLayers[sector], __float_as_uint(src[2u * r].w));
         if (slot0 + r < kBinCap) {
           float4* dst = d.bins + 2u * ((size_t)sector * kBinCap + slot0 + r);
           dst[0] = src[2u * r]; dst[1] = src[2u * r + 1u];
@@ -779,7 +1043,7 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
 __global__ __launch_bounds__(kTile) void k_nudge_roots_x(const DeviceState d, uint32_t n, float dx)
 {
   const uint32_t i = blockIdx.x * kTile + threadIdx.x;
-  const bool root = i < n && (d.link[i] & kParentMask) == kNoParent && (d.link[i] >> kDepthShift) != kUnreachable;
+  const bool root = i < n && (d.link[i] & kParentMask) == kNoParent && linkDepth(d.link[i]) != kUnreachable;
   if (root) d.px[i] = d.px[i] + dx;
   const unsigned long long m = __ballot(root);
   const uint32_t lane = threadIdx.x & 63u;
@@ -825,7 +1089,7 @@ __global__ __launch_bounds__(kTile) void k_emit_draws(const DeviceState d, uint3
   if (blockIdx.x == 0 && threadIdx.x == 0) { d.counters[4] = emitted; d.counters[5] = visible - emitted; }
   for (uint32_t t = blockIdx.x * kTile + threadIdx.x; t < emitted; t += gridDim.x * kTile) {
     const uint32_t j = d.visibleIdx[t];
-    const float4 a = d.w0[j], b = d.w1[j], c = d.w2[j];
+    const float4 a = ldRow(d, 0, j), b = ldRow(d, 1, j), c = ldRow(d, 2, j);
     float4* o = reinterpret_cast<float4*>(&items[t]);
     o[0] = make_float4(__uint_as_float(j), __uint_as_float(d.meshId[j]), __uint_as_float(d.materialId[j]), 0.0f);
     o[1] = make_float4(a.x, b.x, c.x, 0.0f);     // column 0
@@ -841,6 +1105,20 @@ __global__ __launch_bounds__(kTile) void k_emit_draws(const DeviceState d, uint3
 void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
 {
   const bool cull = (p.flags & SC_TICK_CULL) != 0, aabb = (p.flags & SC_TICK_BROADPHASE) != 0;
+  if (p.variant & 1u) {                                       // experimental: wave-cooperative variant (slower: VGPR-bound)
+    if (cull && aabb) hipLaunchKernelGGL((k_xform_cull_coop<true, true>), dim3(grid), dim3(kTile), 0, s, d, p);
+    else if (cull)    hipLaunchKernelGGL((k_xform_cull_coop<true, false>), dim3(grid), dim3(kTile), 0, s, d, p);
+    else if (aabb)    hipLaunchKernelGGL((k_xform_cull_coop<false, true>), dim3(grid), dim3(kTile), 0, s, d, p);
+    else              hipLaunchKernelGGL((k_xform_cull_coop<false, false>), dim3(grid), dim3(kTile), 0, s, d, p);
+    return;
+  }
+  if (p.variant & 2u) {                                       // bounds loaded before the hierarchy walk
+    if (cull && aabb) hipLaunchKernelGGL((k_xform_cull_early<true, true>), dim3(grid), dim3(kTile), 0, s, d, p);
+    else if (cull)    hipLaunchKernelGGL((k_xform_cull_early<true, false>), dim3(grid), dim3(kTile), 0, s, d, p);
+    else if (aabb)    hipLaunchKernelGGL((k_xform_cull_early<false, true>), dim3(grid), dim3(kTile), 0, s, d, p);
+    else              hipLaunchKernelGGL((k_xform_cull_early<false, false>), dim3(grid), dim3(kTile), 0, s, d, p);
+    return;
+  }
   if (cull && aabb) hipLaunchKernelGGL((k_xform_cull<true, true>), dim3(grid), dim3(kTile), 0, s, d, p);
   else if (cull)    hipLaunchKernelGGL((k_xform_cull<true, false>), dim3(grid), dim3(kTile), 0, s, d, p);
   else if (aabb)    hipLaunchKernelGGL((k_xform_cull<false, true>), dim3(grid), dim3(kTile), 0, s, d, p);
@@ -860,8 +1138,17 @@ void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s)
   const uint32_t sectors = p.binSX * p.binSZ;
   if (!sectors) return;
   uint32_t grid = (sectors + 3u) / 4u;
-  if (grid > 2048u) grid = 2048u;
+  const uint32_t cap = (p.variant >> 8) ? (p.variant >> 8) : 2048u;     // SC_TICK_VARIANT bits 8+: pair-kernel grid cap (tuning)
+  if (grid > cap) grid = cap;
   hipLaunchKernelGGL(k_pairs, dim3(grid), dim3(kTile), 0, s, d, p);
+}
+void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s)
+{
+  const uint32_t sectors = p.binSX * p.binSZ;
+  uint32_t pairGrid = (sectors + 3u) / 4u;
+  const uint32_t cap = (p.variant >> 8) ? (p.variant >> 8) : 2048u;
+  if (pairGrid > cap) pairGrid = cap;
+  hipLaunchKernelGGL(k_compact_pairs, dim3(compactGrid + pairGrid), dim3(kTile), 0, s, d, p, compactGrid);
 }
 void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s)
 {
