@@ -39,7 +39,7 @@ def algorithmic_bytes_per_entity(child_frac, stages):
     return b
 
 
-def pmc_traffic(stages, entities_per_gpu):
+def pmc_traffic(stages, entities_per_gpu, workload="config3"):
     """HBM bytes per k_xform_cull launch from the committed rocprofv3 PMC passes (tools/pmc_session.sh ->
     profiles/pmc_traffic.json): FETCH_SIZE and WRITE_SIZE collected in separate passes and calibrated on
     known-byte copy kernels of the same access widths (FETCH_SIZE under-counts 2x on gfx950).  None when
@@ -50,7 +50,7 @@ def pmc_traffic(stages, entities_per_gpu):
     except Exception:
         return None
     cfg = d.get("bench_config", {})
-    if sorted(cfg.get("stages", [])) != sorted(stages) or cfg.get("entities_per_gpu") != entities_per_gpu:
+    if sorted(cfg.get("stages", [])) != sorted(stages) or cfg.get("entities_per_gpu") != entities_per_gpu or cfg.get("workload", "config3") != workload:
         return None
     return d.get("kernels", {}).get("k_xform_cull", {}).get("hbm_bytes_per_launch")
 
@@ -67,8 +67,12 @@ def cpu_baseline(world, ticks=20, warm=3):
                                         has_mesh=world.has_mesh, has_bounds=world.has_bounds)
     ow.add_camera_entity(world.camera["pos"], world.camera["rot"], aspect=world.camera["aspect"])
     times = []
+    vel = None if world.mover_kind is None else world.mover_vel.copy()
     for k in range(warm + ticks):
-        ow.nudge_roots_x(0.01)
+        if vel is None:
+            ow.nudge_roots_x(0.01)
+        else:
+            ow.advance_movers(world.mover_kind, vel, world.mover_lo, world.mover_hi, 1.0 / 60.0)
         t0 = time.perf_counter()
         ow.tick()
         dt = time.perf_counter() - t0
@@ -79,7 +83,8 @@ def cpu_baseline(world, ticks=20, warm=3):
     oracle.lib().orc_jobs_init(0)
     med = float(np.median(times))
     return {"value": world.n / med, "unit": "entities/s", "cores": workers + 1, "kind": "port",
-            "sample": f"same world ({world.n} entities), {warm} warm-up + {ticks} timed ticks, all roots nudged each tick, "
+            "sample": f"same world ({world.n} entities), {warm} warm-up + {ticks} timed ticks, "
+                      f"{'all roots nudged' if vel is None else 'movers advanced'} each tick, "
                       f"median tick {med * 1e3:.1f} ms (xform+camera+cull), host cpus {hw}",
             "visible": vis}
 
@@ -92,6 +97,9 @@ def main():
     ap.add_argument("--sectors", type=int, default=TILE_SECTORS, help="tile side in sectors (default 256 = 1M entities per GPU)")
     ap.add_argument("--stages", default="auto", help="comma list of xform,cull,broadphase (auto = all that are built)")
     ap.add_argument("--graph", type=int, default=0, help="replay the frame from a hipGraph")
+    ap.add_argument("--workload", default="config3", choices=["config3", "config5"],
+                    help="config3: 16 static entities per sector, every root nudged each step (the metric's config); "
+                         "config5: 16 static + 12 vehicles + 4 peds per sector, agents advanced on device each step")
     ap.add_argument("--sample", type=int, default=8, help="record HIP events on every n-th step (1 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
@@ -122,9 +130,15 @@ def main():
     tx, tz = grid
     S = args.sectors
     origin = ((rank % tx) * S, (rank // tx) * S)
-    w = sw.generate(S, S, PROPS, hierarchy=True, origin=origin)
-    cam = sw.default_camera(float(tx * S) * 64.0)
-    cam["pos"][2] = np.float32(float(tz * S) * 64.0 / 2)
+    if args.workload == "config5":
+        SX, SZ = S // 2, S                       # 128 x 256 sectors x 32 entities = the same 1 048 576 per GPU
+        origin = ((rank % tx) * SX, (rank // tx) * SZ)
+        w = sw.generate_config5(SX, SZ, origin=origin)
+    else:
+        SX, SZ = S, S
+        w = sw.generate(S, S, PROPS, hierarchy=True, origin=origin)
+    cam = sw.default_camera(float(tx * SX) * 64.0)
+    cam["pos"][2] = np.float32(float(tz * SZ) * 64.0 / 2)
     w.camera = cam
 
     built = ["xform", "cull"] + (["broadphase"] if capi.HAVE_PAIR_SEARCH else [])
@@ -149,8 +163,14 @@ def main():
         t.set_stream(torch.cuda.current_stream().cuda_stream)
         borders = tiles.BorderBuffers(t, rank, grid, torch.device("cuda", local_rank))
 
+    def produce():
+        if args.workload == "config5":
+            t.advance_movers(1.0 / 60.0)          # vehicles + peds move, props stay clean (50 % dirty)
+        else:
+            t.nudge_roots_x(0.01)                 # every root moves (everything dirty)
+
     def step():
-        t.nudge_roots_x(0.01)
+        produce()
         if borders is None:
             t.run(flags)
         else:
@@ -190,6 +210,10 @@ def main():
         n_total = w.n * world_size
         child_frac = float((w.parent >= 0).mean())
         bpe = algorithmic_bytes_per_entity(child_frac, stages)
+        if args.workload == "config5":
+            # only the movers (half the world, all roots) are rebuilt: they read 40 B of locals and write 48 B;
+            # the clean half re-reads its stored matrix (48 B) for the sphere test / AABB instead
+            bpe = 0.5 * 88.0 + 0.5 * 48.0 + (24.0 if ("cull" in stages or "broadphase" in stages) else 0.0) + (32.0 if "broadphase" in stages else 0.0)
         k1_ms = float(np.mean(k1)) if len(k1) else float("nan")
         achieved = (w.n * bpe) / (k1_ms * 1e-3) / 1e9 if len(k1) else None
         out = {
@@ -206,8 +230,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"SynthWorld v1 config 3 per GPU: {S}x{S} sectors x (15 props + ground) = {w.n} entities, "
-                            f"depths 0/1/2, every root nudged +0.01 m in x and marked dirty each step",
+                "workload": (f"SynthWorld v1 config 3 per GPU: {SX}x{SZ} sectors x (15 props + ground) = {w.n} entities, "
+                             f"depths 0/1/2, every root nudged +0.01 m in x and marked dirty each step") if args.workload == "config3" else
+                            (f"SynthWorld v1 config 5 per GPU: {SX}x{SZ} sectors x (ground + 15 props + 12 vehicles + 4 peds) = {w.n} "
+                             f"entities, vehicles and peds advanced on device each step (dt 1/60), props static"),
                 "stages": stages,
                 "tiles": f"{tx}x{tz}",
                 "entities_total": n_total,
@@ -223,7 +249,7 @@ def main():
                 "bound": "hbm", "kernel": "k_xform_cull",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": pmc_traffic(stages, w.n),
+                "traffic": pmc_traffic(stages, w.n, args.workload),
                 "bytes_per_entity": bpe, "avg_launch_ms": k1_ms, "launches_timed": int(len(k1)),
                 "other_kernels_ms": {"k_compact": float(np.mean(k2)) if len(k2) else None,
                                      "k_nudge_roots_x": float(np.mean(kn)) if len(kn) else None,

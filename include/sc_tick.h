@@ -98,7 +98,7 @@ typedef struct ScTickDrawItem  /* DrawItem, sc_ecs.h:159-165: 80 bytes, model at
 } ScTickDrawItem;
 
 /* kernels whose per-launch durations scTickGetKernelTimes reports */
-enum { SC_TICK_K_XFORM_CULL = 0, SC_TICK_K_COMPACT = 1, SC_TICK_K_PAIRS = 2, SC_TICK_K_NUDGE = 3, SC_TICK_K_COUNT = 4 };
+enum { SC_TICK_K_XFORM_CULL = 0, SC_TICK_K_COMPACT = 1, SC_TICK_K_PAIRS = 2, SC_TICK_K_NUDGE = 3 /* producer: nudge or movers */, SC_TICK_K_COUNT = 4 };
 
 uint32_t       scTickGetApiVersion(void);
 ScTickContext* scTickCreateContext(const ScTickContextDesc* desc);
@@ -175,6 +175,18 @@ int scTickRunPairs(ScTickContext* ctx);
  * RCCL calls are ordered on; NULL returns to the context's own stream */
 int scTickSetStream(ScTickContext* ctx, void* hip_stream);
 
+/* ---- upstream movers (the step before the path) ----
+ * The engine's on-rails traffic tier writes Transform::localPos every fixed step and marks it dirty
+ * (src/engine/traffic/sc_traffic_ai.cpp:434-460, speed 12 m/s src/engine/traffic/sc_traffic_lanes.h:17).
+ * SynthWorld's movers are that model reduced to straight segments inside the agent's sector:
+ *   kind 1 (vehicle): pos += vel*dt, wrapping inside [lo, hi) on x and z
+ *   kind 2 (ped):     pos += vel*dt, reflecting at lo / hi (the velocity component flips)
+ * Only localPos.x / .z change; the moved entities are marked dirty, exactly as setLocalPosition does. */
+int scTickUploadMovers(ScTickContext* ctx, uint32_t first, uint32_t count, const uint8_t* kind,
+                       const float* vel_xz2, const float* lo_xz2, const float* hi_xz2);
+int scTickAdvanceMovers(ScTickContext* ctx, float dt);
+int scTickReadMoverVelocities(ScTickContext* ctx, uint32_t first, uint32_t count, float* vel_xz2);
+
 /* ---- results (each synchronises the stream) ---- */
 int scTickGetCounts(ScTickContext* ctx, ScTickCounts* out);
 int scTickReadVisible(ScTickContext* ctx, uint32_t* dense_indices, uint32_t capacity, uint32_t* count);
@@ -186,7 +198,8 @@ int scTickReadWorldMatricesIndexed(ScTickContext* ctx, const uint32_t* dense_ind
 int scTickReadDirty(ScTickContext* ctx, uint32_t first, uint32_t count, uint8_t* dirty);
 int scTickReadPositions(ScTickContext* ctx, uint32_t first, uint32_t count, float* pos3);
 int scTickReadWorldAabbs(ScTickContext* ctx, uint32_t first, uint32_t count, float* min3, float* max3);
-/* pairs (a, b) of dense indices, a < b, unordered list */
+/* pairs (a, b), a < b, unordered list; *count = pairs found.  The device keeps the list in 64 equal
+ * segments (max_pairs / 64 each); at most that many pairs per segment are kept, pairs_truncated tells. */
 int scTickReadPairs(ScTickContext* ctx, uint32_t* pairs2, uint32_t capacity, uint32_t* count);
 int scTickReadDraws(ScTickContext* ctx, ScTickDrawItem* items, uint32_t capacity, uint32_t* count);
 

@@ -106,6 +106,7 @@ def lib():
     L.orc_broadphase_grid.argtypes = [C.c_uint32, F32P, F32P, U32P, U32P, C.c_float, U32P, C.c_uint64]
     L.orc_broadphase_grid.restype = C.c_uint64
     L.orc_tick.argtypes = [vp, C.POINTER(CameraState), C.POINTER(CullingState)]
+    L.orc_advance_movers.argtypes = [vp, U8P, F32P, F32P, F32P, C.c_float]
     _LIB = L
     return L
 
@@ -302,6 +303,13 @@ class OracleWorld:
     def mark_dirty(self, entities):
         e = np.ascontiguousarray(entities, np.uint32)
         self.L.orc_mark_dirty(self.w, len(e), _u(e))
+
+    def advance_movers(self, kind, vel, lo, hi, dt):
+        """vel (n,2) float32 is updated in place (peds reflect)"""
+        k = np.ascontiguousarray(kind, np.uint8)
+        assert vel.dtype == np.float32 and vel.flags.c_contiguous
+        lo, hi = _c32(lo), _c32(hi)
+        self.L.orc_advance_movers(self.w, k.ctypes.data_as(U8P), _f(vel), _f(lo), _f(hi), float(dt))
 
     # systems
     def transform_system(self):

@@ -801,6 +801,28 @@ void orc_world_to_sector(float sectorSize, float x, float z, int32_t* sx, int32_
   *sz = (int32_t)floorf(z * inv);
 }
 
+/* Upstream movers: pos += vel*dt (two roundings), vehicles (1) wrap inside [lo,hi), peds (2) reflect. */
+void orc_advance_movers(OrcWorld* w, const uint8_t* kind, float* vel, const float* lo, const float* hi, float dt)
+{
+  OrcTransform* d = (OrcTransform*)w->transforms.data;
+  for (uint32_t i = 0; i < w->transforms.size; ++i) {
+    if (!kind[i]) continue;
+    float vx = vel[2 * i], vz = vel[2 * i + 1];
+    const float lox = lo[2 * i], loz = lo[2 * i + 1], hix = hi[2 * i], hiz = hi[2 * i + 1];
+    float x = d[i].localPos[0] + vx * dt, z = d[i].localPos[2] + vz * dt;
+    if (kind[i] == 1) {
+      if (x >= hix) x = lox + (x - hix); else if (x < lox) x = hix - (lox - x);
+      if (z >= hiz) z = loz + (z - hiz); else if (z < loz) z = hiz - (loz - z);
+    } else {
+      if (x > hix) { x = hix - (x - hix); vx = -vx; } else if (x < lox) { x = lox + (lox - x); vx = -vx; }
+      if (z > hiz) { z = hiz - (z - hiz); vz = -vz; } else if (z < loz) { z = loz + (loz - z); vz = -vz; }
+      vel[2 * i] = vx; vel[2 * i + 1] = vz;
+    }
+    d[i].localPos[0] = x; d[i].localPos[2] = z;
+    d[i].dirty = 1;
+  }
+}
+
 void orc_tick(OrcWorld* w, OrcCameraState* cam, OrcCullingState* cull)
 {
   orc_transform_system(w);

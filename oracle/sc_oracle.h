@@ -164,6 +164,10 @@ uint64_t orc_broadphase_grid(uint32_t n, const float* min3, const float* max3,
                              const uint32_t* group, const uint32_t* mask, float cellSize,
                              uint32_t* pairs2, uint64_t cap);
 
+/* ---- upstream movers (own spec, include/sc_tick.h "upstream movers"; model after the on-rails tier,
+ *      sc_traffic_ai.cpp:434-460): dense-order arrays; vel is updated in place for reflecting peds ---- */
+void orc_advance_movers(OrcWorld* w, const uint8_t* kind, float* vel_xz2, const float* lo_xz2, const float* hi_xz2, float dt);
+
 /* ---- whole-tick convenience for the cpu_baseline leg: Transform + Camera + Culling ---- */
 void orc_tick(OrcWorld* w, OrcCameraState* cam, OrcCullingState* cull);
 

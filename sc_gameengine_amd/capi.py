@@ -66,6 +66,9 @@ SYMBOLS = {
     "scTickBindBorderBuffers": (C.c_int, [_CTX, C.c_uint32, C.c_void_p, C.c_void_p]),
     "scTickRunPairs": (C.c_int, [_CTX]),
     "scTickSetStream": (C.c_int, [_CTX, C.c_void_p]),
+    "scTickUploadMovers": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P, F32P, F32P, F32P]),
+    "scTickAdvanceMovers": (C.c_int, [_CTX, C.c_float]),
+    "scTickReadMoverVelocities": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
     "scTickSetViewProj": (C.c_int, [_CTX, F32P]),
     "scTickSetFrustumPlanes": (C.c_int, [_CTX, F32P, C.c_int]),
     "scTickGetFrustumPlanes": (C.c_int, [_CTX, F32P, C.POINTER(C.c_int)]),

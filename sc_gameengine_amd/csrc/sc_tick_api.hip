@@ -72,6 +72,8 @@ struct ScTickContext
 
   // broadphase
   uint32_t sectors = 0, maxPairs = 0;
+  uint2* dPairsOut = nullptr;          // gathered (contiguous) pair list for read-back
+  uint32_t* dPairTotal = nullptr;      // [0] pairs found, [1] truncated flag
   uint32_t parity = 0, lastParity = 0;
   uint32_t rank = 0, neighbourMask = 0;
   bool pairsPending = false;
@@ -403,11 +405,13 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
           && dalloc(c, d.aabbMin, N) && dalloc(c, d.aabbMax, N);
   c->sectors = desc->tile_sectors_x ? (desc->tile_sectors_x + 2u) * (desc->tile_sectors_z + 2u) : 0u;
   c->maxPairs = desc->max_pairs ? desc->max_pairs : desc->capacity * 4u;
+  c->maxPairs = ((c->maxPairs + kPairShards - 1u) / kPairShards) * kPairShards;   // equal shard segments
   if (ok && c->sectors) {
     if ((uint64_t)desc->tile_sectors_x * desc->tile_sectors_z > (1u << 24)) ok = fail(c, "tile rectangle too large");
     ok = ok && dalloc(c, d.binCount, c->sectors) && dalloc(c, d.binLayers, c->sectors) && dalloc(c, d.bins, (size_t)c->sectors * kBinCap * 2u, false)
             && dalloc(c, d.bigList, N * 2u, false) && dalloc(c, d.bigBits[0], N / 32) && dalloc(c, d.bigBits[1], N / 32)
-            && dalloc(c, d.pairs, c->maxPairs, false);
+            && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, 2u * kPairShards * kShardStride)
+            && dalloc(c, c->dPairsOut, c->maxPairs, false) && dalloc(c, c->dPairTotal, 4);
   }
   if (ok) { void* p = nullptr; e = hipMalloc(&p, N * sizeof(ScTickDrawItem)); if (e != hipSuccess) ok = fail(c, "hipMalloc draws", e); else { c->allocs.push_back(p); c->dDraws = p; } }
   if (ok) {
@@ -759,6 +763,53 @@ int scTickNudgeRootsX(ScTickContext* c, float dx)
   return 1;
 }
 
+int scTickUploadMovers(ScTickContext* c, uint32_t first, uint32_t count, const uint8_t* kind, const float* vel, const float* lo, const float* hi)
+{
+  if (!c || !kind || !vel || !lo || !hi) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  DeviceState& d = c->d;
+  if (!d.moverKind) {
+    const size_t N = c->cap;
+    if (!dalloc(c, d.moverKind, N) || !dalloc(c, d.mvx, N) || !dalloc(c, d.mvz, N) || !dalloc(c, d.mlox, N) ||
+        !dalloc(c, d.mloz, N) || !dalloc(c, d.mhix, N) || !dalloc(c, d.mhiz, N)) return 0;
+  }
+  if (!count) return 1;
+  std::vector<uint32_t> k32(count);
+  std::vector<float> a[6];
+  for (auto& v : a) v.resize(count);
+  for (uint32_t i = 0; i < count; ++i) {
+    if (kind[i] > 2) return fail(c, "mover kind must be 0 (none), 1 (vehicle: wrap) or 2 (ped: reflect)");
+    k32[i] = kind[i];
+    a[0][i] = vel[2 * i]; a[1][i] = vel[2 * i + 1]; a[2][i] = lo[2 * i]; a[3][i] = lo[2 * i + 1]; a[4][i] = hi[2 * i]; a[5][i] = hi[2 * i + 1];
+  }
+  float* dst[6] = { d.mvx, d.mvz, d.mlox, d.mloz, d.mhix, d.mhiz };
+  if (!h2d(c, d.moverKind + first, k32.data(), (size_t)count * 4u)) return 0;
+  for (int q = 0; q < 6; ++q) if (!h2d(c, dst[q] + first, a[q].data(), (size_t)count * 4u)) return 0;
+  return sync(c) ? 1 : 0;
+}
+
+int scTickAdvanceMovers(ScTickContext* c, float dt)
+{
+  if (!c) return 0;
+  if (!bind(c) || !flushLinks(c)) return 0;
+  if (!c->d.moverKind) return fail(c, "no movers uploaded");
+  Scoped s(c, SC_TICK_K_NUDGE);
+  launchAdvanceMovers(c->d, c->n, dt, c->stream);
+  return 1;
+}
+
+int scTickReadMoverVelocities(ScTickContext* c, uint32_t first, uint32_t count, float* vel)
+{
+  if (!c || !vel) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!c->d.moverKind) return fail(c, "no movers uploaded");
+  if (!count) return 1;
+  std::vector<float> x(count), z(count);
+  if (!d2h(c, x.data(), c->d.mvx + first, (size_t)count * 4u) || !d2h(c, z.data(), c->d.mvz + first, (size_t)count * 4u) || !sync(c)) return 0;
+  for (uint32_t i = 0; i < count; ++i) { vel[2 * i] = x[i]; vel[2 * i + 1] = z[i]; }
+  return 1;
+}
+
 int scTickGetCounts(ScTickContext* c, ScTickCounts* out)
 {
   if (!c || !out) return c ? fail(c, "null argument") : 0;
@@ -771,8 +822,14 @@ int scTickGetCounts(ScTickContext* c, ScTickCounts* out)
   out->renderables_total = k[6];
   out->visible = k[0];
   out->culled = k[1];
-  out->pairs = bp[kCtrPairs];
-  out->pairs_truncated = bp[kCtrPairs] > c->maxPairs ? 1u : 0u;
+  if (c->sectors && (c->lastFlags & SC_TICK_BROADPHASE) && !c->pairsPending) {
+    TickParams pp{}; pp.maxPairs = c->maxPairs;
+    launchGatherPairs(c->d, pp, c->lastParity, c->dPairsOut, c->dPairTotal, c->stream);
+    uint32_t tot[2] = {};
+    if (!d2h(c, tot, c->dPairTotal, sizeof tot) || !sync(c)) return 0;
+    out->pairs = tot[0];
+    out->pairs_truncated = tot[1];
+  }
   out->bin_overflow = bp[kCtrBinFull];
   out->big_boxes = bp[kCtrBig];
   out->draws_emitted = k[4];
@@ -896,12 +953,21 @@ int scTickReadPairs(ScTickContext* c, uint32_t* pairs2, uint32_t cap, uint32_t* 
   if (!c || !count) return c ? fail(c, "null argument") : 0;
   if (!bind(c)) return 0;
   if (!(c->lastFlags & SC_TICK_BROADPHASE)) return fail(c, "the last scTickRun did not request SC_TICK_BROADPHASE");
-  uint32_t k[32] = {};
-  if (!d2h(c, k, c->d.counters, sizeof k) || !sync(c)) return 0;
-  const uint32_t total = k[kCtrPar + 8u * c->lastParity + kCtrPairs];
-  *count = total;
-  const uint32_t take = std::min(std::min(total, c->maxPairs), cap);
-  if (take && pairs2) { if (!d2h(c, pairs2, c->d.pairs, (size_t)take * 8u) || !sync(c)) return 0; }
+  if (c->pairsPending) return fail(c, "scTickRunPairs has not been called for the last tick");
+  // the pair list is kept in per-shard segments on the device; gather them into one list first
+  TickParams pp{}; pp.maxPairs = c->maxPairs;
+  launchGatherPairs(c->d, pp, c->lastParity, c->dPairsOut, c->dPairTotal, c->stream);
+  uint32_t tot[2] = {};
+  if (!d2h(c, tot, c->dPairTotal, sizeof tot) || !sync(c)) return 0;
+  *count = tot[0];
+  // each shard keeps at most maxPairs / 64 pairs; recount what the gather could place
+  uint32_t sc[2u * kPairShards * kShardStride];
+  if (!d2h(c, sc, c->d.pairShardCount, sizeof sc) || !sync(c)) return 0;
+  uint32_t placed = 0;
+  const uint32_t shardCap = c->maxPairs / kPairShards;
+  for (uint32_t s = 0; s < kPairShards; ++s) placed += std::min(sc[(c->lastParity * kPairShards + s) * kShardStride], shardCap);
+  const uint32_t take = std::min(placed, cap);
+  if (take && pairs2) { if (!d2h(c, pairs2, c->dPairsOut, (size_t)take * 8u) || !sync(c)) return 0; }
   return 1;
 }
 

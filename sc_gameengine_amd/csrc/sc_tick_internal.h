@@ -72,7 +72,10 @@ struct DeviceState {
   float4* bins;                // [sector][kBinCap][2]: (min.xyz, layers) (max.xyz, id | primary<<31)
   float4* bigList;             // [cap][2] boxes that cannot be binned (too large, outside the rect, bin full)
   uint32_t* bigBits[2];        // per-entity "is in the big list" bit, double-buffered by tick parity
-  uint2* pairs;                // (a, b) ids, a < b; id = rank << 24 | dense index
+  uint2* pairs;                // (a, b) ids, a < b; id = rank << 24 | dense index; kPairShards segments of shardCap
+  uint32_t* pairShardCount;    // [2 parities][kPairShards] counters, one per 128-byte line (kShardStride words apart)
+  // upstream movers (allocated on first scTickUploadMovers)
+  uint32_t* moverKind; float *mvx, *mvz, *mlox, *mloz, *mhix, *mhiz;
   // multi-GPU border exchange: one message per neighbour direction (caller-owned device buffers)
   uint32_t* borderSend[8];
   uint32_t* borderRecv[8];
@@ -84,6 +87,9 @@ constexpr uint32_t kBorderHeader = 2;
 constexpr uint32_t kBorderRecsPerBin = 16;    // capacity = L * kBorderRecsPerBin records per message
 
 constexpr uint32_t kBinCap = 64;          // one wave lane per record of a bin
+// Pair output is sharded: a wave buffers its hits in LDS and appends them to the segment of its workgroup's
+// shard with one atomic per flush; 64 counters on separate cache lines instead of one hot word.
+constexpr uint32_t kPairShards = 64, kShardStride = 32, kWavePairBuf = 256;
 constexpr uint32_t kPrimary = 0x80000000u;
 // counters[]: 0 visible, 1 culled, 4 draws, 5 dropped, 6 renderables; per tick parity q: 8+8q+{0 pairs, 1 big, 2 bin-full}
 constexpr uint32_t kCtrPar = 8, kCtrPairs = 0, kCtrBig = 1, kCtrBinFull = 2;
@@ -121,9 +127,11 @@ void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* 
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s);
+void launchGatherPairs(const DeviceState& d, const TickParams& p, uint32_t parity, uint2* dst, uint32_t* total, hipStream_t s);
 void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchBorderMerge(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s);
+void launchAdvanceMovers(const DeviceState& d, uint32_t n, float dt, hipStream_t s);
 void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, hipStream_t s);
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);
 void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s);

@@ -744,25 +744,54 @@ __device__ __forceinline__ bool filterPass(uint32_t la, uint32_t lb)
   return ((la & 0xFFFFu) & (lb >> 16)) != 0u && ((lb & 0xFFFFu) & (la >> 16)) != 0u;
 }
 
-// wave-aggregated append to the pair list; every lane of the wave must call it
-__device__ __forceinline__ void emitPair(const DeviceState& d, const TickParams& p, bool hit, uint32_t ia, uint32_t ib)
+// Per-wave pair sink: hits go to an LDS buffer (no atomics); a flush reserves a range in the segment of
+// the workgroup's shard with ONE atomic and writes it out coalesced.  Every lane of the wave must call these.
+struct PairSink { uint2* buf; uint32_t count; uint32_t shard; };
+
+__device__ __forceinline__ void sinkFlush(const DeviceState& d, const TickParams& p, PairSink& k)
+{
+  if (!k.count) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t shardCap = p.maxPairs / kPairShards;
+  uint32_t done = 0;
+  // reserve in the current shard; what does not fit is handed back and tried in the next shard, so the
+  // list only truncates when every segment is full.  Shards rotate per flush: load stays even when a
+  // few workgroups produce most of the pairs.
+  for (uint32_t attempt = 0; attempt < kPairShards && done < k.count; ++attempt) {
+    const uint32_t shard = (k.shard + attempt) % kPairShards;
+    uint32_t* ctr = &d.pairShardCount[(p.parity * kPairShards + shard) * kShardStride];
+    const uint32_t want = k.count - done;
+    uint32_t base = 0;
+    if (lane == 0) {
+      base = atomicAdd(ctr, want);
+      const uint32_t room = base < shardCap ? shardCap - base : 0u;
+      if (room < want) atomicSub(ctr, want - room);               // give back what this segment cannot hold
+    }
+    base = __shfl(base, 0, 64);
+    const uint32_t room = base < shardCap ? shardCap - base : 0u;
+    const uint32_t take = room < want ? room : want;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t q = lane; q < take; q += 64u) d.pairs[(size_t)shard * shardCap + base + q] = k.buf[done + q];
+    done += take;
+  }
+  if (done < k.count && lane == 0) atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrPairs], k.count - done);   // dropped: every segment full
+  __builtin_amdgcn_wave_barrier();
+  k.shard = (k.shard + 1u) % kPairShards;
+  k.count = 0;
+}
+__device__ __forceinline__ void sinkPush(const DeviceState& d, const TickParams& p, PairSink& k, bool hit, uint32_t ia, uint32_t ib)
 {
   const unsigned long long m = __ballot(hit);
   if (!m) return;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrPairs], (uint32_t)__popcll(m));
-  base = __shfl(base, leader, 64);
-  if (hit) {
-    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (slot < p.maxPairs) d.pairs[slot] = make_uint2(ia < ib ? ia : ib, ia < ib ? ib : ia);
-  }
+  if (hit) k.buf[k.count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(ia < ib ? ia : ib, ia < ib ? ib : ia);
+  k.count += (uint32_t)__popcll(m);
+  if (k.count > kWavePairBuf - 64u) sinkFlush(d, p, k);        // keep room for a full wave of hits
 }
 
 constexpr uint32_t kPairTabSize = kBinCap * (kBinCap - 1) / 2;
 __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks,
-                                          float4 (*tile)[2 * kBinCap], uint16_t* pairTab)
+                                          float4 (*tile)[2 * kBinCap], uint16_t* pairTab, uint2 (*pairBuf)[kWavePairBuf])
 {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
@@ -773,6 +802,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   const uint32_t nbig = d.counters[ctr + kCtrBig];
   const uint32_t* bigBits = d.bigBits[p.parity];
   float4* T = tile[wave];
+  PairSink sink = { pairBuf[wave], 0u, bid % kPairShards };
 
   // triangular pair table, built once per workgroup (row i starts at i(i-1)/2)
   for (uint32_t i = 1u + threadIdx.x / 64u * 16u; i < kBinCap && i < 17u + threadIdx.x / 64u * 16u; ++i)
@@ -780,6 +810,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
 
   // next tick's counter set and big bits start clean
   if (bid == 0 && threadIdx.x < 8) d.counters[kCtrPar + 8u * (p.parity ^ 1u) + threadIdx.x] = 0u;
+  if (bid == 0 && threadIdx.x < kPairShards) d.pairShardCount[((p.parity ^ 1u) * kPairShards + threadIdx.x) * kShardStride] = 0u;
   {
     const uint32_t words = (p.n + 31u) >> 5;
     uint32_t* nextBits = d.bigBits[p.parity ^ 1u];
@@ -876,7 +907,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
               }
             }
           }
-          emitPair(d, p, hit, ia, ib);
+          sinkPush(d, p, sink, hit, ia, ib);
         }
       }
 
@@ -887,7 +918,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
         for (uint32_t b = 0; b < nbig; ++b) {
           const float4 gmin = d.bigList[2u * (size_t)b], gmax = d.bigList[2u * (size_t)b + 1u];
           const bool hit = mine && boxesOverlap(rmin, rmax, gmin, gmax) && filterPass(__float_as_uint(rmin.w), __float_as_uint(gmin.w));
-          emitPair(d, p, hit, myId, __float_as_uint(gmax.w));
+          sinkPush(d, p, sink, hit, myId, __float_as_uint(gmax.w));
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -906,16 +937,38 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
         jid = __float_as_uint(hmax.w);
         hit = boxesOverlap(gmin, gmax, hmin, hmax) && filterPass(__float_as_uint(gmin.w), __float_as_uint(hmin.w));
       }
-      emitPair(d, p, hit, __float_as_uint(gmax.w), jid);
+      sinkPush(d, p, sink, hit, __float_as_uint(gmax.w), jid);
     }
   }
+  sinkFlush(d, p, sink);
 }
 
 __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const TickParams p)
 {
   __shared__ float4 tile[kTile / 64][2 * kBinCap];        // 2 KiB per wave: the bin as an LDS tile
   __shared__ uint16_t pairTab[kPairTabSize];              // q -> (i << 8 | j), 0 <= j < i < 64
-  pairsBody(d, p, blockIdx.x, gridDim.x, tile, pairTab);
+  __shared__ uint2 pairBuf[kTile / 64][kWavePairBuf];     // 2 KiB per wave: hits waiting for a flush
+  pairsBody(d, p, blockIdx.x, gridDim.x, tile, pairTab, pairBuf);
+}
+
+// read-back helper: concatenates the shards' segments into one list and writes the total found
+__global__ __launch_bounds__(kTile) void k_gather_pairs(const DeviceState d, const TickParams p, uint32_t parity, uint2* __restrict__ dst, uint32_t* __restrict__ total)
+{
+  const uint32_t shard = blockIdx.x;
+  const uint32_t shardCap = p.maxPairs / kPairShards;
+  uint32_t before = 0, found = 0;
+  for (uint32_t s = 0; s < kPairShards; ++s) {
+    const uint32_t c = d.pairShardCount[(parity * kPairShards + s) * kShardStride];
+    found += c < shardCap ? c : shardCap;                // (a counter can read above the cap only transiently)
+    if (s < shard) before += c < shardCap ? c : shardCap;
+  }
+  const uint32_t mine = d.pairShardCount[(parity * kPairShards + shard) * kShardStride];
+  const uint32_t take = mine < shardCap ? mine : shardCap;
+  for (uint32_t q = threadIdx.x; q < take; q += kTile) dst[before + q] = d.pairs[(size_t)shard * shardCap + q];
+  if (shard == 0 && threadIdx.x == 0) {
+    const uint32_t dropped = d.counters[kCtrPar + 8u * parity + kCtrPairs];   // pairs found after every segment was full
+    total[0] = found + dropped; total[1] = dropped ? 1u : 0u;
+  }
 }
 
 // compaction and pair search both depend only on the fused kernel: one launch, workgroups split by role
@@ -923,9 +976,10 @@ __global__ __launch_bounds__(kTile) void k_compact_pairs(const DeviceState d, co
 {
   __shared__ float4 tile[kTile / 64][2 * kBinCap];
   __shared__ uint16_t pairTab[kPairTabSize];
+  __shared__ uint2 pairBuf[kTile / 64][kWavePairBuf];
   __shared__ uint32_t scratch[kTile / 64];
   if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, scratch);
-  else pairsBody(d, p, blockIdx.x - compactBlocks, gridDim.x - compactBlocks, tile, pairTab);
+  else pairsBody(d, p, blockIdx.x - compactBlocks, gridDim.x - compactBlocks, tile, pairTab, pairBuf);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1052,6 +1106,32 @@ __global__ __launch_bounds__(kTile) void k_nudge_roots_x(const DeviceState d, ui
   if (lane == 32 && i < n) { d.dirty[i >> 5] |= (uint32_t)(m >> 32); }
 }
 
+// Upstream movers (include/sc_tick.h "upstream movers"): straight-line advance inside the agent's
+// sector, vehicles wrap, peds reflect.  pos + vel*dt is two roundings (no FMA), as the oracle's.
+__global__ __launch_bounds__(kTile) void k_advance_movers(const DeviceState d, uint32_t n, float dt)
+{
+  const uint32_t i = blockIdx.x * kTile + threadIdx.x;
+  const uint32_t kind = i < n ? d.moverKind[i] : 0u;
+  if (kind) {
+    float vx = d.mvx[i], vz = d.mvz[i];
+    const float lox = d.mlox[i], loz = d.mloz[i], hix = d.mhix[i], hiz = d.mhiz[i];
+    float x = d.px[i] + vx * dt, z = d.pz[i] + vz * dt;
+    if (kind == 1u) {
+      if (x >= hix) x = lox + (x - hix); else if (x < lox) x = hix - (lox - x);
+      if (z >= hiz) z = loz + (z - hiz); else if (z < loz) z = hiz - (loz - z);
+    } else {
+      if (x > hix) { x = hix - (x - hix); vx = -vx; } else if (x < lox) { x = lox + (lox - x); vx = -vx; }
+      if (z > hiz) { z = hiz - (z - hiz); vz = -vz; } else if (z < loz) { z = loz + (loz - z); vz = -vz; }
+      d.mvx[i] = vx; d.mvz[i] = vz;
+    }
+    d.px[i] = x; d.pz[i] = z;
+  }
+  const unsigned long long m = __ballot(kind != 0u);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (lane == 0 && i < n && (uint32_t)m) d.dirty[i >> 5] |= (uint32_t)m;          // a wave owns its two dirty words
+  if (lane == 32 && i < n && (uint32_t)(m >> 32)) d.dirty[i >> 5] |= (uint32_t)(m >> 32);
+}
+
 __global__ __launch_bounds__(kTile) void k_set_dirty_range(const DeviceState d, uint32_t first, uint32_t count)
 {
   const uint32_t w = (first >> 5) + blockIdx.x * kTile + threadIdx.x;
@@ -1150,6 +1230,10 @@ void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t comp
   if (pairGrid > cap) pairGrid = cap;
   hipLaunchKernelGGL(k_compact_pairs, dim3(compactGrid + pairGrid), dim3(kTile), 0, s, d, p, compactGrid);
 }
+void launchGatherPairs(const DeviceState& d, const TickParams& p, uint32_t parity, uint2* dst, uint32_t* total, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_gather_pairs, dim3(kPairShards), dim3(kTile), 0, s, d, p, parity, dst, total);
+}
 void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s)
 {
   if (!p.neighbourMask) return;
@@ -1164,6 +1248,11 @@ void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s
 {
   if (!n) return;
   hipLaunchKernelGGL(k_nudge_roots_x, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, dx);
+}
+void launchAdvanceMovers(const DeviceState& d, uint32_t n, float dt, hipStream_t s)
+{
+  if (!n || !d.moverKind) return;
+  hipLaunchKernelGGL(k_advance_movers, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, dt);
 }
 void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, hipStream_t s)
 {

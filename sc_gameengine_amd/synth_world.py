@@ -87,6 +87,11 @@ class SynthWorld:
     origin: tuple = (0, 0)       # first sector (x, z)
     sectors: tuple = (0, 0)      # sectors_x, sectors_z
     camera: dict = field(default_factory=dict)
+    # upstream movers (config 5): kind 0 none / 1 vehicle (wrap) / 2 ped (reflect), velocity and sector box in xz
+    mover_kind: np.ndarray = None
+    mover_vel: np.ndarray = None
+    mover_lo: np.ndarray = None
+    mover_hi: np.ndarray = None
 
     @property
     def n(self):
@@ -185,6 +190,88 @@ def generate(sectors_x, sectors_z, props, hierarchy=True, origin=(0, 0), seed=SE
         group=np.full(N, GROUP_STATIC, np.uint32), mask=np.full(N, MASK_STATIC, np.uint32),
         sector_of=np.repeat(np.stack([cx, cz], axis=1), per, axis=0).astype(np.int32),
         origin=tuple(origin), sectors=(sectors_x, sectors_z))
+    w.camera = default_camera(w.world_side)
+    return w
+
+
+VEHICLES_PER_SECTOR, PEDS_PER_SECTOR = 12, 4
+VEHICLE_SCALE = (1.8, 0.7, 3.5)          # src/engine/traffic/sc_traffic_spawner.h:20
+VEHICLE_Y = 0.35                         # src/engine/traffic/sc_traffic_spawner.cpp:273
+VEHICLE_SPEED = 12.0                     # src/engine/traffic/sc_traffic_lanes.h:17
+LANE_OFFSET = 1.75                       # src/engine/traffic/sc_traffic_lanes.cpp:158-225 (two lanes per axis)
+PED_SCALE, PED_Y, PED_SPEED = (0.5, 1.8, 0.5), 0.9, 1.4
+
+
+def generate_config5(sectors_x, sectors_z, origin=(0, 0), seed=SEED, tiles=(1, 1)):
+    """SynthWorld v1 config 5: per sector ground + 15 props (static, hierarchy as config 3)
+    + 12 vehicles on the sector's four lanes + 4 peds = 32 entities; vehicles and peds are dynamic
+    (group 1 / mask all) roots that the mover kernel advances every tick."""
+    base = generate(sectors_x, sectors_z, 15, hierarchy=True, origin=origin, seed=seed, tiles=tiles)
+    S = base.n // 16
+    per_old, extra = 16, VEHICLES_PER_SECTOR + PEDS_PER_SECTOR
+    per = per_old + extra
+    cx = base.sector_of[::per_old, 0].astype(np.int32)
+    cz = base.sector_of[::per_old, 1].astype(np.int32)
+    size = SECTOR_SIZE
+    min_x, min_z = cx.astype(np.float32) * size, cz.astype(np.float32) * size
+    ctr_x, ctr_z = min_x + size * np.float32(0.5), min_z + size * np.float32(0.5)
+    # a second, independent stream per sector for the agents (the prop stream stays what config 3 draws)
+    state = hash_coord_seed(seed ^ 0x5EED5, cx, cz)
+
+    def grow(a, fill, dt):
+        out = np.empty((S, per) + a.shape[1:], dt)
+        out[:, :per_old] = a.reshape((S, per_old) + a.shape[1:])
+        out[:, per_old:] = fill
+        return out
+
+    pos, rot, scl = grow(base.pos, 0, np.float32), grow(base.rot, 0, np.float32), grow(base.scale, 1, np.float32)
+    mesh, mat = grow(base.mesh, MESH_CUBE, np.uint32), grow(base.material, MAT_TEST, np.uint32)
+    group, mask = grow(base.group, GROUP_DYNAMIC, np.uint32), grow(base.mask, MASK_ALL, np.uint32)
+    kind = np.zeros((S, per), np.uint8)
+    vel = np.zeros((S, per, 2), np.float32)
+    pad = np.float32(2.0)
+    lanes = [((1, 0), None, -LANE_OFFSET), ((-1, 0), None, LANE_OFFSET), ((0, 1), LANE_OFFSET, None), ((0, -1), -LANE_OFFSET, None)]
+    for v in range(VEHICLES_PER_SECTOR):
+        k = per_old + v
+        (dx, dz), offx, offz = lanes[v % 4]
+        along = rand01(state)
+        if dx != 0:                                       # lane along x at z = centre + offz
+            pos[:, k, 0] = lerp(min_x + pad, min_x + size - pad, along)
+            pos[:, k, 2] = ctr_z + np.float32(offz)
+        else:
+            pos[:, k, 0] = ctr_x + np.float32(offx)
+            pos[:, k, 2] = lerp(min_z + pad, min_z + size - pad, along)
+        pos[:, k, 1] = np.float32(VEHICLE_Y)
+        rot[:, k, 1] = np.float32(np.arctan2(np.float32(dx), np.float32(dz)))      # yaw = atan2(dir.x, dir.z), sc_traffic_ai.cpp:72-75
+        scl[:, k] = np.float32(VEHICLE_SCALE)
+        kind[:, k] = 1
+        vel[:, k, 0], vel[:, k, 1] = np.float32(VEHICLE_SPEED * dx), np.float32(VEHICLE_SPEED * dz)
+    for q in range(PEDS_PER_SECTOR):
+        k = per_old + VEHICLES_PER_SECTOR + q
+        pos[:, k, 0] = lerp(min_x + pad, min_x + size - pad, rand01(state))
+        pos[:, k, 2] = lerp(min_z + pad, min_z + size - pad, rand01(state))
+        pos[:, k, 1] = np.float32(PED_Y)
+        heading = (rand01(state) * (K_PI * np.float32(2.0))).astype(np.float32)
+        rot[:, k, 1] = heading
+        scl[:, k] = np.float32(PED_SCALE)
+        kind[:, k] = 2
+        vel[:, k, 0] = (np.float32(PED_SPEED) * np.sin(heading)).astype(np.float32)
+        vel[:, k, 1] = (np.float32(PED_SPEED) * np.cos(heading)).astype(np.float32)
+
+    N = S * per
+    parent_local = np.full((S, per), -1, np.int64)
+    old_parent = base.parent.reshape(S, per_old).astype(np.int64)
+    parent_local[:, :per_old] = np.where(old_parent >= 0, old_parent - (np.arange(S, dtype=np.int64) * per_old)[:, None], -1)
+    parent = np.where(parent_local >= 0, parent_local + (np.arange(S, dtype=np.int64) * per)[:, None], -1).astype(np.int32).reshape(N)
+    lo = np.repeat(np.stack([min_x, min_z], axis=1), per, axis=0).astype(np.float32)
+    w = SynthWorld(
+        pos=pos.reshape(N, 3), rot=rot.reshape(N, 3), scale=scl.reshape(N, 3), parent=parent,
+        bmin=np.full((N, 3), -0.5, np.float32), bmax=np.full((N, 3), 0.5, np.float32),
+        has_mesh=np.ones(N, np.uint8), has_bounds=np.ones(N, np.uint8),
+        mesh=mesh.reshape(N), material=mat.reshape(N), group=group.reshape(N), mask=mask.reshape(N),
+        sector_of=np.repeat(np.stack([cx, cz], axis=1), per, axis=0).astype(np.int32),
+        origin=tuple(origin), sectors=(sectors_x, sectors_z),
+        mover_kind=kind.reshape(N), mover_vel=vel.reshape(N, 2), mover_lo=lo, mover_hi=(lo + size).astype(np.float32))
     w.camera = default_camera(w.world_side)
     return w
 

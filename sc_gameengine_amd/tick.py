@@ -119,6 +119,8 @@ class WorldTick:
         self.upload_render_meshes(0, w.has_mesh, w.mesh, w.material)
         self.upload_layers(0, w.group, w.mask)
         self.set_topology(w.parent)
+        if getattr(w, "mover_kind", None) is not None:
+            self.upload_movers(0, w.mover_kind, w.mover_vel, w.mover_lo, w.mover_hi)
 
     def set_count(self, n):
         self._ok(self.lib.scTickSetEntityCount(self.ctx, n), "scTickSetEntityCount")
@@ -197,6 +199,20 @@ class WorldTick:
 
     def nudge_roots_x(self, dx):
         self._ok(self.lib.scTickNudgeRootsX(self.ctx, float(dx)), "scTickNudgeRootsX")
+
+    # ---- upstream movers ----
+    def upload_movers(self, first, kind, vel, lo, hi):
+        k = np.ascontiguousarray(kind, np.uint8)
+        v, a, b = _c32(vel), _c32(lo), _c32(hi)
+        self._ok(self.lib.scTickUploadMovers(self.ctx, first, len(k), k.ctypes.data_as(capi.U8P), _f(v), _f(a), _f(b)), "scTickUploadMovers")
+
+    def advance_movers(self, dt):
+        self._ok(self.lib.scTickAdvanceMovers(self.ctx, float(dt)), "scTickAdvanceMovers")
+
+    def mover_velocities(self):
+        out = np.zeros((self.n, 2), np.float32)
+        self._ok(self.lib.scTickReadMoverVelocities(self.ctx, 0, self.n, _f(out)), "scTickReadMoverVelocities")
+        return out
 
     # ---- multi-GPU tiles ----
     def set_tile(self, rank, neighbour_mask):
@@ -286,10 +302,12 @@ class WorldTick:
         self._ok(self.lib.scTickReadPairs(self.ctx, None, 0, C.byref(cnt)), "scTickReadPairs")
         n = min(cnt.value, self.max_pairs)              # the list holds at most max_pairs; cnt is the number found
         n = n if cap is None else min(cap, n)
-        out = np.zeros((max(n, 1), 2), np.uint32)
+        out = np.full((max(n, 1), 2), 0xFFFFFFFF, np.uint32)
         if n:
             self._ok(self.lib.scTickReadPairs(self.ctx, _u(out), n, C.byref(cnt)), "scTickReadPairs")
-        return out[:n].copy(), cnt.value
+        out = out[:n]
+        out = out[out[:, 1] != 0xFFFFFFFF]              # a full shard segment keeps fewer than were found
+        return out.copy(), cnt.value
 
     def draws(self):
         cnt = C.c_uint32()

@@ -1,0 +1,60 @@
+"""BASELINE config 5's shape (static props + vehicles + peds, full tick) at a size the oracle finishes
+in seconds: the device-side movers, transforms, visible list and pair set against the oracle, tick by
+tick, with vehicles wrapping and peds reflecting at their sector's edges."""
+import numpy as np
+import pytest
+
+from sc_gameengine_amd import capi, synth_world as sw
+from sc_gameengine_amd.tick import WorldTick, camera_view_proj
+from tests import worlds
+
+pytestmark = pytest.mark.gpu
+DT = 1.0 / 60.0
+
+
+def test_config5_world_shape():
+    w = sw.generate_config5(8, 8)
+    assert w.n == 64 * 32
+    per = w.mover_kind.reshape(64, 32)
+    assert (per[:, :16] == 0).all() and (per[:, 16:28] == 1).all() and (per[:, 28:] == 2).all()
+    assert (w.group[w.mover_kind > 0] == sw.GROUP_DYNAMIC).all() and (w.group[w.mover_kind == 0] == sw.GROUP_STATIC).all()
+    assert abs((w.mover_kind > 0).mean() - 0.5) < 1e-9                       # 50 % of the world moves every tick
+    base = sw.generate(8, 8, 15)
+    assert np.array_equal(w.pos.reshape(64, 32, 3)[:, :16].reshape(-1, 3).view(np.uint32), base.pos.view(np.uint32))   # props as config 3
+
+
+def test_movers_full_tick_matches_oracle(oracle):
+    w = sw.generate_config5(12, 12)                                           # 4 608 entities
+    ow = worlds.oracle_world(oracle, w)
+    t = WorldTick.from_world(w, broadphase=True)
+    vp = camera_view_proj(w.camera)
+    t.set_view_proj(vp)
+    vel = w.mover_vel.copy()
+    flags = capi.FULL | capi.DENSE_AABBS
+    wrapped = reflected = 0
+    for k in range(60):
+        big = 20.0 if k % 7 == 3 else 1.0                                     # some long steps: many wraps / reflections
+        before = np.array([list(ow.get_transform(int(e)).localPos) for e in ow.dense_entities()[:w.n:97]], np.float32)
+        v0 = vel.copy()
+        ow.advance_movers(w.mover_kind, vel, w.mover_lo, w.mover_hi, DT * big)
+        t.advance_movers(DT * big)
+        reflected += int((np.sign(v0) != np.sign(vel)).sum())
+        ow.transform_system(); ow.culling_system(view_proj=vp)
+        t.run(flags)
+        if k % 6 == 0 or k > 55:
+            assert np.array_equal(t.positions().view(np.uint32),
+                                  np.array([list(ow.get_transform(int(e)).localPos) for e in ow.dense_entities()[:w.n]], np.float32).view(np.uint32))
+            assert np.array_equal(t.mover_velocities().view(np.uint32), vel.view(np.uint32))
+            assert np.array_equal(t.world_matrices(), ow.world_matrices()[:w.n])
+            assert np.array_equal(t.visible(), ow.visible())
+            mn, mx = ow.world_aabbs()
+            want = oracle.broadphase_grid(mn[:w.n], mx[:w.n], w.group, w.mask, 16.0)
+            got, total = t.pairs()
+            key = np.sort(got[:, 0].astype(np.uint64) << np.uint64(32) | got[:, 1].astype(np.uint64))
+            assert total == len(want) and np.array_equal(key, want[:, 0].astype(np.uint64) << np.uint64(32) | want[:, 1].astype(np.uint64))
+            assert np.array_equal(t.dirty(), ow.dirty()[:w.n])
+    pos = t.positions()
+    inside = (pos[:, 0] >= w.mover_lo[:, 0] - 1e-3) & (pos[:, 0] <= w.mover_hi[:, 0] + 1e-3) & (pos[:, 2] >= w.mover_lo[:, 1] - 1e-3) & (pos[:, 2] <= w.mover_hi[:, 1] + 1e-3)
+    assert inside[w.mover_kind > 0].all()                                      # agents never leave their sector
+    assert reflected > 10 and t.counts().pairs > 20
+    t.close(); ow.close()
