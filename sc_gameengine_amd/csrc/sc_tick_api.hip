@@ -318,6 +318,7 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
       launchDeepLevel(c->d, p, c->dLevelList + b, e - b, c->stream);
     }
   }
+  if ((flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_DENSE_AABBS)) launchDenseAabbs(c->d, c->n, c->stream);   // read-back aid, off the hot path
   const bool needCompact = (flags & (SC_TICK_XFORM | SC_TICK_CULL)) != 0;
   const bool pairsNow = (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS);
   if (needCompact && pairsNow && !(c->variant & 8u)) {

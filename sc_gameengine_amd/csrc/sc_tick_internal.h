@@ -132,6 +132,7 @@ void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchBorderMerge(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s);
 void launchAdvanceMovers(const DeviceState& d, uint32_t n, float dt, hipStream_t s);
+void launchDenseAabbs(const DeviceState& d, uint32_t n, hipStream_t s);
 void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, hipStream_t s);
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);
 void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s);
