@@ -258,116 +258,6 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
   }
 }
 
-// Variant with ONE atomic round trip per tile: the primary copy (k = 0) goes through the run-aggregated
-// reservation as above; every secondary copy (a box touching 2 or 4 sectors) becomes an item in a small
-// per-wave LDS list that the first lanes pick up, so all secondary reservations are a single extra round
-// of per-lane atomics -- and both rounds' atomics are in flight before either result is consumed.
-struct BinItems { float4 rmin[64]; float4 rmax[64]; uint32_t sector[64]; };
-
-__device__ __forceinline__ void binEntityWaveFused(const DeviceState& d, const TickParams& p, uint32_t i, bool collider,
-                                                   const Aff& M, const BoundsCE& b, BinItems* items)
-{
-  const uint32_t lane = threadIdx.x & 63u;
-  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
-  BinPlan plan; plan.collide = false; plan.big = false; plan.x0 = plan.z0 = 0.0f; plan.nx = plan.nz = 0;
-  float4 rmin = make_float4(0, 0, 0, 0), rmax = make_float4(0, 0, 0, 0);
-  if (collider) {
-    worldAabb(M, b, mn, mx);
-    plan = planBins(p, mn, mx);
-    rmin = make_float4(mn[0], mn[1], mn[2], __uint_as_float(ldU(d, kLAYERS, i)));
-    rmax = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i | p.rankBits));
-  }
-  const bool binned = plan.collide && !plan.big;
-  const uint32_t sx = (uint32_t)plan.x0, sz = (uint32_t)plan.z0;
-  bool binFull = false;
-
-  // ---- primary copy: run-aggregated reservation, atomic issued now, consumed later
-  const uint32_t sector0 = sz * p.binSX + sx;
-  const unsigned long long act = __ballot(binned);
-  uint32_t base0 = 0, myHead = 0, lay = binned ? __float_as_uint(rmin.w) : 0u;
-  if (act) {
-    const uint32_t key = binned ? sector0 : 0xFFFFFFFFu;
-    const uint32_t prev = __shfl_up(key, 1, 64);
-    const bool head = binned && (lane == 0 || prev != key);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long upto = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
-    myHead = (63u - (uint32_t)__clzll(heads & upto)) & 63u;
-    const unsigned long long above = (myHead == 63u) ? 0ull : ~((2ull << myHead) - 1ull);
-    const unsigned long long ends = (heads | ~act) & above;
-    const uint32_t runEnd = ends ? (uint32_t)__ffsll((long long)ends) - 1u : 64u;
-    const uint32_t headLay = (uint32_t)__shfl((int)lay, (int)myHead, 64);
-    if (__ballot(binned && headLay != lay)) {
-#pragma unroll
-      for (uint32_t o = 1; o < 64u; o <<= 1) {
-        const uint32_t other = (uint32_t)__shfl_down((int)lay, o, 64);
-        if (binned && lane + o < runEnd) lay |= other;
-      }
-    }
-    if (head) { base0 = atomicAdd(&d.binCount[sector0], runEnd - lane); atomicOr(&d.binLayers[sector0], lay); }
-  }
-
-  // ---- secondary copies -> LDS items (0, 1 or 3 per box)
-  const uint32_t extra = binned ? plan.nx * plan.nz - 1u : 0u;
-  const unsigned long long mAny = __ballot(extra >= 1u), mThree = __ballot(extra == 3u);
-  const uint32_t total = (uint32_t)__popcll(mAny) + 2u * (uint32_t)__popcll(mThree);
-  if (total) {
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const uint32_t first = (uint32_t)__popcll(mAny & below) + 2u * (uint32_t)__popcll(mThree & below);
-    for (uint32_t pass = 0; pass < total; pass += 64u) {
-      uint32_t slot = first;
-#pragma unroll
-      for (uint32_t k = 1; k < 4; ++k) {
-        const uint32_t dx = k & 1u, dz = k >> 1;
-        if (binned && dx < plan.nx && dz < plan.nz) {
-          if (slot >= pass && slot < pass + 64u) {
-            items->rmin[slot - pass] = rmin; items->rmax[slot - pass] = rmax;
-            items->sector[slot - pass] = (sz + dz) * p.binSX + (sx + dx);
-          }
-          ++slot;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      const bool mine = pass + lane < total;
-      float4 imin = make_float4(0, 0, 0, 0), imax = make_float4(0, 0, 0, 0);
-      uint32_t isec = 0, islot = 0;
-      if (mine) {
-        imin = items->rmin[lane]; imax = items->rmax[lane]; isec = items->sector[lane];
-        islot = atomicAdd(&d.binCount[isec], 1u);
-        atomicOr(&d.binLayers[isec], __float_as_uint(imin.w));
-      }
-      if (mine) {
-        if (islot < kBinCap) { float4* r = d.bins + 2u * ((size_t)isec * kBinCap + islot); r[0] = imin; r[1] = imax; }
-        else {
-          // the owner has to learn that one of its copies did not fit: flag it through the big bits
-          const uint32_t id = __float_as_uint(imax.w) & kParentMask, bit = 1u << (id & 31u);
-          const uint32_t old = atomicOr(&d.bigBits[p.parity][id >> 5], bit);
-          if (!(old & bit)) { appendBig(d, p, imin, imax); atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBinFull], 1u); }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-
-  // ---- consume the primary reservation
-  if (act) {
-    base0 = __shfl(base0, myHead, 64);
-    if (binned) {
-      const uint32_t slot = base0 + (lane - myHead);
-      if (slot < kBinCap) {
-        float4* r = d.bins + 2u * ((size_t)sector0 * kBinCap + slot);
-        float4 rm = rmax; rm.w = __uint_as_float(i | p.rankBits | kPrimary);
-        r[0] = rmin; r[1] = rm;
-      } else binFull = true;
-    }
-  }
-  if (plan.collide && plan.big) appendBig(d, p, rmin, rmax);
-  if (binFull) {
-    const uint32_t bit = 1u << (i & 31u);
-    const uint32_t old = atomicOr(&d.bigBits[p.parity][i >> 5], bit);
-    if (!(old & bit)) { appendBig(d, p, rmin, rmax); atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBinFull], 1u); }
-  }
-}
-
 // Same for a single lane (level kernels: entities of one level are scattered, no runs to aggregate).
 __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const TickParams& p, uint32_t i, const Aff& M, const BoundsCE& b)
 {
@@ -410,18 +300,18 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
 // workgroup ever waits for another one.  Everything above `top` is clean, hence its stored matrix
 // is not written by anyone this tick and can be read race-free.
 // ------------------------------------------------------------------------------------------
-template <bool kCull, bool kAabb, bool kEarly, bool kFusedBins>
+// (Variants that were measured and dropped -- a wave-cooperative hierarchy resolve through ds_bpermute, bounds
+// loaded before the walk, binning with a single atomic round trip -- are in the history at 72ae167; all of
+// them lost to this form because they cost VGPRs, and this kernel is occupancy-bound.  DESIGN.md section 5.)
+// The body is a device function taking the arguments by reference on purpose: written directly in the
+// __global__ function the same code allocates 84/91 VGPRs instead of 64/77 (hipcc, ROCm 7.2).
+template <bool kCull, bool kAabb>
 __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p);
 
 template <bool kCull, bool kAabb>
-__global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, false, false>(d, p); }
+__global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb>(d, p); }
 
-// A/B build (SC_TICK_VARIANT bit 1): binning with ONE atomic round trip per tile (binEntityWaveFused).
-// Measured slower (46.7 vs 39.9 us at 1M entities): 87 VGPRs instead of 79 cost a wave per SIMD.
 template <bool kCull, bool kAabb>
-__global__ __launch_bounds__(kTile) void k_xform_cull_early(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, false, true>(d, p); }
-
-template <bool kCull, bool kAabb, bool kEarly, bool kFusedBins>
 __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p)
 {
   const uint32_t lane = threadIdx.x & 63u;
@@ -433,7 +323,6 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
   const bool hasDeep = (p.flags & kFlagHasDeep) != 0;
 
   uint32_t visCount = 0, candCount = 0;      // wave-uniform running sums
-  __shared__ BinItems sItems[(kAabb && kFusedBins) ? kTile / 64 : 1];
 
   for (uint32_t base = begin; base < end; base += kTile) {
     const uint32_t i = base + threadIdx.x;
@@ -441,13 +330,6 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
     const uint32_t lk = active ? ldU(d, kLINK, i) : ((kUnreachable << kDepthShift) | kNoParent);
     const uint32_t depth = linkDepth(lk);
     const bool chain = depth <= kMaxChain;
-    // loads that depend on nothing but the index are issued first (they cannot be hoisted by the
-    // compiler across the matrix stores below: the SoA pointers may alias as far as it knows)
-    const bool candE = active && (lk & kHasMesh);
-    const bool hbE = active && (lk & kHasBounds);
-    BoundsCE bE = {0, 0, 0, 0, 0, 0};
-    if ((kCull || kAabb) && kEarly && hbE) bE = loadBounds(d, i);
-
     // ---- walk up: ancestors a[1..depth], top = dirty level nearest the root
     uint32_t a[kMaxChain + 1];                         // ancestors
     uint32_t rotFlags = lk >> 29;                      // 3 rotation-triviality bits per level, level k at bits 3k..3k+2
@@ -499,10 +381,10 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
     }
 
     if (kCull || kAabb) {
-      const bool cand = candE;
-      const bool hb = hbE;
-      BoundsCE b = bE;
-      if (!kEarly && hb) b = loadBounds(d, i);
+      const bool cand = active && (lk & kHasMesh);
+      const bool hb = active && (lk & kHasBounds);
+      BoundsCE b = {0, 0, 0, 0, 0, 0};
+      if (hb) b = loadBounds(d, i);
 
       if (kCull) {
         bool visible = cand;
@@ -523,173 +405,6 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
       }
       if (kAabb) {
         // deeper entities are binned by the level kernels once their matrix is final
-        const bool collider = hb && !(doXform && depth > kMaxChain && depth != kUnreachable);
-        if (kFusedBins) binEntityWaveFused(d, p, i, collider, M, b, &sItems[kAabb ? wave : 0]);
-        else binEntityWave(d, p, i, collider, M, b);
-      }
-    }
-  }
-
-  if (kCull) {
-    __shared__ uint32_t sVis[kTile / 64], sCand[kTile / 64];
-    if (lane == 0) { sVis[wave] = visCount; sCand[wave] = candCount; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      d.blockVis[blockIdx.x] = sVis[0] + sVis[1] + sVis[2] + sVis[3];
-      d.blockCand[blockIdx.x] = sCand[0] + sCand[1] + sCand[2] + sCand[3];
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// K1, wave-cooperative variant (experimental, SC_TICK_VARIANT bit 0; measured slower: 85-94 VGPRs).  Same results as k_xform_cull, fewer dependent memory
-// phases and no redundant ancestor work:
-//   phase A  link word + dirty word of the own entity                         (1 memory round trip)
-//   phase B  own locals (whenever the wave holds a dirty entity), bounds, or the stored rows
-//   resolve  a child whose parent sits in the SAME WAVE takes the parent's freshly built matrix with
-//            12 cross-lane reads (ds_bpermute), level by level -- parents are final before children
-//            because a child's depth is its parent's + 1.  world = parent * local is the very product
-//            TransformSystem's DFS forms, so the bits are the same.
-//   Only lanes whose parent lives outside the wave walk the chain through memory as k_xform_cull does.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ Aff shflAff(const Aff& M, uint32_t srcLane)
-{
-  Aff P;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    P.r0[k] = __shfl(M.r0[k], (int)srcLane, 64);
-    P.r1[k] = __shfl(M.r1[k], (int)srcLane, 64);
-    P.r2[k] = __shfl(M.r2[k], (int)srcLane, 64);
-  }
-  return P;
-}
-
-template <bool kCull, bool kAabb>
-__global__ __launch_bounds__(kTile) void k_xform_cull_coop(const DeviceState d, const TickParams p)
-{
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t begin = blockIdx.x * p.span;
-  const uint32_t end = (begin + p.span < p.n) ? begin + p.span : p.n;
-  const bool doXform = (p.flags & SC_TICK_XFORM) != 0;
-  const bool wantCand = (p.flags & SC_TICK_CULLED_LIST) != 0;
-  const bool hasDeep = (p.flags & kFlagHasDeep) != 0;
-
-  uint32_t visCount = 0, candCount = 0;
-
-  for (uint32_t base = begin; base < end; base += kTile) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t waveBase = base + wave * 64u;
-    const bool active = i < p.n;
-
-    // ---- phase A
-    const uint32_t lk = active ? ldU(d, kLINK, i) : ((kUnreachable << kDepthShift) | kNoParent);
-    const uint32_t dword = (doXform && active) ? d.dirty[i >> 5] : 0u;
-    const uint32_t depth = linkDepth(lk);
-    const uint32_t par = lk & kParentMask;
-    const bool chain = doXform && depth <= kMaxChain;
-    const bool selfDirty = chain && ((dword >> (i & 31u)) & 1u);
-    const uint32_t parLane = par - waveBase;                    // < 64 iff the parent is in this wave
-    const bool inWave = chain && depth >= 1u && parLane < 64u;
-    const bool slow = chain && depth >= 1u && !inWave;
-    const bool waveDirty = __ballot(selfDirty) != 0ull;
-    const bool cand = active && (lk & kHasMesh);
-    const bool hb = active && (lk & kHasBounds);
-
-    // ---- phase B loads that depend on nothing else
-    Aff L; bool haveL = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { L.r0[k] = 0.0f; L.r1[k] = 0.0f; L.r2[k] = 0.0f; }
-    if (waveDirty && chain) { L = loadLocal(d, i, lk); haveL = true; }
-    BoundsCE b = {0, 0, 0, 0, 0, 0};
-    if ((kCull || kAabb) && hb) b = loadBounds(d, i);
-
-    // ---- nodeDirty: own flag, chain walk for out-of-wave parents, then in-wave propagation by level
-    bool nd = selfDirty;
-    uint32_t a[kMaxChain + 1];
-    uint32_t rotFlags = lk >> 29;
-    int top = selfDirty ? 0 : -1;
-#pragma unroll
-    for (uint32_t k = 0; k <= kMaxChain; ++k) a[k] = i;
-    if (slow) {
-      uint32_t cur = lk;
-#pragma unroll
-      for (uint32_t k = 1; k <= kMaxChain; ++k) {
-        if (k <= depth) {
-          a[k] = cur & kParentMask;
-          cur = ldU(d, kLINK, a[k]);
-          rotFlags |= (cur >> 29) << (3u * k);
-          if (dirtyBit(d.dirty, a[k])) top = (int)k;
-        }
-      }
-      nd = top >= 0;
-    }
-#pragma unroll
-    for (uint32_t lev = 1; lev <= kMaxChain; ++lev) {
-      const bool mine = inWave && depth == lev;
-      if (!__ballot(mine)) continue;
-      const int pnd = __shfl((int)nd, (int)(parLane & 63u), 64);
-      if (mine) nd = nd || (pnd != 0);
-    }
-
-    // ---- matrices
-    Aff M;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { M.r0[k] = 0.0f; M.r1[k] = 0.0f; M.r2[k] = 0.0f; }
-    if (nd && !haveL) L = loadLocal(d, i, lk);                  // a clean wave reached through an outside ancestor
-    if (nd && depth == 0u) M = L;
-    if (nd && slow) {
-      const bool fromRoot = (uint32_t)top == depth;
-      if (!fromRoot) {
-        const uint32_t seed = (top == 0) ? a[1] : (top == 1) ? a[2] : a[3];
-        M = loadRows(d, seed);
-      }
-#pragma unroll
-      for (int lev = (int)kMaxChain; lev >= 0; --lev) {
-        if (lev <= top) {
-          const Aff Ll = (lev == 0) ? L : loadLocal(d, a[lev], (rotFlags >> (3 * lev)) << 29);
-          if (lev == top && fromRoot) M = Ll;
-          else M = mulAff(M, Ll);
-        }
-      }
-    }
-    if (!nd && (kCull || kAabb) && active) M = loadRows(d, i);
-#pragma unroll
-    for (uint32_t lev = 1; lev <= kMaxChain; ++lev) {
-      const bool mine = inWave && depth == lev && nd;
-      if (!__ballot(mine)) continue;
-      const int pnd = __shfl((int)nd, (int)(parLane & 63u), 64);
-      Aff P = shflAff(M, parLane & 63u);
-      if (mine) {
-        if (!pnd) P = loadRows(d, par);                         // clean parent: its stored (possibly stale) matrix
-        M = mulAff(P, L);
-      }
-    }
-    if (nd) storeRows(d, i, M);
-
-    if (hasDeep) {
-      const unsigned long long rm = __ballot(nd);
-      if (lane == 0 && waveBase < p.n) d.recomp[(base >> 6) + wave] = rm;
-    }
-
-    if (kCull || kAabb) {
-      if (kCull) {
-        bool visible = cand;
-        if (cand && hb && !p.freeze && p.frustumValid) {
-          float c0, c1, c2;
-          visible = sphereVisible(M, b, p.fr, c0, c1, c2);
-        }
-        if (doXform && depth > kMaxChain && depth != kUnreachable) visible = false;   // level kernels own these
-        const unsigned long long vm = __ballot(visible);
-        const unsigned long long cm = __ballot(cand);
-        if (lane == 0 && waveBase < p.n) {
-          d.vis[(base >> 6) + wave] = vm;
-          if (wantCand) d.cand[(base >> 6) + wave] = cm;
-        }
-        visCount += (uint32_t)__popcll(vm);
-        candCount += (uint32_t)__popcll(cm);
-      }
-      if (kAabb) {
         const bool collider = hb && !(doXform && depth > kMaxChain && depth != kUnreachable);
         binEntityWave(d, p, i, collider, M, b);
       }
@@ -1302,20 +1017,6 @@ __global__ __launch_bounds__(kTile) void k_emit_draws(const DeviceState d, uint3
 void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
 {
   const bool cull = (p.flags & SC_TICK_CULL) != 0, aabb = (p.flags & SC_TICK_BROADPHASE) != 0;
-  if (p.variant & 1u) {                                       // experimental: wave-cooperative variant (slower: VGPR-bound)
-    if (cull && aabb) hipLaunchKernelGGL((k_xform_cull_coop<true, true>), dim3(grid), dim3(kTile), 0, s, d, p);
-    else if (cull)    hipLaunchKernelGGL((k_xform_cull_coop<true, false>), dim3(grid), dim3(kTile), 0, s, d, p);
-    else if (aabb)    hipLaunchKernelGGL((k_xform_cull_coop<false, true>), dim3(grid), dim3(kTile), 0, s, d, p);
-    else              hipLaunchKernelGGL((k_xform_cull_coop<false, false>), dim3(grid), dim3(kTile), 0, s, d, p);
-    return;
-  }
-  if (p.variant & 2u) {                                       // A/B: single-round-trip binning
-    if (cull && aabb) hipLaunchKernelGGL((k_xform_cull_early<true, true>), dim3(grid), dim3(kTile), 0, s, d, p);
-    else if (cull)    hipLaunchKernelGGL((k_xform_cull_early<true, false>), dim3(grid), dim3(kTile), 0, s, d, p);
-    else if (aabb)    hipLaunchKernelGGL((k_xform_cull_early<false, true>), dim3(grid), dim3(kTile), 0, s, d, p);
-    else              hipLaunchKernelGGL((k_xform_cull_early<false, false>), dim3(grid), dim3(kTile), 0, s, d, p);
-    return;
-  }
   if (cull && aabb) hipLaunchKernelGGL((k_xform_cull<true, true>), dim3(grid), dim3(kTile), 0, s, d, p);
   else if (cull)    hipLaunchKernelGGL((k_xform_cull<true, false>), dim3(grid), dim3(kTile), 0, s, d, p);
   else if (aabb)    hipLaunchKernelGGL((k_xform_cull<false, true>), dim3(grid), dim3(kTile), 0, s, d, p);
