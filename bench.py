@@ -55,13 +55,34 @@ def pmc_traffic(stages, entities_per_gpu, workload="config3"):
     return d.get("kernels", {}).get("k_xform_cull", {}).get("hbm_bytes_per_launch")
 
 
-def cpu_baseline(world, ticks=20, warm=3):
+def copy_ceiling_gbs(torch, device):
+    """Measured device copy rate (read + write bytes per second) of a 1 GiB buffer, the practical HBM
+    ceiling SURVEY 8d asks to report next to the vendor peak."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=device)
+    b = torch.empty_like(a)
+    a.fill_(1.0)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    del a, b
+    return 2.0 * n * 4 / (ms * 1e-3) / 1e9
+
+
+def cpu_baseline(world, ticks=20, warm=3, workers=None):
     """Reference-faithful CPU tick (oracle port), timed on this host: Transform + Camera + Culling,
     hardware_concurrency()-1 workers as the sandbox does (src/sandbox/src/main.cpp:52-54)."""
     from oracle import oracle_py as oracle
     oracle.build()
     hw = os.cpu_count() or 1
-    workers = max(hw - 1, 1)
+    workers = max(hw - 1, 1) if workers is None else workers
     oracle.lib().orc_jobs_init(workers)
     ow = oracle.OracleWorld.from_arrays(world.pos, world.rot, world.scale, world.parent, world.bmin, world.bmax,
                                         has_mesh=world.has_mesh, has_bounds=world.has_bounds)
@@ -256,8 +277,22 @@ def main():
                                      "k_compact_pairs (one launch)" if not len(k2) else "k_pairs": float(np.mean(kp)) if len(kp) else None},
             },
         }
+        if world_size == 1:
+            ceiling = copy_ceiling_gbs(torch, torch.device("cuda", local_rank))
+            out["roofline"]["copy_ceiling"] = ceiling
+            out["roofline"]["frac_of_copy_ceiling"] = (achieved / ceiling) if achieved else None
+            # resident mode's per-frame read-back: the visible list and the matrices of the visible entities
+            for _ in range(2):                      # the first call allocates scratch; report the warm one
+                t0 = time.perf_counter()
+                vis = t.visible()
+                mats = t.world_matrices_indexed(vis[:65536])
+                out["config"]["readback_ms_visible_list_and_matrices"] = (time.perf_counter() - t0) * 1e3
+            del mats
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
+            one = cpu_baseline(w, ticks=5, warm=1, workers=0)
+            out["cpu_baseline"]["single_thread_value"] = one["value"]
+            out["cpu_baseline"]["single_thread_sample"] = one["sample"]
         print(json.dumps(out))
     t.close()
     if world_size > 1:

@@ -366,7 +366,7 @@ const char* scTickGetLastError(const ScTickContext* ctx) { return ctx ? ctx->err
 ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
 {
   if (!desc) { fail(nullptr, "null desc"); return nullptr; }
-  if (desc->capacity == 0 || desc->capacity > SC_TICK_MAX_ENTITIES) { fail(nullptr, "capacity must be 1..2^24"); return nullptr; }
+  if (desc->capacity == 0 || desc->capacity > SC_TICK_MAX_ENTITIES) { fail(nullptr, "capacity must be 1..2^24-1"); return nullptr; }
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) { fail(nullptr, "no HIP device available (libsc_tick needs an AMD GPU; there is no CPU fallback)", e); return nullptr; }

@@ -248,3 +248,38 @@ def test_full_size_1m_properties():
     t.run(XC)
     assert np.array_equal(t.visible(), t.visible())
     t.close()
+
+
+def test_maximum_size_16m_entities():
+    """Near the 24-bit entity-index limit (sc_ecs.h:18-20): 16 000 000 entities on one GPU, full tick.
+    Size-independent properties only (the oracle would take minutes)."""
+    w = sw.generate(1000, 1000, 15)
+    assert w.n == 16_000_000
+    dyn = (np.arange(w.n) % 16) == 5
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    t = WorldTick.from_world(w, broadphase=True)
+    t.set_camera(w.camera)
+    t.run(capi.FULL | capi.CULLED_LIST)
+    vis, cul = t.visible(), t.culled()
+    assert (np.diff(vis.astype(np.int64)) > 0).all() and len(vis) + len(cul) == w.n and 0 < len(vis) < w.n
+    assert np.array_equal(np.flatnonzero(t.visibility_bits()).astype(np.uint32), vis)
+    last = np.arange(w.n - 4096, w.n, dtype=np.uint32)                        # the highest indices are addressed correctly
+    m = t.world_matrices_indexed(last)
+    roots = w.parent[last] < 0
+    assert np.array_equal(m[roots, 12:15].view(np.uint32), w.pos[last][roots].view(np.uint32))
+    p1, n1 = t.pairs()
+    c = t.counts()
+    assert c.big_boxes == 0 and c.bin_overflow == 0 and c.pairs_truncated == 0 and n1 == len(p1) > 1000
+    assert (p1[:, 0] < p1[:, 1]).all() and p1.max() < w.n
+    # every reported pair really overlaps (closed intervals) -- checked on the host from the matrices
+    from oracle import oracle_np as onp
+    idx = np.unique(p1[:20000].ravel())
+    mn, mx = onp.world_aabb(t.world_matrices_indexed(idx), w.bmin[idx], w.bmax[idx])
+    pos = {int(k): q for q, k in enumerate(idx)}
+    a = np.array([pos[int(x)] for x in p1[:20000, 0]]); b = np.array([pos[int(x)] for x in p1[:20000, 1]])
+    assert ((mn[a] <= mx[b]) & (mn[b] <= mx[a])).all()
+    # idempotence at this size: a second tick with everything marked dirty reproduces lists and pair count
+    t.mark_dirty(0, w.n); t.run(capi.FULL)
+    _, n2 = t.pairs()
+    assert np.array_equal(t.visible(), vis) and n2 == n1
+    t.close()
