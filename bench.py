@@ -180,8 +180,11 @@ def main():
     # torch's current stream so the RCCL send/recv group is stream-ordered with the kernels around it
     # (no host synchronisation inside a step).
     borders = None
+    tick_stream = None
     if world_size > 1 and (flags & capi.BROADPHASE):
-        t.set_stream(torch.cuda.current_stream().cuda_stream)
+        tick_stream = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(tick_stream)            # torch's current stream for everything below, RCCL ops included
+        t.set_stream(tick_stream.cuda_stream, external=True)
         borders = tiles.BorderBuffers(t, rank, grid, torch.device("cuda", local_rank))
 
     def produce():

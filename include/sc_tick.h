@@ -171,9 +171,10 @@ uint32_t scTickBorderBytes(ScTickContext* ctx, uint32_t direction);
 /* caller-owned device buffers (e.g. torch tensors) of at least scTickBorderBytes(d) bytes each */
 int scTickBindBorderBuffers(ScTickContext* ctx, uint32_t direction, void* send_device_ptr, void* recv_device_ptr);
 int scTickRunPairs(ScTickContext* ctx);
-/* run all device work of this context on a stream the caller owns (hipStream_t), e.g. the stream its
- * RCCL calls are ordered on; NULL returns to the context's own stream */
-int scTickSetStream(ScTickContext* ctx, void* hip_stream);
+/* external != 0: run all device work of this context on the caller's stream `hip_stream` (hipStream_t;
+ * NULL is the legacy default stream), e.g. the stream its RCCL calls are ordered on.
+ * external == 0: return to the context's own stream. */
+int scTickSetStream(ScTickContext* ctx, void* hip_stream, int external);
 
 /* ---- upstream movers (the step before the path) ----
  * The engine's on-rails traffic tier writes Transform::localPos every fixed step and marks it dirty

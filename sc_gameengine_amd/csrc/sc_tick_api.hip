@@ -739,12 +739,12 @@ int scTickBindBorderBuffers(ScTickContext* c, uint32_t dir, void* send, void* re
   return 1;
 }
 
-int scTickSetStream(ScTickContext* c, void* stream)
+int scTickSetStream(ScTickContext* c, void* stream, int external)
 {
   if (!c) return 0;
   if (!bind(c) || !sync(c)) return 0;
   dropGraph(c);
-  c->stream = stream ? static_cast<hipStream_t>(stream) : c->ownStream;
+  c->stream = external ? static_cast<hipStream_t>(stream) : c->ownStream;
   return 1;
 }
 

@@ -492,6 +492,12 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
   const bool doCull = (p.flags & SC_TICK_CULL) != 0;
   const bool doCulled = (p.flags & SC_TICK_CULLED_LIST) != 0;
 
+  // requested before the prefix is known, so they travel together with the count loads
+  const uint32_t wBegin = begin >> 5, wEnd = (end + 31u) >> 5;
+  uint32_t dirtyKeep = 0; const uint32_t dirtyWord = wBegin + threadIdx.x;
+  const bool clearDirty = (p.flags & SC_TICK_XFORM) && dirtyWord < wEnd;
+  if (clearDirty) dirtyKeep = d.dirty[dirtyWord] & d.unreach[dirtyWord];
+
   if (doCull) {
     uint32_t pv = 0, pc = 0;
     for (uint32_t j = threadIdx.x; j < bid; j += kTile) { pv += d.blockVis[j]; pc += d.blockCand[j]; }
@@ -532,10 +538,10 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
     }
   }
 
+  // Transform::dirty = false for every visited entity; entities in a cycle keep theirs (sc_ecs.cpp:201)
+  if (clearDirty) d.dirty[dirtyWord] = dirtyKeep;
   if (p.flags & SC_TICK_XFORM) {
-    // Transform::dirty = false for every visited entity; entities in a cycle keep theirs
-    const uint32_t wBegin = begin >> 5, wEnd = (end + 31u) >> 5;
-    for (uint32_t w = wBegin + threadIdx.x; w < wEnd; w += kTile) d.dirty[w] &= d.unreach[w];
+    for (uint32_t w = wBegin + kTile + threadIdx.x; w < wEnd; w += kTile) d.dirty[w] &= d.unreach[w];   // spans wider than 8192 entities
   }
 }
 
@@ -916,13 +922,18 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
 __global__ __launch_bounds__(kTile) void k_nudge_roots_x(const DeviceState d, uint32_t n, float dx)
 {
   const uint32_t i = blockIdx.x * kTile + threadIdx.x;
-  const bool root = i < n && (d.link[i] & kParentMask) == kNoParent && linkDepth(d.link[i]) != kUnreachable;
-  if (root) d.px[i] = d.px[i] + dx;
-  const unsigned long long m = __ballot(root);
   const uint32_t lane = threadIdx.x & 63u;
-  // a wave owns exactly the two dirty words of its 64 entities
-  if (lane == 0 && i < n) { d.dirty[i >> 5] |= (uint32_t)m; }
-  if (lane == 32 && i < n) { d.dirty[i >> 5] |= (uint32_t)(m >> 32); }
+  // one memory round trip: link, position and the wave's dirty word are requested together
+  const bool in = i < n;
+  const uint32_t lk = in ? d.link[i] : ((kUnreachable << kDepthShift) | 1u);
+  const float x = in ? d.px[i] : 0.0f;
+  uint32_t dw = 0;
+  if (in && (lane & 31u) == 0u) dw = d.dirty[i >> 5];           // a wave owns exactly the two dirty words of its 64 entities
+  const bool root = in && (lk & kParentMask) == kNoParent && linkDepth(lk) != kUnreachable;
+  if (root) d.px[i] = x + dx;
+  const unsigned long long m = __ballot(root);
+  const uint32_t mine = lane < 32u ? (uint32_t)m : (uint32_t)(m >> 32);
+  if (in && (lane & 31u) == 0u && mine) d.dirty[i >> 5] = dw | mine;
 }
 
 // Read-back / debug only (SC_TICK_DENSE_AABBS): per-entity world AABBs in dense order, from the stored
@@ -943,11 +954,16 @@ __global__ __launch_bounds__(kTile) void k_dense_aabbs(const DeviceState d, uint
 __global__ __launch_bounds__(kTile) void k_advance_movers(const DeviceState d, uint32_t n, float dt)
 {
   const uint32_t i = blockIdx.x * kTile + threadIdx.x;
-  const uint32_t kind = i < n ? d.moverKind[i] : 0u;
+  const uint32_t lane = threadIdx.x & 63u;
+  const bool in = i < n;
+  // everything is requested at once (one round trip); non-movers just drop what they fetched
+  const uint32_t kind = in ? d.moverKind[i] : 0u;
+  float vx = 0, vz = 0, lox = 0, loz = 0, hix = 0, hiz = 0, x = 0, z = 0;
+  if (in) { vx = d.mvx[i]; vz = d.mvz[i]; lox = d.mlox[i]; loz = d.mloz[i]; hix = d.mhix[i]; hiz = d.mhiz[i]; x = d.px[i]; z = d.pz[i]; }
+  uint32_t dw = 0;
+  if (in && (lane & 31u) == 0u) dw = d.dirty[i >> 5];
   if (kind) {
-    float vx = d.mvx[i], vz = d.mvz[i];
-    const float lox = d.mlox[i], loz = d.mloz[i], hix = d.mhix[i], hiz = d.mhiz[i];
-    float x = d.px[i] + vx * dt, z = d.pz[i] + vz * dt;
+    x = x + vx * dt; z = z + vz * dt;
     if (kind == 1u) {
       if (x >= hix) x = lox + (x - hix); else if (x < lox) x = hix - (lox - x);
       if (z >= hiz) z = loz + (z - hiz); else if (z < loz) z = hiz - (loz - z);
@@ -959,9 +975,8 @@ __global__ __launch_bounds__(kTile) void k_advance_movers(const DeviceState d, u
     d.px[i] = x; d.pz[i] = z;
   }
   const unsigned long long m = __ballot(kind != 0u);
-  const uint32_t lane = threadIdx.x & 63u;
-  if (lane == 0 && i < n && (uint32_t)m) d.dirty[i >> 5] |= (uint32_t)m;          // a wave owns its two dirty words
-  if (lane == 32 && i < n && (uint32_t)(m >> 32)) d.dirty[i >> 5] |= (uint32_t)(m >> 32);
+  const uint32_t mine = lane < 32u ? (uint32_t)m : (uint32_t)(m >> 32);
+  if (in && (lane & 31u) == 0u && mine) d.dirty[i >> 5] = dw | mine;
 }
 
 __global__ __launch_bounds__(kTile) void k_set_dirty_range(const DeviceState d, uint32_t first, uint32_t count)

@@ -227,8 +227,9 @@ class WorldTick:
     def run_pairs(self):
         self._ok(self.lib.scTickRunPairs(self.ctx), "scTickRunPairs")
 
-    def set_stream(self, hip_stream):
-        self._ok(self.lib.scTickSetStream(self.ctx, hip_stream), "scTickSetStream")
+    def set_stream(self, hip_stream, external=True):
+        """external=True: run on the caller's hipStream_t (0 = the legacy default stream); False: own stream"""
+        self._ok(self.lib.scTickSetStream(self.ctx, hip_stream, 1 if external else 0), "scTickSetStream")
 
     def set_profiling(self, period):
         """0 = off, n = record HIP events on every n-th tick"""

@@ -85,3 +85,23 @@ def test_tiled_pairs_equal_whole_world_pairs(oracle, grid):
     for t in ticks:
         t.close()
     ow.close()
+
+
+def test_context_runs_on_an_external_stream(oracle):
+    """scTickSetStream: the tick is stream-ordered with the caller's own work on that stream (what the
+    RCCL exchange relies on) -- including the legacy default stream, whose handle is NULL."""
+    import torch
+    w = sw.generate(8, 8, 15)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    ow.transform_system()
+    for stream in (torch.cuda.Stream(), None):
+        t = WorldTick.from_world(w, broadphase=False)
+        t.set_stream(stream.cuda_stream if stream is not None else 0, external=True)
+        t.run(capi.XFORM)
+        (stream.synchronize() if stream is not None else torch.cuda.synchronize())
+        assert np.array_equal(t.world_matrices(), ow.world_matrices())
+        t.set_stream(0, external=False)                # back to the context's own stream
+        t.mark_dirty(0, w.n); t.run(capi.XFORM)
+        assert np.array_equal(t.world_matrices(), ow.world_matrices())
+        t.close()
+    ow.close()
