@@ -209,6 +209,27 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    exchange_note = None
+    if borders is not None:
+        # one guarded step first: if the RCCL point-to-point group cannot run on this node, every rank learns it
+        # (min-reduce of a flag) and the broadphase stage is dropped -- and reported as dropped -- instead of
+        # crashing the whole scaling measurement
+        ok = 1
+        try:
+            step()
+            fence()
+        except Exception as e:                                  # noqa: BLE001
+            ok = 0
+            exchange_note = f"border exchange failed ({type(e).__name__}: {e}); broadphase stage dropped"
+            print(exchange_note, file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            exchange_note = exchange_note or "border exchange failed on another rank; broadphase stage dropped"
+            borders = None
+            stages = [x for x in stages if x != "broadphase"]
+            flags &= ~capi.BROADPHASE
+            t.set_stream(0, external=False)
     for _ in range(args.warmup):
         step()
     fence()
@@ -264,7 +285,7 @@ def main():
                 "visible": int(counts.visible),
                 "pairs": int(counts.pairs),
                 "graph": bool(args.graph),
-                "exchange": ("border AABBs, RCCL send/recv to <=8 neighbour tiles per step" if borders is not None else "none"),
+                "exchange": (exchange_note or ("border AABBs, RCCL send/recv to <=8 neighbour tiles per step" if borders is not None else "none")),
                 "resident": "device SoA authoritative; no per-step host transfer",
                 "backend": args.backend if world_size > 1 else None,
                 "rehearsal_same_device": bool(args.same_device),
