@@ -504,9 +504,9 @@ int scTickUploadBounds(ScTickContext* c, uint32_t first, uint32_t count, const f
   if (!upload3(c, max3, first, count, c->d.bmaxx, c->d.bmaxy, c->d.bmaxz)) return 0;
   for (uint32_t i = 0; i < count; ++i) {
     uint8_t& f = c->hFlags[first + i];
-    f = (uint8_t)((f & ~2u) | ((!has || has[i]) ? 2u : 0u));
+    const uint8_t nf = (uint8_t)((f & ~2u) | ((!has || has[i]) ? 2u : 0u));
+    if (nf != f) { f = nf; c->linksStale = true; }          // link words only change when membership does
   }
-  c->linksStale = true;
   return 1;
 }
 
@@ -520,9 +520,9 @@ int scTickUploadRenderMeshes(ScTickContext* c, uint32_t first, uint32_t count, c
   if (!sync(c)) return 0;
   for (uint32_t i = 0; i < count; ++i) {
     uint8_t& f = c->hFlags[first + i];
-    f = (uint8_t)((f & ~1u) | ((!has || has[i]) ? 1u : 0u));
+    const uint8_t nf = (uint8_t)((f & ~1u) | ((!has || has[i]) ? 1u : 0u));
+    if (nf != f) { f = nf; c->linksStale = true; }
   }
-  c->linksStale = true;
   return 1;
 }
 
