@@ -615,8 +615,23 @@ __device__ __forceinline__ void sinkPush(const DeviceState& d, const TickParams&
 }
 
 constexpr uint32_t kPairTabSize = kBinCap * (kBinCap - 1) / 2;
+constexpr uint32_t kFineThreshold = 24;      // bins with more records than this use the 4x4 cell grid
+
+// pair predicate shared by both search paths: group/mask filter, closed-interval overlap, and "this sector
+// holds the low corner of the intersection" (so the pair is reported from exactly one bin)
+__device__ __forceinline__ bool pairHit(const TickParams& p, const float4& amin, const float4& amax, const float4& bmin, const float4& bmax,
+                                        float secX, float secZ, uint32_t& ia, uint32_t& ib)
+{
+  if (!filterPass(__float_as_uint(amin.w), __float_as_uint(bmin.w))) return false;
+  if (!boxesOverlap(amin, amax, bmin, bmax)) return false;
+  ia = __float_as_uint(amax.w) & ~kPrimary; ib = __float_as_uint(bmax.w) & ~kPrimary;
+  const float lx = amin.x > bmin.x ? amin.x : bmin.x, lz = amin.z > bmin.z ? amin.z : bmin.z;
+  return ia != ib && (floorf(lx * p.invSector) - p.binOx) == secX && (floorf(lz * p.invSector) - p.binOz) == secZ;
+}
+
 __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks,
-                                          float4 (*tile)[2 * kBinCap], uint16_t* pairTab, uint2 (*pairBuf)[kWavePairBuf])
+                                          float4 (*tile)[2 * kBinCap], uint16_t* pairTab, uint2 (*pairBuf)[kWavePairBuf],
+                                          unsigned long long (*cellMembers)[16])
 {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
@@ -712,27 +727,63 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       if (anyPairs) {
         T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
         __builtin_amdgcn_wave_barrier();
-        const uint32_t npairs = n * (n - 1u) / 2u;
-        for (uint32_t q0 = 0; q0 < npairs; q0 += 64u) {
-          const uint32_t q = q0 + lane;
-          bool hit = false;
-          uint32_t ia = 0, ib = 0;
-          if (q < npairs) {
-            const uint32_t ij = pairTab[q];
-            const uint32_t i = ij >> 8, j = ij & 255u;
-            if ((validMask >> i) & (validMask >> j) & 1ull) {
-              const float4 amin = T[2u * i], bmin = T[2u * j];
-              if (filterPass(__float_as_uint(amin.w), __float_as_uint(bmin.w))) {
-                const float4 amax = T[2u * i + 1u], bmax = T[2u * j + 1u];
-                if (boxesOverlap(amin, amax, bmin, bmax)) {
-                  ia = __float_as_uint(amax.w) & ~kPrimary; ib = __float_as_uint(bmax.w) & ~kPrimary;
-                  const float lx = amin.x > bmin.x ? amin.x : bmin.x, lz = amin.z > bmin.z ? amin.z : bmin.z;
-                  hit = ia != ib && (floorf(lx * p.invSector) - p.binOx) == secX && (floorf(lz * p.invSector) - p.binOz) == secZ;
-                }
-              }
+        if (n <= kFineThreshold) {
+          // sparse bin: all n(n-1)/2 record pairs spread over the lanes through the triangular table
+          const uint32_t npairs = n * (n - 1u) / 2u;
+          for (uint32_t q0 = 0; q0 < npairs; q0 += 64u) {
+            const uint32_t q = q0 + lane;
+            bool hit = false;
+            uint32_t ia = 0, ib = 0;
+            if (q < npairs) {
+              const uint32_t ij = pairTab[q];
+              const uint32_t i = ij >> 8, j = ij & 255u;
+              if ((validMask >> i) & (validMask >> j) & 1ull)
+                hit = pairHit(p, T[2u * i], T[2u * i + 1u], T[2u * j], T[2u * j + 1u], secX, secZ, ia, ib);
             }
+            sinkPush(d, p, sink, hit, ia, ib);
           }
-          sinkPush(d, p, sink, hit, ia, ib);
+        } else {
+          // dense bin: LDS grid of 4x4 cells (16 m at the default sector size) inside the tile.  A box covering
+          // at most 2x2 cells is "small": it registers in its cells with LDS atomics and only meets the small
+          // boxes sharing a cell (any monotone cell function keeps every overlapping pair, clamping included);
+          // the few wider boxes (ground slabs span the sector) are broadcast partners for everybody.
+          unsigned long long* cells = cellMembers[wave];
+          if (lane < 16u) cells[lane] = 0ull;
+          const float ox = (secX + p.binOx) * 4.0f, oz = (secZ + p.binOz) * 4.0f, inv4 = p.invSector * 4.0f;
+          const int cx0 = min(3, max(0, (int)floorf(rmin.x * inv4 - ox))), cx1 = min(3, max(0, (int)floorf(rmax.x * inv4 - ox)));
+          const int cz0 = min(3, max(0, (int)floorf(rmin.z * inv4 - oz))), cz1 = min(3, max(0, (int)floorf(rmax.z * inv4 - oz)));
+          const bool small = admissible && (cx1 - cx0) <= 1 && (cz1 - cz0) <= 1;
+          const bool wide = admissible && !small;
+          __builtin_amdgcn_wave_barrier();
+          const uint32_t c00 = (uint32_t)(cz0 * 4 + cx0), c01 = (uint32_t)(cz0 * 4 + cx1), c10 = (uint32_t)(cz1 * 4 + cx0), c11 = (uint32_t)(cz1 * 4 + cx1);
+          if (small) {
+            const unsigned long long bit = 1ull << lane;
+            atomicOr(&cells[c00], bit);
+            if (c01 != c00) atomicOr(&cells[c01], bit);
+            if (c10 != c00) atomicOr(&cells[c10], bit);
+            if (c11 != c01 && c11 != c10) atomicOr(&cells[c11], bit);
+          }
+          __builtin_amdgcn_wave_barrier();
+          unsigned long long cand = 0ull;
+          if (small) cand = (cells[c00] | cells[c01] | cells[c10] | cells[c11]) & ((1ull << lane) - 1ull);   // partners j < i
+          while (__ballot(cand != 0ull)) {
+            bool hit = false; uint32_t ia = 0, ib = 0;
+            if (cand) {
+              const uint32_t j = (uint32_t)__ffsll((long long)cand) - 1u;
+              cand &= cand - 1ull;
+              hit = pairHit(p, rmin, rmax, T[2u * j], T[2u * j + 1u], secX, secZ, ia, ib);
+            }
+            sinkPush(d, p, sink, hit, ia, ib);
+          }
+          unsigned long long wides = __ballot(wide);
+          while (wides) {
+            const uint32_t wI = (uint32_t)__ffsll((long long)wides) - 1u;
+            wides &= wides - 1ull;
+            bool hit = false; uint32_t ia = 0, ib = 0;
+            // every small box meets every wide one; two wide boxes meet once (lower lane tests against the higher)
+            if (admissible && lane != wI && (small || lane < wI)) hit = pairHit(p, rmin, rmax, T[2u * wI], T[2u * wI + 1u], secX, secZ, ia, ib);
+            sinkPush(d, p, sink, hit, ia, ib);
+          }
         }
       }
 
@@ -773,7 +824,8 @@ __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const Tick
   __shared__ float4 tile[kTile / 64][2 * kBinCap];        // 2 KiB per wave: the bin as an LDS tile
   __shared__ uint16_t pairTab[kPairTabSize];              // q -> (i << 8 | j), 0 <= j < i < 64
   __shared__ uint2 pairBuf[kTile / 64][kWavePairBuf];     // 2 KiB per wave: hits waiting for a flush
-  pairsBody(d, p, blockIdx.x, gridDim.x, tile, pairTab, pairBuf);
+  __shared__ unsigned long long cellMembers[kTile / 64][16];   // per wave: which records touch each of the 4x4 cells
+  pairsBody(d, p, blockIdx.x, gridDim.x, tile, pairTab, pairBuf, cellMembers);
 }
 
 // read-back helper: concatenates the shards' segments into one list and writes the total found
@@ -802,9 +854,10 @@ __global__ __launch_bounds__(kTile) void k_compact_pairs(const DeviceState d, co
   __shared__ float4 tile[kTile / 64][2 * kBinCap];
   __shared__ uint16_t pairTab[kPairTabSize];
   __shared__ uint2 pairBuf[kTile / 64][kWavePairBuf];
+  __shared__ unsigned long long cellMembers[kTile / 64][16];
   __shared__ uint32_t scratch[kTile / 64];
   if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, scratch);
-  else pairsBody(d, p, blockIdx.x - compactBlocks, gridDim.x - compactBlocks, tile, pairTab, pairBuf);
+  else pairsBody(d, p, blockIdx.x - compactBlocks, gridDim.x - compactBlocks, tile, pairTab, pairBuf, cellMembers);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1051,7 +1104,7 @@ void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s)
   const uint32_t sectors = p.binSX * p.binSZ;
   if (!sectors) return;
   uint32_t grid = (sectors + 3u) / 4u;
-  const uint32_t cap = (p.variant >> 8) ? (p.variant >> 8) : 2048u;     // SC_TICK_VARIANT bits 8+: pair-kernel grid cap (tuning)
+  const uint32_t cap = (p.variant >> 8) ? (p.variant >> 8) : 1024u;     // SC_TICK_VARIANT bits 8+: pair-kernel grid cap (tuning)
   if (grid > cap) grid = cap;
   hipLaunchKernelGGL(k_pairs, dim3(grid), dim3(kTile), 0, s, d, p);
 }
@@ -1059,7 +1112,7 @@ void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t comp
 {
   const uint32_t sectors = p.binSX * p.binSZ;
   uint32_t pairGrid = (sectors + 3u) / 4u;
-  const uint32_t cap = (p.variant >> 8) ? (p.variant >> 8) : 2048u;
+  const uint32_t cap = (p.variant >> 8) ? (p.variant >> 8) : 1024u;
   if (pairGrid > cap) pairGrid = cap;
   hipLaunchKernelGGL(k_compact_pairs, dim3(compactGrid + pairGrid), dim3(kTile), 0, s, d, p, compactGrid);
 }
