@@ -187,7 +187,13 @@ def main():
         t.set_stream(tick_stream.cuda_stream, external=True)
         borders = tiles.BorderBuffers(t, rank, grid, torch.device("cuda", local_rank))
 
+    if args.graph:
+        # the producer becomes part of the frame, so one hipGraph holds producer + fused kernel + compaction/pairs
+        t.set_frame_producer(2 if args.workload == "config5" else 1, 1.0 / 60.0 if args.workload == "config5" else 0.01)
+
     def produce():
+        if args.graph:
+            return
         if args.workload == "config5":
             t.advance_movers(1.0 / 60.0)          # vehicles + peds move, props stay clean (50 % dirty)
         else:

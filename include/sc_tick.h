@@ -187,6 +187,10 @@ int scTickUploadMovers(ScTickContext* ctx, uint32_t first, uint32_t count, const
                        const float* vel_xz2, const float* lo_xz2, const float* hi_xz2);
 int scTickAdvanceMovers(ScTickContext* ctx, float dt);
 int scTickReadMoverVelocities(ScTickContext* ctx, uint32_t first, uint32_t count, float* vel_xz2);
+/* Make a producer part of the frame: every scTickRun then starts with it, so the whole frame (producer +
+ * tick) is one stream sequence and, in graph mode, one captured hipGraph.  kind 0 = none,
+ * 1 = scTickNudgeRootsX(param), 2 = scTickAdvanceMovers(param). */
+int scTickSetFrameProducer(ScTickContext* ctx, uint32_t kind, float param);
 
 /* ---- results (each synchronises the stream) ---- */
 int scTickGetCounts(ScTickContext* ctx, ScTickCounts* out);

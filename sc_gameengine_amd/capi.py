@@ -69,6 +69,7 @@ SYMBOLS = {
     "scTickUploadMovers": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P, F32P, F32P, F32P]),
     "scTickAdvanceMovers": (C.c_int, [_CTX, C.c_float]),
     "scTickReadMoverVelocities": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
+    "scTickSetFrameProducer": (C.c_int, [_CTX, C.c_uint32, C.c_float]),
     "scTickSetViewProj": (C.c_int, [_CTX, F32P]),
     "scTickSetFrustumPlanes": (C.c_int, [_CTX, F32P, C.c_int]),
     "scTickGetFrustumPlanes": (C.c_int, [_CTX, F32P, C.POINTER(C.c_int)]),

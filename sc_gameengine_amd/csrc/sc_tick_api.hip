@@ -76,6 +76,7 @@ struct ScTickContext
   uint32_t* dPairTotal = nullptr;      // [0] pairs found, [1] truncated flag
   uint32_t parity = 0, lastParity = 0;
   uint32_t rank = 0, neighbourMask = 0;
+  uint32_t producerKind = 0; float producerParam = 0.0f;      // part of the frame when set (scTickSetFrameProducer)
   bool pairsPending = false;
   TickParams pendingParams{};
   hipStream_t ownStream = nullptr;
@@ -308,6 +309,11 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
   const bool prof = allowProfile && c->profiling;
   const bool saved = c->profiling;
   c->profiling = prof;
+  if (c->producerKind) {
+    Scoped s(c, SC_TICK_K_NUDGE);
+    if (c->producerKind == 1) launchNudgeRootsX(c->d, c->n, c->producerParam, c->stream);
+    else launchAdvanceMovers(c->d, c->n, c->producerParam, c->stream);
+  }
   if (flags & (SC_TICK_XFORM | SC_TICK_CULL | SC_TICK_BROADPHASE)) {
     Scoped s(c, SC_TICK_K_XFORM_CULL);
     launchXformCull(c->d, p, grid, c->stream);
@@ -675,7 +681,8 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   c->lastFlags = flags;
 
   const uint32_t q = (flags & SC_TICK_BROADPHASE) ? c->parity : 0u;
-  if (c->graphMode && !c->profiling) {
+  const bool sampledTick = c->profiling && (c->tickIndex % c->profPeriod) == 0;     // events need eager launches
+  if (c->graphMode && !sampledTick) {
     const bool stale = !c->graphExec[q] || c->graphEpoch[q] != c->topoEpoch || std::memcmp(&p, &c->graphParams[q], sizeof p) != 0;
     if (stale) {
       dropGraph(c, (int)q);
@@ -796,6 +803,18 @@ int scTickAdvanceMovers(ScTickContext* c, float dt)
   if (!c->d.moverKind) return fail(c, "no movers uploaded");
   Scoped s(c, SC_TICK_K_NUDGE);
   launchAdvanceMovers(c->d, c->n, dt, c->stream);
+  return 1;
+}
+
+int scTickSetFrameProducer(ScTickContext* c, uint32_t kind, float param)
+{
+  if (!c) return 0;
+  if (kind > 2u) return fail(c, "producer kind must be 0 (none), 1 (nudge roots) or 2 (advance movers)");
+  if (kind == 2u && !c->d.moverKind) return fail(c, "no movers uploaded");
+  if (!bind(c) || !sync(c)) return 0;
+  dropGraph(c);                                   // the captured frame changes
+  c->producerKind = kind;
+  c->producerParam = param;
   return 1;
 }
 

@@ -209,6 +209,10 @@ class WorldTick:
     def advance_movers(self, dt):
         self._ok(self.lib.scTickAdvanceMovers(self.ctx, float(dt)), "scTickAdvanceMovers")
 
+    def set_frame_producer(self, kind, param=0.0):
+        """0 none, 1 nudge roots by `param`, 2 advance movers by dt=`param`: run() then is the whole frame"""
+        self._ok(self.lib.scTickSetFrameProducer(self.ctx, int(kind), float(param)), "scTickSetFrameProducer")
+
     def mover_velocities(self):
         out = np.zeros((self.n, 2), np.float32)
         self._ok(self.lib.scTickReadMoverVelocities(self.ctx, 0, self.n, _f(out)), "scTickReadMoverVelocities")

@@ -58,3 +58,30 @@ def test_movers_full_tick_matches_oracle(oracle):
     assert inside[w.mover_kind > 0].all()                                      # agents never leave their sector
     assert reflected > 10 and t.counts().pairs > 20
     t.close(); ow.close()
+
+
+def test_frame_producer_and_graph_replay_match_separate_calls(oracle):
+    """The whole frame (movers + tick) as one call -- and as one replayed hipGraph -- equals producer and
+    tick issued separately (BASELINE config 5: "hipGraph-captured frame")."""
+    w = sw.generate_config5(10, 10)
+    vp = camera_view_proj(w.camera)
+    ref = WorldTick.from_world(w, broadphase=True); ref.set_view_proj(vp)
+    one = WorldTick.from_world(w, broadphase=True); one.set_view_proj(vp)
+    gra = WorldTick.from_world(w, broadphase=True); gra.set_view_proj(vp)
+    one.set_frame_producer(2, DT)
+    gra.set_frame_producer(2, DT); gra.set_graph_mode(True)
+    for k in range(12):
+        ref.advance_movers(DT); ref.run(capi.FULL)
+        one.run(capi.FULL)
+        gra.run(capi.FULL)
+        if k % 3 == 2:
+            for other in (one, gra):
+                assert np.array_equal(other.positions().view(np.uint32), ref.positions().view(np.uint32))
+                assert np.array_equal(other.world_matrices().view(np.uint32), ref.world_matrices().view(np.uint32))
+                assert np.array_equal(other.visible(), ref.visible())
+                a, na = other.pairs(); b, nb = ref.pairs()
+                ka = np.sort(a[:, 0].astype(np.uint64) << np.uint64(32) | a[:, 1]); kb = np.sort(b[:, 0].astype(np.uint64) << np.uint64(32) | b[:, 1])
+                assert na == nb and np.array_equal(ka, kb)
+    gra.set_frame_producer(0)
+    for t in (ref, one, gra):
+        t.close()
