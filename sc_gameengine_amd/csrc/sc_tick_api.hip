@@ -301,6 +301,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.rankBits = c->rank << 24;
   p.neighbourMask = c->neighbourMask;
   p.variant = c->variant;
+  p.chain = std::min(c->maxDepth, kMaxChain);
 }
 
 void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool allowProfile)

@@ -305,13 +305,17 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
 // them lost to this form because they cost VGPRs, and this kernel is occupancy-bound.  DESIGN.md section 5.)
 // The body is a device function taking the arguments by reference on purpose: written directly in the
 // __global__ function the same code allocates 84/91 VGPRs instead of 64/77 (hipcc, ROCm 7.2).
-template <bool kCull, bool kAabb>
+// kChain = how many ancestors a lane may have to walk: min(deepest level in the world, kMaxChain), known to the
+// host after scTickSetTopology.  Specialising on it removes dead levels from worlds that are flat or shallow.
+// (Requesting all levels' locals before multiplying -- one round trip instead of one per level -- was measured:
+// it needs 12 more VGPRs per level, 104-116 in all, and lost 5-25 %)
+template <bool kCull, bool kAabb, uint32_t kChain>
 __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p);
 
-template <bool kCull, bool kAabb>
-__global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb>(d, p); }
+template <bool kCull, bool kAabb, uint32_t kChain>
+__global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, kChain>(d, p); }
 
-template <bool kCull, bool kAabb>
+template <bool kCull, bool kAabb, uint32_t kChain>
 __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p)
 {
   const uint32_t lane = threadIdx.x & 63u;
@@ -328,18 +332,21 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
     const uint32_t i = base + threadIdx.x;
     const bool active = i < p.n;
     const uint32_t lk = active ? ldU(d, kLINK, i) : ((kUnreachable << kDepthShift) | kNoParent);
+    // requested together with the link word (it must not wait behind the depth test below: that costs
+    // a whole memory round trip per tile)
+    const uint32_t ownDirtyWord = (doXform && active) ? d.dirty[i >> 5] : 0u;
     const uint32_t depth = linkDepth(lk);
-    const bool chain = depth <= kMaxChain;
+    const bool chain = depth <= kChain;
     // ---- walk up: ancestors a[1..depth], top = dirty level nearest the root
-    uint32_t a[kMaxChain + 1];                         // ancestors
+    uint32_t a[kChain + 1];                            // ancestors
     uint32_t rotFlags = lk >> 29;                      // 3 rotation-triviality bits per level, level k at bits 3k..3k+2
     a[0] = i;
     int top = -1;
     if (doXform && chain) {
-      if (dirtyBit(d.dirty, i)) top = 0;
+      if ((ownDirtyWord >> (i & 31u)) & 1u) top = 0;
       uint32_t cur = lk;
 #pragma unroll
-      for (uint32_t k = 1; k <= kMaxChain; ++k) {
+      for (uint32_t k = 1; k <= kChain; ++k) {
         a[k] = i;
         if (k <= depth) {
           a[k] = cur & kParentMask;
@@ -350,20 +357,20 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
       }
     } else {
 #pragma unroll
-      for (uint32_t k = 1; k <= kMaxChain; ++k) a[k] = i;
+      for (uint32_t k = 1; k <= kChain; ++k) a[k] = i;
     }
     const bool recompute = top >= 0;
 
     Aff M;
     if (recompute) {
       const bool fromRoot = (uint32_t)top == depth;       // the chain's root itself is rebuilt: world = local
-      if (!fromRoot) {
-        // clean parent of the top dirty ancestor: its stored (possibly stale) matrix is the seed
-        const uint32_t seed = (top == 0) ? a[1] : (top == 1) ? a[2] : a[3];
-        M = loadRows(d, seed);
-      }
+      uint32_t seed = i;
 #pragma unroll
-      for (int lev = (int)kMaxChain; lev >= 0; --lev) {
+      for (uint32_t k = 0; k < kChain; ++k) if ((uint32_t)top == k) seed = a[k + 1];
+      // clean parent of the top dirty ancestor: its stored (possibly stale) matrix is the seed
+      if (!fromRoot) M = loadRows(d, seed);
+#pragma unroll
+      for (int lev = (int)kChain; lev >= 0; --lev) {
         if (lev <= top) {
           const Aff L = loadLocal(d, a[lev], (rotFlags >> (3 * lev)) << 29);
           if (lev == top && fromRoot) M = L;
@@ -393,7 +400,7 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
           visible = sphereVisible(M, b, p.fr, c0, c1, c2);
         }
         // deeper entities get their matrix (and their bit) from the level kernels
-        if (doXform && depth > kMaxChain && depth != kUnreachable) visible = false;
+        if (doXform && depth > kChain && depth != kUnreachable) visible = false;
         const unsigned long long vm = __ballot(visible);
         const unsigned long long cm = __ballot(cand);
         if (lane == 0 && (base + wave * 64u) < p.n) {
@@ -405,7 +412,7 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
       }
       if (kAabb) {
         // deeper entities are binned by the level kernels once their matrix is final
-        const bool collider = hb && !(doXform && depth > kMaxChain && depth != kUnreachable);
+        const bool collider = hb && !(doXform && depth > kChain && depth != kUnreachable);
         binEntityWave(d, p, i, collider, M, b);
       }
     }
@@ -1082,13 +1089,23 @@ __global__ __launch_bounds__(kTile) void k_emit_draws(const DeviceState d, uint3
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
+template <uint32_t kChain>
+static void launchXformCullChain(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
 {
   const bool cull = (p.flags & SC_TICK_CULL) != 0, aabb = (p.flags & SC_TICK_BROADPHASE) != 0;
-  if (cull && aabb) hipLaunchKernelGGL((k_xform_cull<true, true>), dim3(grid), dim3(kTile), 0, s, d, p);
-  else if (cull)    hipLaunchKernelGGL((k_xform_cull<true, false>), dim3(grid), dim3(kTile), 0, s, d, p);
-  else if (aabb)    hipLaunchKernelGGL((k_xform_cull<false, true>), dim3(grid), dim3(kTile), 0, s, d, p);
-  else              hipLaunchKernelGGL((k_xform_cull<false, false>), dim3(grid), dim3(kTile), 0, s, d, p);
+  if (cull && aabb) hipLaunchKernelGGL((k_xform_cull<true, true, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
+  else if (cull)    hipLaunchKernelGGL((k_xform_cull<true, false, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
+  else if (aabb)    hipLaunchKernelGGL((k_xform_cull<false, true, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
+  else              hipLaunchKernelGGL((k_xform_cull<false, false, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
+}
+void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
+{
+  switch (p.chain) {                                          // deepest level a lane walks: min(world depth, kMaxChain)
+    case 0: launchXformCullChain<0>(d, p, grid, s); break;
+    case 1: launchXformCullChain<1>(d, p, grid, s); break;
+    case 2: launchXformCullChain<2>(d, p, grid, s); break;
+    default: launchXformCullChain<3>(d, p, grid, s); break;
+  }
 }
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* list, uint32_t count, hipStream_t s)
 {
