@@ -8,7 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sc_gameengine_amd import capi, synth_world as sw
 from sc_gameengine_amd.tick import WorldTick, camera_view_proj
 
-variants = [v for v in (sys.argv[1] if len(sys.argv) > 1 else "0,1").split(",")]
+# a variant is "BITS[:SPANS]": SC_TICK_VARIANT bits (8 = compaction and pair search as separate launches,
+# bits 8+ = pair-kernel grid cap) and optionally SC_TICK_SPANS (workgroups of the fused kernel)
+variants = [v for v in (sys.argv[1] if len(sys.argv) > 1 else "0,8").split(",")]
 w = sw.config("config3")
 vp = camera_view_proj(w.camera)
 ctxs = {}
