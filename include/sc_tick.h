@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SC_TICK_API_VERSION 1u
+#define SC_TICK_API_VERSION 2u
 #define SC_TICK_MAX_ENTITIES ((1u << 24) - 1u)   /* Entity::INDEX_BITS = 24 (sc_ecs.h:18-20); index 0xFFFFFF is the "no parent" value */
 #define SC_TICK_NO_PARENT (-1)
 
@@ -220,6 +220,63 @@ int scTickHostMat4PerspectiveRhZo(float fov_y_radians, float aspect, float z_nea
 /* viewProj = perspective(fovY*pi/180, aspect, near, far, flipY) * inverse(cameraWorld), sc_ecs.cpp:261-270 */
 int scTickHostCameraViewProj(const float camera_world[16], float fov_y_degrees, float aspect,
                              float z_near, float z_far, float out_view_proj[16]);
+
+/* ---- sector data (.scsector) and residency: the callers either side of the tick ----
+ * Host-side reader of the editor/streamer sector format, tools/shared/world_format.cpp:185-338 (ReadSectorFile;
+ * record layout as written by WriteSectorFile :76-181), straight into SoA arrays the upload calls take.
+ * All versions the reference reads are read the same way: the INST record size is derived from the chunk size,
+ * names / texture overrides are present when the record is long enough (:219-230), extra record bytes are
+ * skipped, unknown chunks are skipped by their size, zero-sized chunk headers are ignored, and known chunks are
+ * parsed by their own counts.  A file that ends early leaves the remaining fields at the reference's defaults
+ * (id 0, scale 1, empty name), as its ifstream reads do; info->truncated tells. */
+typedef struct ScTickSectorInfo
+{
+  uint32_t version;                /* SectorFile::version (kSectorVersion = 4, world_format.h:13) */
+  int32_t  sector_x, sector_z;     /* SectorFile::sector */
+  uint32_t instances;              /* records in the file (may exceed what was stored: see capacity) */
+  uint32_t lanes, lane_points, spawners, colliders;
+  uint32_t truncated;              /* 1 = the data ended inside a header, count or record */
+} ScTickSectorInfo;
+
+typedef struct ScTickSectorInstances
+{
+  uint32_t capacity;               /* records each non-NULL array below can hold; the first `capacity` are stored */
+  uint64_t* id;                    /* Instance::id */
+  uint64_t* model_id;              /* 0 for version < 4 */
+  uint64_t* mesh_id;               /* asset ids (HashAssetPath), resolved to handles by the caller (:746-792 of sc_world_partition.cpp) */
+  uint64_t* material_id;
+  uint64_t* albedo_texture_id;     /* 0 unless the record carries overrides */
+  uint32_t* material_flags;
+  uint32_t* tags;
+  float* pos3; float* rot3; float* scale3;     /* Instance::transform, [capacity][3] each: what setLocal takes */
+  char* name64;                    /* [capacity][64], NUL-terminated (kInstanceNameMax) */
+} ScTickSectorInstances;
+
+/* 0 = not a sector file (bad magic / shorter than the magic) or NULL arguments; `out` may be NULL to only fill info */
+int scTickSectorParse(const void* data, uint64_t size, ScTickSectorInfo* info, const ScTickSectorInstances* out);
+int scTickSectorReadFile(const char* path, ScTickSectorInfo* info, const ScTickSectorInstances* out);
+/* AssetId of a path: FNV-1a 64 (with the reference's non-standard starting value) over the lexically normalised, '/'-separated, lower-cased path (world_format.cpp:52-74); 0 for NULL */
+uint64_t scTickHashAssetPath(const char* path);
+/* "<root>/sectors/sector_<x>_<z>.scsector" (world_format.cpp:382-389); returns the length needed (excluding NUL) */
+uint32_t scTickSectorPath(const char* world_root, int32_t x, int32_t z, char* out, uint32_t capacity);
+
+/* Sector activation (WorldPartition::pumpCompletedLoads, sc_world_partition.cpp:916-958): `count` entities are
+ * created at the END of the Transform pool's dense order (ComponentPool::add, sc_ecs.h:203-221) with setLocal
+ * (dirty), a RenderMesh, Bounds (NULL min/max = the unit cube kUnitCubeBounds, :27) and collision layers (NULL =
+ * group/mask all).  parent = NULL: all roots, nothing else is touched (O(count) work); otherwise dense indices
+ * (earlier entities or this batch) and the hierarchy is re-linked.  *first_index = dense index of the first one. */
+int scTickAppendEntities(ScTickContext* ctx, uint32_t count, const float* pos3, const float* rot3, const float* scale3,
+                         const float* bounds_min3, const float* bounds_max3,
+                         const uint32_t* mesh_id, const uint32_t* material_id,
+                         const uint32_t* group, const uint32_t* mask, const int32_t* parent, uint32_t* first_index);
+/* Despawn (WorldPartition::pumpUnloadQueue -> World::destroy, sc_world_partition.cpp:963-990, sc_ecs.cpp:28-42):
+ * `count` distinct entities, named by their dense indices AT THE TIME OF THE CALL, are removed one after the other
+ * with the pool's swap-remove (the last entity moves into the hole, sc_ecs.h:240-262), so the dense order afterwards
+ * is the reference's.  Children of a removed entity become dirty roots (sc_ecs.cpp:151-160).  The net relocations
+ * are returned: entity that was at moved_from[k] is now at moved_to[k] (arrays of `count`; may be NULL).
+ * Device cost is O(count) unless a removed or relocated entity has children (then the hierarchy is re-linked). */
+int scTickRemoveEntities(ScTickContext* ctx, const uint32_t* dense_indices, uint32_t count,
+                         uint32_t* moved_from, uint32_t* moved_to, uint32_t* moved_count);
 
 /* ---- measurement ---- */
 /* record HIP events around the kernel launches (on the context's stream) of every `enable`-th tick

@@ -42,6 +42,19 @@ class DrawItem(C.Structure):
                 ("pad", C.c_uint32), ("model", C.c_float * 16)]
 
 
+class SectorInfo(C.Structure):
+    _fields_ = [("version", C.c_uint32), ("sector_x", C.c_int32), ("sector_z", C.c_int32), ("instances", C.c_uint32),
+                ("lanes", C.c_uint32), ("lane_points", C.c_uint32), ("spawners", C.c_uint32), ("colliders", C.c_uint32),
+                ("truncated", C.c_uint32)]
+
+
+class SectorInstances(C.Structure):
+    _fields_ = [("capacity", C.c_uint32),
+                ("id", U64P), ("model_id", U64P), ("mesh_id", U64P), ("material_id", U64P), ("albedo_texture_id", U64P),
+                ("material_flags", U32P), ("tags", U32P),
+                ("pos3", F32P), ("rot3", F32P), ("scale3", F32P), ("name64", C.c_void_p)]
+
+
 # every symbol of include/sc_tick.h: name -> (restype, argtypes)
 _CTX = C.c_void_p
 SYMBOLS = {
@@ -92,6 +105,12 @@ SYMBOLS = {
     "scTickGetKernelTimes": (C.c_int, [_CTX, C.c_uint32, F32P, C.c_uint32, U32P]),
     "scTickSetGraphMode": (C.c_int, [_CTX, C.c_int]),
     "scTickGetStream": (C.c_void_p, [_CTX]),
+    "scTickSectorParse": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(SectorInfo), C.POINTER(SectorInstances)]),
+    "scTickSectorReadFile": (C.c_int, [C.c_char_p, C.POINTER(SectorInfo), C.POINTER(SectorInstances)]),
+    "scTickHashAssetPath": (C.c_uint64, [C.c_char_p]),
+    "scTickSectorPath": (C.c_uint32, [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_uint32]),
+    "scTickAppendEntities": (C.c_int, [_CTX, C.c_uint32, F32P, F32P, F32P, F32P, F32P, U32P, U32P, U32P, U32P, I32P, U32P]),
+    "scTickRemoveEntities": (C.c_int, [_CTX, U32P, C.c_uint32, U32P, U32P, U32P]),
     "scTickHostMat4Mul": (C.c_int, [F32P, F32P, F32P]),
     "scTickHostMat4Trs": (C.c_int, [F32P, F32P, F32P, F32P]),
     "scTickHostMat4Inverse": (C.c_int, [F32P, F32P]),

@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 using namespace sctick;
@@ -38,6 +40,7 @@ struct ScTickContext
   // host mirrors needed to (re)build link words
   std::vector<int32_t> hParent;
   std::vector<uint8_t> hFlags;       // bit0 has mesh, bit1 has bounds, bits 2..4 rotation about X/Y/Z trivial (sin 0, cos 1)
+  std::vector<uint32_t> hChildren;   // direct children per entity (valid while !linksStale): decides whether a despawn can skip re-linking
   bool linksStale = true;
   uint32_t maxDepth = 0, unreachable = 0;
   std::vector<uint32_t> levelOffsets;   // offsets into dLevelList for depth kMaxChain+1, +2, ...
@@ -177,6 +180,9 @@ void rebuildLinks(ScTickContext* c, std::vector<uint32_t>& link, std::vector<uin
     if (p == SC_TICK_NO_PARENT) continue;
     if (p < 0 || (uint32_t)p >= n || (uint32_t)p == i) { par[i] = SC_TICK_NO_PARENT; detached.push_back(i); }
   }
+
+  std::fill(c->hChildren.begin(), c->hChildren.begin() + n, 0u);
+  for (uint32_t i = 0; i < n; ++i) if (par[i] != SC_TICK_NO_PARENT) c->hChildren[(uint32_t)par[i]]++;
 
   // depth by walking up with memoisation; a walk that meets its own trail has found a cycle
   constexpr int32_t kUnknown = -1, kCycle = -2;
@@ -433,6 +439,7 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
   if (!ok) { gCreateError = c->err; scTickDestroyContext(c); return nullptr; }
   c->hParent.assign(desc->capacity, SC_TICK_NO_PARENT);
   c->hFlags.assign(desc->capacity, 0);
+  c->hChildren.assign(desc->capacity, 0);
   return c;
 }
 
@@ -556,6 +563,151 @@ int scTickSetTopology(ScTickContext* c, const int32_t* parent, uint32_t count)
   std::copy(parent, parent + count, c->hParent.begin());
   c->linksStale = true;
   return flushLinks(c);
+}
+
+// ---- sector residency -------------------------------------------------------------------------------
+static uint32_t linkWordOfRoot(uint8_t f)
+{
+  return kNoParent | ((f & 1u) ? kHasMesh : 0u) | ((f & 2u) ? kHasBounds : 0u) |
+         ((f & 4u) ? kRotTrivialX : 0u) | ((f & 8u) ? kRotTrivialY : 0u) | ((f & 16u) ? kRotTrivialZ : 0u);
+}
+
+int scTickAppendEntities(ScTickContext* c, uint32_t count, const float* pos3, const float* rot3, const float* scale3,
+                         const float* bmin3, const float* bmax3, const uint32_t* mesh, const uint32_t* material,
+                         const uint32_t* group, const uint32_t* mask, const int32_t* parent, uint32_t* firstOut)
+{
+  if (!c) return 0;
+  if (count && (!pos3 || !rot3 || !scale3)) return fail(c, "null argument");
+  if ((bmin3 == nullptr) != (bmax3 == nullptr) || (group == nullptr) != (mask == nullptr)) return fail(c, "bounds / layers come in pairs");
+  if (!bind(c)) return 0;
+  const uint32_t first = c->n;
+  if ((uint64_t)first + count > c->desc.capacity) return fail(c, "append exceeds capacity");
+  if (firstOut) *firstOut = first;
+  if (!count) return 1;
+  if (parent) for (uint32_t i = 0; i < count; ++i)
+    if (parent[i] != SC_TICK_NO_PARENT && (parent[i] < 0 || (uint32_t)parent[i] >= first + count)) return fail(c, "parent index out of range");
+
+  const bool wasStale = c->linksStale;
+  c->n = first + count;
+  for (uint32_t i = first; i < first + count; ++i) { c->hFlags[i] = 0; c->hParent[i] = SC_TICK_NO_PARENT; c->hChildren[i] = 0; }
+
+  std::vector<float> cube;
+  if (!bmin3) { cube.assign((size_t)count * 6, 0.5f); for (size_t i = 0; i < (size_t)count * 3; ++i) cube[i] = -0.5f; }   // kUnitCubeBounds
+  std::vector<uint32_t> all;
+  if (!group) all.assign(count, 0xFFFFFFFFu);
+  std::vector<uint32_t> zeros;
+  if (!mesh || !material) zeros.assign(count, 0u);
+  const bool ok =
+      scTickUploadLocals(c, first, count, pos3, rot3, scale3, nullptr) &&
+      scTickUploadBounds(c, first, count, bmin3 ? bmin3 : cube.data(), bmax3 ? bmax3 : cube.data() + (size_t)count * 3, nullptr) &&
+      scTickUploadRenderMeshes(c, first, count, nullptr, mesh ? mesh : zeros.data(), material ? material : zeros.data()) &&
+      scTickUploadLayers(c, first, count, group ? group : all.data(), mask ? mask : all.data());
+  if (!ok) { c->n = first; c->linksStale = true; return 0; }
+  if (c->d.moverKind) {       // an appended entity is no mover until scTickUploadMovers says so
+    const hipError_t e = hipMemsetAsync(c->d.moverKind + first, 0, (size_t)count * 4u, c->stream);
+    if (e != hipSuccess) return fail(c, "hipMemsetAsync", e);
+  }
+
+  if (parent || wasStale) {
+    if (parent) std::copy(parent, parent + count, c->hParent.begin() + first);
+    c->linksStale = true;
+    return flushLinks(c);
+  }
+  // roots only and the rest of the hierarchy untouched: write just the new link words
+  std::vector<uint32_t> link(count);
+  for (uint32_t i = 0; i < count; ++i) link[i] = linkWordOfRoot(c->hFlags[first + i]);
+  if (!h2d(c, c->d.link + first, link.data(), (size_t)count * 4u) || !sync(c)) { c->linksStale = true; return 0; }
+  c->linksStale = false;
+  c->topoEpoch++;
+  return 1;
+}
+
+int scTickRemoveEntities(ScTickContext* c, const uint32_t* idx, uint32_t count, uint32_t* movedFrom, uint32_t* movedTo, uint32_t* movedCount)
+{
+  if (!c) return 0;
+  if (movedCount) *movedCount = 0;
+  if (!idx && count) return fail(c, "null argument");
+  if (!bind(c)) return 0;
+  if (!count) return 1;
+  const uint32_t n0 = c->n;
+  if (count > n0) return fail(c, "more removals than entities");
+
+  // Replay the swap-removes on an index map that only holds the slots they touch.
+  std::unordered_map<uint32_t, uint32_t> occupant;   // slot -> original index of the entity now in it
+  std::unordered_map<uint32_t, uint32_t> where;      // original index -> slot it was moved to
+  std::unordered_set<uint32_t> removed;
+  occupant.reserve(count * 2u); where.reserve(count * 2u); removed.reserve(count * 2u);
+  uint32_t size = n0;
+  for (uint32_t k = 0; k < count; ++k) {
+    const uint32_t r = idx[k];
+    if (r >= n0) return fail(c, "dense index out of range");
+    if (!removed.insert(r).second) return fail(c, "dense index listed twice");
+    const auto w = where.find(r);
+    const uint32_t slot = w == where.end() ? r : w->second;
+    const uint32_t last = size - 1u;
+    const auto o = occupant.find(last);
+    const uint32_t lastOrig = o == occupant.end() ? last : o->second;
+    if (slot != last) { occupant[slot] = lastOrig; where[lastOrig] = slot; }
+    size = last;
+  }
+  const uint32_t n1 = size;
+  std::vector<uint32_t> src, dst;
+  for (const auto& kv : occupant) if (kv.first < n1 && kv.second != kv.first) { dst.push_back(kv.first); src.push_back(kv.second); }
+  // deterministic order for the caller
+  {
+    std::vector<uint32_t> order(dst.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return dst[a] < dst[b]; });
+    std::vector<uint32_t> s2(src.size()), d2(dst.size());
+    for (uint32_t i = 0; i < order.size(); ++i) { s2[i] = src[order[i]]; d2[i] = dst[order[i]]; }
+    src.swap(s2); dst.swap(d2);
+  }
+  const uint32_t moves = (uint32_t)src.size();
+
+  // Can the hierarchy be left alone?  Only if nothing that goes away or moves is anybody's parent, and no
+  // index lives in a level list or a cycle.
+  bool relink = c->linksStale || c->unreachable > 0 || c->maxDepth > kMaxChain;
+  if (!relink) {
+    for (uint32_t k = 0; k < count && !relink; ++k) relink = c->hChildren[idx[k]] != 0;
+    for (uint32_t k = 0; k < moves && !relink; ++k) relink = c->hChildren[src[k]] != 0;
+  }
+
+  // device: relocate every per-entity array
+  if (moves) {
+    if (c->scratchCap < 2u * moves) {
+      if (!dalloc(c, c->dIdx, 2u * (size_t)moves, false) || !dalloc(c, c->dRows, 2u * (size_t)moves * 12, false)) return 0;
+      c->scratchCap = 2u * moves;
+    }
+    if (!h2d(c, c->dIdx, src.data(), (size_t)moves * 4u) || !h2d(c, c->dIdx + moves, dst.data(), (size_t)moves * 4u)) return 0;
+    launchMoveEntities(c->d, c->dIdx, c->dIdx + moves, moves, c->stream);
+  }
+
+  // host mirrors
+  if (!relink) {
+    for (uint32_t k = 0; k < count; ++k) { const int32_t p = c->hParent[idx[k]]; if (p != SC_TICK_NO_PARENT) c->hChildren[(uint32_t)p]--; }
+    for (uint32_t k = 0; k < moves; ++k) { c->hParent[dst[k]] = c->hParent[src[k]]; c->hFlags[dst[k]] = c->hFlags[src[k]]; c->hChildren[dst[k]] = 0; }
+  } else {
+    // parents are rewritten through the relocation map; a child of a removed entity gets an invalid parent,
+    // which the re-link detaches and marks dirty (sc_ecs.cpp:151-160)
+    std::unordered_map<uint32_t, uint32_t> movedTo;
+    movedTo.reserve(moves * 2u);
+    for (uint32_t k = 0; k < moves; ++k) movedTo[src[k]] = dst[k];
+    for (uint32_t k = 0; k < moves; ++k) { c->hParent[dst[k]] = c->hParent[src[k]]; c->hFlags[dst[k]] = c->hFlags[src[k]]; }
+    constexpr int32_t kGone = -2;
+    for (uint32_t i = 0; i < n1; ++i) {
+      const int32_t p = c->hParent[i];
+      if (p == SC_TICK_NO_PARENT) continue;
+      if (removed.count((uint32_t)p)) c->hParent[i] = kGone;
+      else { const auto m = movedTo.find((uint32_t)p); if (m != movedTo.end()) c->hParent[i] = (int32_t)m->second; }
+    }
+    c->linksStale = true;
+  }
+  c->n = n1;
+  c->topoEpoch++;
+  if (movedFrom && movedTo) { std::copy(src.begin(), src.end(), movedFrom); std::copy(dst.begin(), dst.end(), movedTo); }
+  if (movedCount) *movedCount = moves;
+  if (relink) return flushLinks(c);
+  return sync(c) ? 1 : 0;
 }
 
 int scTickMarkDirty(ScTickContext* c, uint32_t first, uint32_t count)

@@ -1066,6 +1066,36 @@ __global__ __launch_bounds__(kTile) void k_gather_rows(const DeviceState d, cons
   o[0] = d.w0[j]; o[1] = d.w1[j]; o[2] = d.w2[j];
 }
 
+// Swap-remove relocations (ComponentPool::remove, sc_ecs.h:240-262, applied to every per-entity array at
+// once): entity src[k] moves to slot dst[k].  The host guarantees every src lies at or beyond the new
+// entity count and every dst below it, so no slot is both read and written.  One thread per (move, array).
+constexpr uint32_t kMoveSlots = 40;     // 22 streams, 3 matrix rows, the dirty bit, 7 mover arrays (+ idle)
+__global__ __launch_bounds__(kTile) void k_move_entities(const DeviceState d, const uint32_t* __restrict__ src,
+                                                         const uint32_t* __restrict__ dst, uint32_t moves)
+{
+  const uint32_t t = blockIdx.x * kTile + threadIdx.x;
+  const uint32_t k = t / kMoveSlots, slot = t % kMoveSlots;
+  if (k >= moves) return;
+  const uint32_t from = src[k], to = dst[k];
+  if (slot < kStreamCount) {
+    uint32_t* base = reinterpret_cast<uint32_t*>(const_cast<char*>(d.fslab) + (size_t)slot * d.capBytes);
+    base[to] = base[from];
+  } else if (slot < kStreamCount + 3u) {
+    float4* rows = reinterpret_cast<float4*>(d.rslab + (size_t)(slot - kStreamCount) * d.capBytes16);
+    rows[to] = rows[from];
+  } else if (slot == kStreamCount + 3u) {
+    const bool isDirty = (d.dirty[from >> 5] >> (from & 31u)) & 1u;
+    if (isDirty) atomicOr(&d.dirty[to >> 5], 1u << (to & 31u));
+    else atomicAnd(&d.dirty[to >> 5], ~(1u << (to & 31u)));
+  } else if (d.moverKind && slot < kStreamCount + 11u) {
+    uint32_t* arrays[7] = { d.moverKind, reinterpret_cast<uint32_t*>(d.mvx), reinterpret_cast<uint32_t*>(d.mvz),
+                            reinterpret_cast<uint32_t*>(d.mlox), reinterpret_cast<uint32_t*>(d.mloz),
+                            reinterpret_cast<uint32_t*>(d.mhix), reinterpret_cast<uint32_t*>(d.mhiz) };
+    uint32_t* a = arrays[slot - kStreamCount - 4u];
+    a[to] = a[from];
+  }
+}
+
 // RenderPrepStreamingSystem draw emission (sc_world_partition.cpp:1306-1329): the first `budget`
 // visible entities, in order, become DrawItem{entity, mesh, material, worldMatrix}.
 struct DrawItem80 { uint32_t dense, mesh, material, pad; float model[16]; };
@@ -1172,6 +1202,12 @@ void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t c
 {
   if (!count) return;
   hipLaunchKernelGGL(k_set_dirty_indices, dim3((count + kTile - 1) / kTile), dim3(kTile), 0, s, d, idx, count);
+}
+void launchMoveEntities(const DeviceState& d, const uint32_t* src, const uint32_t* dst, uint32_t moves, hipStream_t s)
+{
+  if (!moves) return;
+  const uint64_t threads = (uint64_t)moves * kMoveSlots;
+  hipLaunchKernelGGL(k_move_entities, dim3((uint32_t)((threads + kTile - 1) / kTile)), dim3(kTile), 0, s, d, src, dst, moves);
 }
 void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s)
 {
