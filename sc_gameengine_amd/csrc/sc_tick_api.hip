@@ -78,6 +78,7 @@ struct ScTickContext
   uint2* dPairsOut = nullptr;          // gathered (contiguous) pair list for read-back
   uint32_t* dPairTotal = nullptr;      // [0] pairs found, [1] truncated flag
   uint32_t parity = 0, lastParity = 0;
+  uint32_t prevBroadphaseN = 0;        // entity count of the previous broadphase tick: bounds the bigBits words it may have set
   uint32_t rank = 0, neighbourMask = 0;
   uint32_t producerKind = 0; float producerParam = 0.0f;      // part of the frame when set (scTickSetFrameProducer)
   bool pairsPending = false;
@@ -308,6 +309,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.neighbourMask = c->neighbourMask;
   p.variant = c->variant;
   p.chain = std::min(c->maxDepth, kMaxChain);
+  p.bigClearWords = (c->prevBroadphaseN + 31u) >> 5;
 }
 
 void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool allowProfile)
@@ -850,6 +852,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
     enqueueStages(c, p, grid, true);
   }
   if (flags & SC_TICK_BROADPHASE) {
+    c->prevBroadphaseN = c->n;
     if (flags & SC_TICK_SPLIT_PAIRS) { c->pairsPending = true; c->pendingParams = p; }
     else { c->lastParity = c->parity; c->parity ^= 1u; }
   }

@@ -110,6 +110,7 @@ struct TickParams {
   uint32_t neighbourMask;   // bit d set: a neighbour tile exists in direction d (its ring side is foreign)
   uint32_t variant;         // kernel variant selector (A/B tuning; 0 = default)
   uint32_t chain;           // min(deepest hierarchy level, kMaxChain): selects the fused kernel's specialisation
+  uint32_t bigClearWords;   // words of the other parity's bigBits the previous broadphase tick may have set (its entity count / 32)
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d
 __host__ __device__ inline void borderDir(uint32_t d, int& dx, int& dz) { const uint32_t k = d < 4 ? d : d + 1; dx = (int)(k % 3) - 1; dz = (int)(k / 3) - 1; }

@@ -659,7 +659,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   if (bid == 0 && threadIdx.x < 8) d.counters[kCtrPar + 8u * (p.parity ^ 1u) + threadIdx.x] = 0u;
   if (bid == 0 && threadIdx.x < kPairShards) d.pairShardCount[((p.parity ^ 1u) * kPairShards + threadIdx.x) * kShardStride] = 0u;
   {
-    const uint32_t words = (p.n + 31u) >> 5;
+    const uint32_t words = p.bigClearWords;      // what the previous tick (other parity) can have set: its entity count, not this one's
     uint32_t* nextBits = d.bigBits[p.parity ^ 1u];
     for (uint32_t w = bid * kTile + threadIdx.x; w < words; w += nblocks * kTile) nextBits[w] = 0u;
   }

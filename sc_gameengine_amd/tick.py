@@ -200,6 +200,41 @@ class WorldTick:
     def nudge_roots_x(self, dx):
         self._ok(self.lib.scTickNudgeRootsX(self.ctx, float(dx)), "scTickNudgeRootsX")
 
+    # ---- sector residency (WorldPartition::pumpCompletedLoads / pumpUnloadQueue) ----
+    def append_entities(self, pos, rot, scale, bmin=None, bmax=None, mesh=None, material=None, group=None, mask=None, parent=None):
+        """Create len(pos) entities at the end of the dense order; returns the first one's dense index."""
+        p, r, s = _c32(pos).reshape(-1, 3), _c32(rot).reshape(-1, 3), _c32(scale).reshape(-1, 3)
+        k = len(p)
+        opt_f = [None if a is None else _c32(a) for a in (bmin, bmax)]
+        opt_u = [None if a is None else np.ascontiguousarray(a, np.uint32) for a in (mesh, material, group, mask)]
+        par = None if parent is None else np.ascontiguousarray(parent, np.int32)
+        first = C.c_uint32()
+        self._ok(self.lib.scTickAppendEntities(
+            self.ctx, k, _f(p), _f(r), _f(s), *[None if a is None else _f(a) for a in opt_f],
+            *[None if a is None else _u(a) for a in opt_u],
+            None if par is None else par.ctypes.data_as(capi.I32P), C.byref(first)), "scTickAppendEntities")
+        self.n += k
+        return first.value
+
+    def remove_entities(self, idx):
+        """Swap-remove the entities at these dense indices, in this order; returns (moved_from, moved_to)."""
+        i = np.ascontiguousarray(idx, np.uint32)
+        src, dst, m = np.zeros(len(i), np.uint32), np.zeros(len(i), np.uint32), C.c_uint32()
+        self._ok(self.lib.scTickRemoveEntities(self.ctx, _u(i), len(i), _u(src), _u(dst), C.byref(m)), "scTickRemoveEntities")
+        self.n -= len(i)
+        return src[:m.value].copy(), dst[:m.value].copy()
+
+    def activate_sector(self, sector, resolve_mesh=None, resolve_material=None):
+        """Spawn a parsed .scsector (sectors.SectorData) as pumpCompletedLoads does (sc_world_partition.cpp:916-958):
+        one root entity per instance with setLocal, RenderMesh handles from the resolvers (asset id -> handle; the
+        reference resolves id 0 to handle 0, :746-749), unit-cube Bounds.  Returns the dense indices."""
+        rm = resolve_mesh or (lambda a: 0)
+        rt = resolve_material or (lambda a: 0)
+        mesh = np.array([0 if int(a) == 0 else rm(int(a)) for a in sector.mesh_id], np.uint32)
+        mat = np.array([0 if int(a) == 0 else rt(int(a)) for a in sector.material_id], np.uint32)
+        first = self.append_entities(sector.pos, sector.rot, sector.scale, mesh=mesh, material=mat)
+        return np.arange(first, first + len(mesh), dtype=np.uint32)
+
     # ---- upstream movers ----
     def upload_movers(self, first, kind, vel, lo, hi):
         k = np.ascontiguousarray(kind, np.uint8)
