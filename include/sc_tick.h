@@ -53,6 +53,7 @@ enum {
   SC_TICK_DENSE_AABBS = 1u << 5,   /* with BROADPHASE: also keep per-entity world AABBs for scTickReadWorldAabbs */
   SC_TICK_SPLIT_PAIRS = 1u << 6,   /* with BROADPHASE on a multi-GPU tile: stop after filling the bins and packing the
                                       border messages; the caller exchanges them and calls scTickRunPairs */
+  SC_TICK_SORT_DRAWS  = 1u << 7,   /* with DRAWS: the list comes out in the renderer's bind order (scTickSetDrawSortTable) */
   SC_TICK_FULL        = SC_TICK_XFORM | SC_TICK_CULL | SC_TICK_BROADPHASE
 };
 
@@ -86,6 +87,7 @@ typedef struct ScTickCounts    /* CullingStats (sc_world_partition.h:334-339) + 
   uint32_t unreachable;        /* entities in or below a parent cycle (never updated, sc_ecs.cpp:173-210) */
   uint32_t bin_overflow;       /* broadphase boxes that found a sector bin full (they take the big list) */
   uint32_t big_boxes;          /* boxes in the big list: larger than 2x2 sectors, outside the tile rectangle, or bin full */
+  uint32_t draws_sorted;       /* with SC_TICK_SORT_DRAWS: draws left after the renderer's mesh / material handle checks */
 } ScTickCounts;
 
 typedef struct ScTickDrawItem  /* DrawItem, sc_ecs.h:159-165: 80 bytes, model at offset 16, column-major */
@@ -191,6 +193,14 @@ int scTickReadMoverVelocities(ScTickContext* ctx, uint32_t first, uint32_t count
  * tick) is one stream sequence and, in graph mode, one captured hipGraph.  kind 0 = none,
  * 1 = scTickNudgeRootsX(param), 2 = scTickAdvanceMovers(param). */
 int scTickSetFrameProducer(ScTickContext* ctx, uint32_t kind, float param);
+
+/* The renderer's draw order (VkRenderer::recordCommandBuffer, src/engine/src/sc_vk.cpp:1842-1864): draws whose
+ * mesh handle is >= mesh_count or whose material handle has no Material are skipped, the rest sorted by
+ * (Material::pipelineId, material handle, mesh handle).  pipeline_of_material[h] = pipelineId (< 128; PipelineId has
+ * two values, sc_assets.h:22-26) of material handle h, 0xFF = no such material; both counts <= 2^24.  With
+ * SC_TICK_DRAWS | SC_TICK_SORT_DRAWS the list scTickReadDraws returns is that sorted list.  Equal keys keep their
+ * visible-list order (std::sort leaves it unspecified).  Call again when materials or meshes are created. */
+int scTickSetDrawSortTable(ScTickContext* ctx, const uint8_t* pipeline_of_material, uint32_t material_count, uint32_t mesh_count);
 
 /* ---- results (each synchronises the stream) ---- */
 int scTickGetCounts(ScTickContext* ctx, ScTickCounts* out);

@@ -98,6 +98,8 @@ def lib():
     L.orc_culling_system.argtypes = [vp, C.POINTER(CullingState), F32P]
     L.orc_render_prep_streaming.argtypes = [vp, C.POINTER(CullingState), C.c_uint32, C.POINTER(DrawItem), C.c_uint32, U32P]
     L.orc_render_prep_streaming.restype = C.c_uint32
+    L.orc_renderer_draw_order.argtypes = [C.POINTER(DrawItem), C.c_uint32, U8P, C.c_uint32, C.c_uint32, U32P]
+    L.orc_renderer_draw_order.restype = C.c_uint32
     L.orc_world_to_sector.argtypes = [C.c_float, C.c_float, C.c_float, I32P, I32P]
     L.orc_world_aabb.argtypes = [F32P, C.POINTER(Bounds), F32P, F32P]
     L.orc_read_world_aabbs.argtypes = [vp, F32P, F32P]
@@ -386,8 +388,17 @@ class OracleWorld:
         buf = (DrawItem * cap)()
         dropped = C.c_uint32()
         n = self.L.orc_render_prep_streaming(self.w, self.cull, max_draws, buf, cap, C.byref(dropped))
+        self._last_draws = (buf, n)
         ent = np.array([buf[i].entity for i in range(n)], np.uint32)
         mesh = np.array([buf[i].meshId for i in range(n)], np.uint32)
         mat = np.array([buf[i].materialId for i in range(n)], np.uint32)
         model = np.array([buf[i].model[:] for i in range(n)], np.float32).reshape(n, 16)
         return ent, mesh, mat, model, int(dropped.value)
+
+    def renderer_draw_order(self, pipeline_of_material, mesh_count):
+        """Indices into the last draw_items() list in the renderer's bind order (sc_vk.cpp:1842-1864), stable."""
+        buf, n = self._last_draws
+        pipe = np.ascontiguousarray(pipeline_of_material, np.uint8)
+        order = np.zeros(max(n, 1), np.uint32)
+        kept = self.L.orc_renderer_draw_order(buf, n, pipe.ctypes.data_as(U8P), len(pipe), mesh_count, _u(order))
+        return order[:kept].copy()

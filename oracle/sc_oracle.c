@@ -793,6 +793,34 @@ uint32_t orc_render_prep_streaming(OrcWorld* w, const OrcCullingState* s, uint32
   return emitted;
 }
 
+/* The renderer's draw order, src/engine/src/sc_vk.cpp:1842-1864: draws with meshId >= meshCount or without a
+ * Material are skipped (:1846-1851), the rest ordered by (pipelineId of the material, materialId, meshId) (:1854-1864).
+ * pipelineOfMaterial[h] = 0xFF means getMaterial(h) == nullptr.  std::sort does not define the order of equal
+ * keys; this restatement uses a stable insertion order (equal keys keep RenderFrameData::draws order), one of the
+ * orders the reference can produce.  Writes indices into `items`; returns how many draws are left. */
+static int draw_before(const OrcDrawItem* a, const OrcDrawItem* b, const uint8_t* pipe)
+{
+  const uint32_t pa = pipe[a->materialId], pb = pipe[b->materialId];
+  if (pa != pb) return pa < pb;
+  if (a->materialId != b->materialId) return a->materialId < b->materialId;
+  return a->meshId < b->meshId;
+}
+uint32_t orc_renderer_draw_order(const OrcDrawItem* items, uint32_t n, const uint8_t* pipelineOfMaterial,
+                                 uint32_t materialCount, uint32_t meshCount, uint32_t* order)
+{
+  uint32_t kept = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (items[i].meshId >= meshCount) continue;
+    if (items[i].materialId >= materialCount || pipelineOfMaterial[items[i].materialId] == 0xFF) continue;
+    /* stable insertion from the back: stop at the first element that is not after the new one */
+    uint32_t at = kept;
+    while (at > 0 && draw_before(&items[i], &items[order[at - 1]], pipelineOfMaterial)) { order[at] = order[at - 1]; --at; }
+    order[at] = i;
+    ++kept;
+  }
+  return kept;
+}
+
 /* sc_world_partition.cpp:268-275 */
 void orc_world_to_sector(float sectorSize, float x, float z, int32_t* sx, int32_t* sz)
 {

@@ -145,6 +145,11 @@ void orc_culling_system(OrcWorld* w, OrcCullingState* s, const float viewProj[16
 uint32_t orc_render_prep_streaming(OrcWorld* w, const OrcCullingState* s, uint32_t maxDraws,
                                    OrcDrawItem* out, uint32_t outCap, uint32_t* dropped);
 
+/* the renderer's filter + sort of RenderFrameData::draws (src/engine/src/sc_vk.cpp:1842-1864), stable; UNPINNED like
+ * the other systems (sc_vk.cpp needs Vulkan); order[] receives indices into items, returns the number kept */
+uint32_t orc_renderer_draw_order(const OrcDrawItem* items, uint32_t n, const uint8_t* pipelineOfMaterial,
+                                 uint32_t materialCount, uint32_t meshCount, uint32_t* order);
+
 /* ---- sector binning: sc_world_partition.cpp:268-275 ---- */
 void orc_world_to_sector(float sectorSize, float x, float z, int32_t* sx, int32_t* sz);
 

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsc_tick.so")
 
 # scTickRun flags (include/sc_tick.h)
-XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS, DENSE_AABBS, SPLIT_PAIRS = 1, 2, 4, 8, 16, 32, 64
+XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS, DENSE_AABBS, SPLIT_PAIRS, SORT_DRAWS = 1, 2, 4, 8, 16, 32, 64, 128
 FULL = XFORM | CULL | BROADPHASE
 K_XFORM_CULL, K_COMPACT, K_PAIRS, K_NUDGE, K_COUNT = 0, 1, 2, 3, 4
 NO_PARENT = -1
@@ -34,7 +34,7 @@ class ContextDesc(C.Structure):
 class Counts(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "entities", "renderables_total", "visible", "culled", "pairs", "pairs_truncated",
-        "draws_emitted", "draws_dropped", "max_depth", "unreachable", "bin_overflow", "big_boxes")]
+        "draws_emitted", "draws_dropped", "max_depth", "unreachable", "bin_overflow", "big_boxes", "draws_sorted")]
 
 
 class DrawItem(C.Structure):
@@ -74,6 +74,7 @@ SYMBOLS = {
     "scTickUploadWorldMatrices": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
     "scTickSetDirtyFlags": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P]),
     "scTickSetDrawBudget": (C.c_int, [_CTX, C.c_uint32]),
+    "scTickSetDrawSortTable": (C.c_int, [_CTX, U8P, C.c_uint32, C.c_uint32]),
     "scTickSetTile": (C.c_int, [_CTX, C.c_uint32, C.c_uint32]),
     "scTickBorderBytes": (C.c_uint32, [_CTX, C.c_uint32]),
     "scTickBindBorderBuffers": (C.c_int, [_CTX, C.c_uint32, C.c_void_p, C.c_void_p]),

@@ -58,6 +58,8 @@ struct ScTickContext
   // scratch device buffers for indexed read-back
   uint32_t* dIdx = nullptr; float* dRows = nullptr; uint32_t scratchCap = 0;
   void* dDraws = nullptr;
+  DrawSortState sort{};                // renderer draw order (scTickSetDrawSortTable); key/idx buffers allocated on first use
+  uint8_t* dPipeline = nullptr; uint32_t pipelineCap = 0;
 
   // profiling
   bool profiling = false;
@@ -116,6 +118,29 @@ bool dalloc(ScTickContext* c, T*& p, size_t count, bool zero = true)
   if (zero) { e = hipMemset(v, 0, bytes); if (e != hipSuccess) return fail(c, "hipMemset", e); }
   c->allocs.push_back(v);
   p = static_cast<T*>(v);
+  return true;
+}
+
+bool sync(ScTickContext* c);
+
+void dfree(ScTickContext* c, void* p)
+{
+  if (!p) return;
+  auto it = std::find(c->allocs.begin(), c->allocs.end(), p);
+  if (it != c->allocs.end()) c->allocs.erase(it);
+  hipFree(p);
+}
+
+// scratch index / row buffers for indexed calls: grown geometrically, the old pair is released
+bool needScratch(ScTickContext* c, size_t count)
+{
+  if (c->scratchCap >= count) return true;
+  if (!sync(c)) return false;                         // nothing queued may still read the old buffers
+  const size_t want = std::max(count, (size_t)c->scratchCap * 2u);
+  dfree(c, c->dIdx); dfree(c, c->dRows);
+  c->dIdx = nullptr; c->dRows = nullptr; c->scratchCap = 0;
+  if (!dalloc(c, c->dIdx, want, false) || !dalloc(c, c->dRows, want * 12, false)) return false;
+  c->scratchCap = (uint32_t)want;
   return true;
 }
 
@@ -245,6 +270,8 @@ int flushLinks(ScTickContext* c)
   for (auto& lv : deep) { flat.insert(flat.end(), lv.begin(), lv.end()); c->levelOffsets.push_back((uint32_t)flat.size()); }
   if (!flat.empty()) {
     if (flat.size() > c->levelListCap) {
+      if (!sync(c)) return 0;
+      dfree(c, c->dLevelList); c->dLevelList = nullptr; c->levelListCap = 0;
       uint32_t* p = nullptr;
       if (!dalloc(c, p, flat.size(), false)) return 0;
       c->dLevelList = p; c->levelListCap = (uint32_t)flat.size();
@@ -254,10 +281,7 @@ int flushLinks(ScTickContext* c)
   uint32_t* dDet = nullptr;
   if (!detached.empty()) {
     // detached entities become dirty roots (sc_ecs.cpp:154-160)
-    if (c->scratchCap < detached.size()) {
-      if (!dalloc(c, c->dIdx, detached.size(), false) || !dalloc(c, c->dRows, detached.size() * 12, false)) return 0;
-      c->scratchCap = (uint32_t)detached.size();
-    }
+    if (!needScratch(c, detached.size())) return 0;
     dDet = c->dIdx;
     if (!h2d(c, dDet, detached.data(), detached.size() * 4u)) return 0;
     launchSetDirtyIndices(c->d, dDet, (uint32_t)detached.size(), c->stream);
@@ -350,7 +374,11 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
       else { Scoped s(c, SC_TICK_K_PAIRS); launchPairs(c->d, p, c->stream); }
     }
   }
-  if (flags & SC_TICK_DRAWS) launchEmitDraws(c->d, c->desc.max_draws_budget, c->dDraws, c->stream);
+  if (flags & SC_TICK_DRAWS) {
+    const uint32_t budget = c->desc.max_draws_budget;
+    if (flags & SC_TICK_SORT_DRAWS) launchSortedDraws(c->d, c->sort, budget, (budget && budget < c->n) ? budget : c->n, c->dDraws, c->stream);
+    else launchEmitDraws(c->d, budget, c->dDraws, c->stream);
+  }
   c->profiling = saved;
 }
 
@@ -676,10 +704,7 @@ int scTickRemoveEntities(ScTickContext* c, const uint32_t* idx, uint32_t count, 
 
   // device: relocate every per-entity array
   if (moves) {
-    if (c->scratchCap < 2u * moves) {
-      if (!dalloc(c, c->dIdx, 2u * (size_t)moves, false) || !dalloc(c, c->dRows, 2u * (size_t)moves * 12, false)) return 0;
-      c->scratchCap = 2u * moves;
-    }
+    if (!needScratch(c, 2u * (size_t)moves)) return 0;
     if (!h2d(c, c->dIdx, src.data(), (size_t)moves * 4u) || !h2d(c, c->dIdx + moves, dst.data(), (size_t)moves * 4u)) return 0;
     launchMoveEntities(c->d, c->dIdx, c->dIdx + moves, moves, c->stream);
   }
@@ -726,10 +751,7 @@ int scTickMarkDirtyIndices(ScTickContext* c, const uint32_t* idx, uint32_t count
   if (!bind(c)) return 0;
   if (!count) return 1;
   for (uint32_t i = 0; i < count; ++i) if (idx[i] >= c->n) return fail(c, "dense index out of range");
-  if (c->scratchCap < count) {
-    if (!dalloc(c, c->dIdx, count, false) || !dalloc(c, c->dRows, (size_t)count * 12, false)) return 0;
-    c->scratchCap = count;
-  }
+  if (!needScratch(c, count)) return 0;
   if (!h2d(c, c->dIdx, idx, (size_t)count * 4u)) return 0;
   launchSetDirtyIndices(c->d, c->dIdx, count, c->stream);
   return sync(c) ? 1 : 0;
@@ -751,6 +773,41 @@ int scTickSetDirtyFlags(ScTickContext* c, uint32_t first, uint32_t count, const 
   }
   if (!h2d(c, c->d.dirty + w0, words.data(), words.size() * 4u)) return 0;
   return sync(c) ? 1 : 0;
+}
+
+int scTickSetDrawSortTable(ScTickContext* c, const uint8_t* pipelineOfMaterial, uint32_t materialCount, uint32_t meshCount)
+{
+  if (!c) return 0;
+  if (!pipelineOfMaterial && materialCount) return fail(c, "null argument");
+  if (materialCount > (1u << 24) || meshCount > (1u << 24)) return fail(c, "more than 2^24 material or mesh handles");
+  for (uint32_t i = 0; i < materialCount; ++i)
+    if (pipelineOfMaterial[i] >= 128u && pipelineOfMaterial[i] != kNoMaterial) return fail(c, "pipeline ids must be < 128 (0xFF = no such material)");
+  if (!bind(c) || !sync(c)) return 0;
+  DrawSortState& st = c->sort;
+  if (!st.key[0]) {
+    const size_t N = c->cap;
+    const size_t groups = (N + kSortGroup - 1) / kSortGroup;
+    if (!dalloc(c, st.key[0], N, false) || !dalloc(c, st.key[1], N, false) || !dalloc(c, st.idx[0], N, false) ||
+        !dalloc(c, st.idx[1], N, false) || !dalloc(c, st.hist, 256u * groups, false)) return 0;
+  }
+  if (c->pipelineCap < std::max(materialCount, 1u)) {
+    dfree(c, c->dPipeline); c->dPipeline = nullptr; c->pipelineCap = 0;
+    const uint32_t want = std::max(materialCount, 64u);
+    if (!dalloc(c, c->dPipeline, want, false)) return 0;
+    c->pipelineCap = want;
+  }
+  if (materialCount && (!h2d(c, c->dPipeline, pipelineOfMaterial, materialCount) || !sync(c))) return 0;
+  st.pipeline = c->dPipeline;
+  st.materialCount = materialCount; st.meshCount = meshCount;
+  // key = pipeline << 48 | material << 24 | mesh: sort only over the bytes the handle ranges can reach,
+  // and always over the top byte (pipeline + the "dropped" mark)
+  auto bytesOf = [](uint32_t count) { uint32_t top = count > 1u ? count - 1u : 0u, b = 0; while (top) { ++b; top >>= 8; } return b; };
+  st.passes = 0;
+  for (uint32_t b = 0; b < bytesOf(meshCount); ++b) st.shift[st.passes++] = 8u * b;
+  for (uint32_t b = 0; b < bytesOf(materialCount); ++b) st.shift[st.passes++] = 24u + 8u * b;
+  st.shift[st.passes++] = 48u;
+  c->topoEpoch++;                      // captured graphs hold the old pass list
+  return 1;
 }
 
 int scTickSetDrawBudget(ScTickContext* c, uint32_t maxDraws)
@@ -829,8 +886,13 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   if (!c) return 0;
   if (!bind(c)) return 0;
   if (!flushLinks(c)) return 0;
-  if (c->n == 0) { c->lastFlags = flags; return 1; }
+  if (c->n == 0) {                    // nothing to launch: the per-tick counts read as zero
+    c->lastFlags = flags;
+    HIP_OK(c, hipMemsetAsync(c->d.counters, 0, 8 * sizeof(uint32_t), c->stream));
+    return 1;
+  }
   if ((flags & SC_TICK_BROADPHASE) && c->desc.tile_sectors_x == 0) return fail(c, "broadphase requested but the context has no tile rectangle");
+  if ((flags & SC_TICK_SORT_DRAWS) && !c->sort.pipeline) return fail(c, "SC_TICK_SORT_DRAWS needs scTickSetDrawSortTable first");
   TickParams p; uint32_t grid;
   fillParams(c, flags, p, grid);
   c->lastFlags = flags;
@@ -1010,6 +1072,7 @@ int scTickGetCounts(ScTickContext* c, ScTickCounts* out)
   out->big_boxes = bp[kCtrBig];
   out->draws_emitted = k[4];
   out->draws_dropped = k[5];
+  out->draws_sorted = (c->lastFlags & SC_TICK_SORT_DRAWS) ? k[kCtrDrawsSorted] : 0u;
   out->max_depth = c->maxDepth;
   out->unreachable = c->unreachable;
   return 1;
@@ -1072,10 +1135,7 @@ int scTickReadWorldMatricesIndexed(ScTickContext* c, const uint32_t* idx, uint32
   if (!bind(c)) return 0;
   if (!count) return 1;
   for (uint32_t i = 0; i < count; ++i) if (idx[i] >= c->n) return fail(c, "dense index out of range");
-  if (c->scratchCap < count) {
-    if (!dalloc(c, c->dIdx, count, false) || !dalloc(c, c->dRows, (size_t)count * 12, false)) return 0;
-    c->scratchCap = count;
-  }
+  if (!needScratch(c, count)) return 0;
   if (!h2d(c, c->dIdx, idx, (size_t)count * 4u)) return 0;
   launchGatherRows(c->d, c->dIdx, count, c->dRows, c->stream);
   std::vector<float> rows((size_t)count * 12);
@@ -1154,8 +1214,9 @@ int scTickReadDraws(ScTickContext* c, ScTickDrawItem* items, uint32_t cap, uint3
   if (!(c->lastFlags & SC_TICK_DRAWS)) return fail(c, "the last scTickRun did not request SC_TICK_DRAWS");
   uint32_t k[16] = {};
   if (!d2h(c, k, c->d.counters, sizeof k) || !sync(c)) return 0;
-  *count = k[4];
-  const uint32_t take = std::min(k[4], cap);
+  const uint32_t have = (c->lastFlags & SC_TICK_SORT_DRAWS) ? k[kCtrDrawsSorted] : k[4];
+  *count = have;
+  const uint32_t take = std::min(have, cap);
   if (take && items) { if (!d2h(c, items, c->dDraws, (size_t)take * sizeof(ScTickDrawItem)) || !sync(c)) return 0; }
   return 1;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 namespace sctick {
 
@@ -122,6 +123,20 @@ __host__ __device__ inline bool hasNb(const TickParams& p, int dx, int dz) { ret
 __host__ __device__ inline uint32_t borderWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { const uint32_t L = borderLen(d, coreSX, coreSZ); return kBorderHeader + L + L * kBorderRecsPerBin * 8u; }
 constexpr uint32_t kFlagHasDeep = 1u << 16;   // write recomp bits for the level kernels
 constexpr uint32_t kFlagDenseAabbs = 1u << 5; // == SC_TICK_DENSE_AABBS
+
+// ---- renderer draw order (sc_tick_drawsort.hip) ----
+constexpr uint32_t kSortThreads = 1024, kSortGroup = 8192;     // keys one workgroup orders per pass
+constexpr uint64_t kDrawInvalid = 1ull << 55;                  // above every pipeline id (< 128): dropped draws sort last
+constexpr uint32_t kNoMaterial = 0xFFu;                        // pipeline table entry of a material handle that does not exist
+constexpr uint32_t kCtrDrawsSorted = 7;                        // counters[7]: draws that survived the renderer's handle checks
+struct DrawSortState {
+  uint64_t* key[2]; uint32_t* idx[2];     // ping-pong (key, rank in the visible list)
+  uint32_t* hist;                         // [256][groups] digit totals for multi-workgroup passes
+  const uint8_t* pipeline;                // Material::pipelineId per material handle, kNoMaterial = none
+  uint32_t materialCount, meshCount;
+  uint32_t passes; uint32_t shift[7];     // key bytes that can differ, least significant first
+};
+void launchSortedDraws(const DeviceState& d, const DrawSortState& st, uint32_t budget, uint32_t bound, void* items, hipStream_t s);
 
 // launchers (sc_tick_kernels.hip)
 void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);

@@ -200,6 +200,12 @@ class WorldTick:
     def nudge_roots_x(self, dx):
         self._ok(self.lib.scTickNudgeRootsX(self.ctx, float(dx)), "scTickNudgeRootsX")
 
+    def set_draw_sort_table(self, pipeline_of_material, mesh_count):
+        """Material::pipelineId per material handle (0xFF = no such material) and the number of mesh handles:
+        what the renderer's filter + sort of the draw list reads (sc_vk.cpp:1842-1864)."""
+        p = np.ascontiguousarray(pipeline_of_material, np.uint8)
+        self._ok(self.lib.scTickSetDrawSortTable(self.ctx, p.ctypes.data_as(capi.U8P), len(p), int(mesh_count)), "scTickSetDrawSortTable")
+
     # ---- sector residency (WorldPartition::pumpCompletedLoads / pumpUnloadQueue) ----
     def append_entities(self, pos, rot, scale, bmin=None, bmax=None, mesh=None, material=None, group=None, mask=None, parent=None):
         """Create len(pos) entities at the end of the dense order; returns the first one's dense index."""

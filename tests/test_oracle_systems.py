@@ -193,3 +193,21 @@ def test_job_pool_gives_same_mask(oracle, workers):
     ow.tick()
     assert np.array_equal(got, ow.visible())
     ow.close()
+
+
+def test_renderer_draw_order_is_the_stable_sort_of_the_kept_draws(oracle):
+    """orc_renderer_draw_order (sc_vk.cpp:1842-1864) against Python's stable sort over the same comparator keys."""
+    w = worlds.random_world(1500, seed=77, spread=60.0)
+    rng = np.random.default_rng(5)
+    w.mesh = rng.integers(0, 9, w.n).astype(np.uint32)
+    w.material = rng.integers(0, 12, w.n).astype(np.uint32)
+    ow = worlds.oracle_world(oracle, w, camera=True)
+    ow.tick()
+    ent, mesh, mat, model, _ = ow.draw_items()
+    assert len(ent) > 100
+    pipeline = np.array([1, 0, 0xFF, 1, 0, 0, 1, 0xFF, 0, 1, 1, 0], np.uint8)
+    order = ow.renderer_draw_order(pipeline, mesh_count=7)
+    kept = [i for i in range(len(ent)) if mesh[i] < 7 and pipeline[mat[i]] != 0xFF]
+    want = sorted(kept, key=lambda i: (int(pipeline[mat[i]]), int(mat[i]), int(mesh[i])))      # sorted() is stable
+    assert order.tolist() == want
+    ow.close()
