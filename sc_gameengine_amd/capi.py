@@ -34,7 +34,7 @@ class ContextDesc(C.Structure):
 class Counts(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "entities", "renderables_total", "visible", "culled", "pairs", "pairs_truncated",
-        "draws_emitted", "draws_dropped", "max_depth", "unreachable", "bin_overflow", "big_boxes", "draws_sorted")]
+        "draws_emitted", "draws_dropped", "max_depth", "unreachable", "bin_overflow", "big_boxes", "draws_sorted", "border_lost", "relinks")]
 
 
 class DrawItem(C.Structure):
@@ -76,6 +76,7 @@ SYMBOLS = {
     "scTickSetDrawBudget": (C.c_int, [_CTX, C.c_uint32]),
     "scTickSetDrawSortTable": (C.c_int, [_CTX, U8P, C.c_uint32, C.c_uint32]),
     "scTickSetTile": (C.c_int, [_CTX, C.c_uint32, C.c_uint32]),
+    "scTickSetTileGrid": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "scTickBorderBytes": (C.c_uint32, [_CTX, C.c_uint32]),
     "scTickBindBorderBuffers": (C.c_int, [_CTX, C.c_uint32, C.c_void_p, C.c_void_p]),
     "scTickRunPairs": (C.c_int, [_CTX]),

@@ -40,9 +40,12 @@ struct ScTickContext
   // host mirrors needed to (re)build link words
   std::vector<int32_t> hParent;
   std::vector<uint8_t> hFlags;       // bit0 has mesh, bit1 has bounds, bits 2..4 rotation about X/Y/Z trivial (sin 0, cos 1)
-  std::vector<uint32_t> hChildren;   // direct children per entity (valid while !linksStale): decides whether a despawn can skip re-linking
+  std::vector<uint32_t> hChildren;   // direct children per entity (valid while !linksStale)
+  // child lists in dense-index space (-1 = none), valid while !linksStale: a despawn patches exactly the links that
+  // name a relocated entity instead of re-linking the world
+  std::vector<int32_t> hFirstChild, hNextSib, hPrevSib;
   bool linksStale = true;
-  uint32_t maxDepth = 0, unreachable = 0;
+  uint32_t maxDepth = 0, unreachable = 0, relinks = 0;
   std::vector<uint32_t> levelOffsets;   // offsets into dLevelList for depth kMaxChain+1, +2, ...
   uint32_t* dLevelList = nullptr;
   uint32_t levelListCap = 0;
@@ -82,6 +85,7 @@ struct ScTickContext
   uint32_t parity = 0, lastParity = 0;
   uint32_t prevBroadphaseN = 0;        // entity count of the previous broadphase tick: bounds the bigBits words it may have set
   uint32_t rank = 0, neighbourMask = 0;
+  uint32_t tileX = 0, tileZ = 0, tilesX = 0, tilesZ = 0;
   uint32_t producerKind = 0; float producerParam = 0.0f;      // part of the frame when set (scTickSetFrameProducer)
   bool pairsPending = false;
   TickParams pendingParams{};
@@ -208,7 +212,17 @@ void rebuildLinks(ScTickContext* c, std::vector<uint32_t>& link, std::vector<uin
   }
 
   std::fill(c->hChildren.begin(), c->hChildren.begin() + n, 0u);
-  for (uint32_t i = 0; i < n; ++i) if (par[i] != SC_TICK_NO_PARENT) c->hChildren[(uint32_t)par[i]]++;
+  std::fill(c->hFirstChild.begin(), c->hFirstChild.begin() + n, -1);
+  for (uint32_t i = n; i-- > 0;) {               // backwards, pushing at the front: lists come out in ascending order
+    c->hNextSib[i] = -1; c->hPrevSib[i] = -1;
+    if (par[i] == SC_TICK_NO_PARENT) continue;
+    const uint32_t q = (uint32_t)par[i];
+    c->hChildren[q]++;
+    const int32_t head = c->hFirstChild[q];
+    c->hNextSib[i] = head;
+    if (head >= 0) c->hPrevSib[(uint32_t)head] = (int32_t)i;
+    c->hFirstChild[q] = (int32_t)i;
+  }
 
   // depth by walking up with memoisation; a walk that meets its own trail has found a cycle
   constexpr int32_t kUnknown = -1, kCycle = -2;
@@ -289,6 +303,7 @@ int flushLinks(ScTickContext* c)
   if (!sync(c)) return 0;
   c->linksStale = false;
   c->topoEpoch++;
+  c->relinks++;
   return 1;
 }
 
@@ -334,6 +349,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.variant = c->variant;
   p.chain = std::min(c->maxDepth, kMaxChain);
   p.bigClearWords = (c->prevBroadphaseN + 31u) >> 5;
+  p.tileX = c->tileX; p.tileZ = c->tileZ; p.tilesX = c->tilesX; p.tilesZ = c->tilesZ;
 }
 
 void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool allowProfile)
@@ -453,7 +469,8 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
   if (ok && c->sectors) {
     if ((uint64_t)desc->tile_sectors_x * desc->tile_sectors_z > (1u << 24)) ok = fail(c, "tile rectangle too large");
     ok = ok && dalloc(c, d.binCount, c->sectors) && dalloc(c, d.binLayers, c->sectors) && dalloc(c, d.bins, (size_t)c->sectors * kBinCap * 2u, false)
-            && dalloc(c, d.bigList, N * 2u, false) && dalloc(c, d.bigBits[0], N / 32) && dalloc(c, d.bigBits[1], N / 32)
+            && dalloc(c, d.bigList, (N + 8u * kBorderBigCap) * 2u, false) && dalloc(c, d.spill, 2u * kSpillCap, false) && dalloc(c, d.spillSector, kSpillCap)
+            && dalloc(c, d.bigBits[0], N / 32) && dalloc(c, d.bigBits[1], N / 32)
             && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, 2u * kPairShards * kShardStride)
             && dalloc(c, c->dPairsOut, c->maxPairs, false) && dalloc(c, c->dPairTotal, 4);
   }
@@ -470,6 +487,7 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
   c->hParent.assign(desc->capacity, SC_TICK_NO_PARENT);
   c->hFlags.assign(desc->capacity, 0);
   c->hChildren.assign(desc->capacity, 0);
+  c->hFirstChild.assign(desc->capacity, -1); c->hNextSib.assign(desc->capacity, -1); c->hPrevSib.assign(desc->capacity, -1);
   return c;
 }
 
@@ -619,7 +637,10 @@ int scTickAppendEntities(ScTickContext* c, uint32_t count, const float* pos3, co
 
   const bool wasStale = c->linksStale;
   c->n = first + count;
-  for (uint32_t i = first; i < first + count; ++i) { c->hFlags[i] = 0; c->hParent[i] = SC_TICK_NO_PARENT; c->hChildren[i] = 0; }
+  for (uint32_t i = first; i < first + count; ++i) {
+    c->hFlags[i] = 0; c->hParent[i] = SC_TICK_NO_PARENT; c->hChildren[i] = 0;
+    c->hFirstChild[i] = -1; c->hNextSib[i] = -1; c->hPrevSib[i] = -1;
+  }
 
   std::vector<float> cube;
   if (!bmin3) { cube.assign((size_t)count * 6, 0.5f); for (size_t i = 0; i < (size_t)count * 3; ++i) cube[i] = -0.5f; }   // kUnitCubeBounds
@@ -694,38 +715,79 @@ int scTickRemoveEntities(ScTickContext* c, const uint32_t* idx, uint32_t count, 
   }
   const uint32_t moves = (uint32_t)src.size();
 
-  // Can the hierarchy be left alone?  Only if nothing that goes away or moves is anybody's parent, and no
-  // index lives in a level list or a cycle.
+  std::unordered_map<uint32_t, uint32_t> newIndexOf;
+  newIndexOf.reserve(moves * 2u);
+  for (uint32_t k = 0; k < moves; ++k) newIndexOf[src[k]] = dst[k];
+  auto remap = [&](int32_t i) -> int32_t {          // index before the call -> index after it (sources are >= n1, targets < n1)
+    if (i < 0) return i;
+    const auto m = newIndexOf.find((uint32_t)i);
+    return m == newIndexOf.end() ? i : (int32_t)m->second;
+  };
+
+  // The hierarchy is patched in place unless an index sits in a level list or a cycle, or a removed entity
+  // leaves a child behind (orphans change the depth of whole subtrees: full re-link, sc_ecs.cpp:151-160).
   bool relink = c->linksStale || c->unreachable > 0 || c->maxDepth > kMaxChain;
-  if (!relink) {
-    for (uint32_t k = 0; k < count && !relink; ++k) relink = c->hChildren[idx[k]] != 0;
-    for (uint32_t k = 0; k < moves && !relink; ++k) relink = c->hChildren[src[k]] != 0;
-  }
+  for (uint32_t k = 0; k < count && !relink; ++k)
+    for (int32_t ch = c->hFirstChild[idx[k]]; ch >= 0 && !relink; ch = c->hNextSib[(uint32_t)ch]) relink = !removed.count((uint32_t)ch);
 
   // device: relocate every per-entity array
   if (moves) {
     if (!needScratch(c, 2u * (size_t)moves)) return 0;
     if (!h2d(c, c->dIdx, src.data(), (size_t)moves * 4u) || !h2d(c, c->dIdx + moves, dst.data(), (size_t)moves * 4u)) return 0;
     launchMoveEntities(c->d, c->dIdx, c->dIdx + moves, moves, c->stream);
+    if (!sync(c)) return 0;                          // the scratch buffer is reused for the parent patches below
   }
 
-  // host mirrors
+  std::vector<uint32_t> patch;                       // (entity, new parent) pairs for the device link words
   if (!relink) {
-    for (uint32_t k = 0; k < count; ++k) { const int32_t p = c->hParent[idx[k]]; if (p != SC_TICK_NO_PARENT) c->hChildren[(uint32_t)p]--; }
-    for (uint32_t k = 0; k < moves; ++k) { c->hParent[dst[k]] = c->hParent[src[k]]; c->hFlags[dst[k]] = c->hFlags[src[k]]; c->hChildren[dst[k]] = 0; }
+    std::vector<int32_t>&par = c->hParent, &fc = c->hFirstChild, &ns = c->hNextSib, &ps = c->hPrevSib;
+    // 1. unlink the removed entities from surviving parents (indices as before the call)
+    for (uint32_t k = 0; k < count; ++k) {
+      const uint32_t r = idx[k];
+      const int32_t q = par[r];
+      if (q < 0 || removed.count((uint32_t)q)) continue;
+      if (ps[r] >= 0) ns[(uint32_t)ps[r]] = ns[r]; else fc[(uint32_t)q] = ns[r];
+      if (ns[r] >= 0) ps[(uint32_t)ns[r]] = ps[r];
+      c->hChildren[(uint32_t)q]--;
+    }
+    // 2. gather every write a relocation needs, reading only the records as they stand (sources are never written)
+    struct Set { std::vector<int32_t>* arr; uint32_t at; int32_t value; };
+    std::vector<Set> sets;
+    for (uint32_t k = 0; k < moves; ++k) {
+      const uint32_t s0 = src[k], d0 = dst[k];
+      sets.push_back({ &par, d0, remap(par[s0]) });
+      sets.push_back({ &fc, d0, remap(fc[s0]) });
+      sets.push_back({ &ns, d0, remap(ns[s0]) });
+      sets.push_back({ &ps, d0, remap(ps[s0]) });
+      if (ps[s0] >= 0) sets.push_back({ &ns, (uint32_t)remap(ps[s0]), (int32_t)d0 });
+      else if (par[s0] >= 0) sets.push_back({ &fc, (uint32_t)remap(par[s0]), (int32_t)d0 });
+      if (ns[s0] >= 0) sets.push_back({ &ps, (uint32_t)remap(ns[s0]), (int32_t)d0 });
+      for (int32_t ch = fc[s0]; ch >= 0; ch = ns[(uint32_t)ch]) {
+        const uint32_t at = (uint32_t)remap(ch);
+        sets.push_back({ &par, at, (int32_t)d0 });
+        patch.push_back(at); patch.push_back(d0);
+      }
+      c->hFlags[d0] = c->hFlags[s0];
+      c->hChildren[d0] = c->hChildren[s0];
+    }
+    // 3. apply (writes that meet on one field carry the same value)
+    for (const Set& w : sets) (*w.arr)[w.at] = w.value;
+    if (!patch.empty()) {
+      const uint32_t pairs = (uint32_t)(patch.size() / 2);
+      if (!needScratch(c, patch.size())) return 0;
+      if (!h2d(c, c->dIdx, patch.data(), patch.size() * 4u)) return 0;
+      launchPatchParents(c->d, c->dIdx, pairs, c->stream);
+    }
   } else {
     // parents are rewritten through the relocation map; a child of a removed entity gets an invalid parent,
     // which the re-link detaches and marks dirty (sc_ecs.cpp:151-160)
-    std::unordered_map<uint32_t, uint32_t> movedTo;
-    movedTo.reserve(moves * 2u);
-    for (uint32_t k = 0; k < moves; ++k) movedTo[src[k]] = dst[k];
     for (uint32_t k = 0; k < moves; ++k) { c->hParent[dst[k]] = c->hParent[src[k]]; c->hFlags[dst[k]] = c->hFlags[src[k]]; }
     constexpr int32_t kGone = -2;
     for (uint32_t i = 0; i < n1; ++i) {
-      const int32_t p = c->hParent[i];
-      if (p == SC_TICK_NO_PARENT) continue;
-      if (removed.count((uint32_t)p)) c->hParent[i] = kGone;
-      else { const auto m = movedTo.find((uint32_t)p); if (m != movedTo.end()) c->hParent[i] = (int32_t)m->second; }
+      const int32_t q = c->hParent[i];
+      if (q == SC_TICK_NO_PARENT) continue;
+      if (removed.count((uint32_t)q)) c->hParent[i] = kGone;
+      else c->hParent[i] = remap(q);
     }
     c->linksStale = true;
   }
@@ -950,6 +1012,21 @@ int scTickSetTile(ScTickContext* c, uint32_t rank, uint32_t neighbourMask)
   return 1;
 }
 
+int scTickSetTileGrid(ScTickContext* c, uint32_t tileX, uint32_t tileZ, uint32_t tilesX, uint32_t tilesZ)
+{
+  if (!c) return 0;
+  if (tilesX == 0 || tilesZ == 0 || tileX >= tilesX || tileZ >= tilesZ || (uint64_t)tilesX * tilesZ > 128u) return fail(c, "tile grid: need tile < tiles and at most 128 tiles");
+  c->tileX = tileX; c->tileZ = tileZ; c->tilesX = tilesX; c->tilesZ = tilesZ;
+  uint32_t mask = 0;
+  for (uint32_t d = 0; d < 8; ++d) {
+    int dx, dz; borderDir(d, dx, dz);
+    const int x = (int)tileX + dx, z = (int)tileZ + dz;
+    if (x >= 0 && z >= 0 && x < (int)tilesX && z < (int)tilesZ) mask |= 1u << d;
+  }
+  c->neighbourMask = mask;
+  return 1;
+}
+
 uint32_t scTickBorderBytes(ScTickContext* c, uint32_t dir)
 {
   if (!c || dir > 7u || !c->desc.tile_sectors_x) return 0;
@@ -1069,12 +1146,14 @@ int scTickGetCounts(ScTickContext* c, ScTickCounts* out)
     out->pairs_truncated = tot[1];
   }
   out->bin_overflow = bp[kCtrBinFull];
-  out->big_boxes = bp[kCtrBig];
+  out->big_boxes = (c->lastFlags & SC_TICK_SPLIT_PAIRS) ? bp[kCtrBigLocal] : bp[kCtrBig];
+  out->border_lost = bp[kCtrBorderLost];
   out->draws_emitted = k[4];
   out->draws_dropped = k[5];
   out->draws_sorted = (c->lastFlags & SC_TICK_SORT_DRAWS) ? k[kCtrDrawsSorted] : 0u;
   out->max_depth = c->maxDepth;
   out->unreachable = c->unreachable;
+  out->relinks = c->relinks;
   return 1;
 }
 

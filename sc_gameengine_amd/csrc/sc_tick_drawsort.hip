@@ -65,6 +65,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const PassArgs a)
   __shared__ uint32_t tot[kDigits];
   const uint32_t n = a.counters[4];
   const uint32_t base = blockIdx.x * kSortGroup;
+  if (base >= n) return;                         // the scan only visits groups that hold keys
   if (threadIdx.x < kDigits) tot[threadIdx.x] = 0u;
   __syncthreads();
   for (uint32_t r = 0; r < kSortGroup / kSortThreads; ++r) {
@@ -75,14 +76,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const PassArgs a)
   if (threadIdx.x < kDigits) a.hist[threadIdx.x * a.groups + blockIdx.x] = tot[threadIdx.x];
 }
 
-// exclusive scan of hist[0 .. 256*groups) in place, one workgroup
-__global__ __launch_bounds__(kSortThreads) void k_radix_scan(uint32_t* hist, uint32_t entries)
+// exclusive scan, in place and in [digit][group] order, over the groups that hold keys this tick (one workgroup)
+__global__ __launch_bounds__(kSortThreads) void k_radix_scan(uint32_t* hist, const uint32_t* counters, uint32_t groups)
 {
   __shared__ uint32_t part[kSortThreads];
+  const uint32_t n = counters[4];
+  const uint32_t active = min((n + kSortGroup - 1) / kSortGroup, groups);
+  const uint32_t entries = kDigits * active;
   const uint32_t per = (entries + kSortThreads - 1) / kSortThreads;
-  const uint32_t b = threadIdx.x * per, e = min(b + per, entries);
+  const uint32_t b = min(threadIdx.x * per, entries), e = min(b + per, entries);
+  auto at = [&](uint32_t i) -> uint32_t& { return hist[(i / active) * groups + (i % active)]; };
   uint32_t sum = 0;
-  for (uint32_t i = b; i < e; ++i) sum += hist[i];
+  for (uint32_t i = b; i < e; ++i) sum += at(i);
   part[threadIdx.x] = sum;
   __syncthreads();
   for (uint32_t step = 1; step < kSortThreads; step <<= 1) {        // Hillis-Steele over the 1024 partial sums
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scan(uint32_t* hist, uin
     __syncthreads();
   }
   uint32_t run = part[threadIdx.x] - sum;
-  for (uint32_t i = b; i < e; ++i) { const uint32_t v = hist[i]; hist[i] = run; run += v; }
+  for (uint32_t i = b; i < e; ++i) { const uint32_t v = at(i); at(i) = run; run += v; }
 }
 
 // one stable pass over this workgroup's 8192 keys
@@ -201,7 +206,7 @@ void launchSortedDraws(const DeviceState& d, const DrawSortState& st, uint32_t b
     if (groups == 1) hipLaunchKernelGGL((k_radix_pass<true>), dim3(1), dim3(kSortThreads), 0, s, a);
     else {
       hipLaunchKernelGGL(k_radix_hist, dim3(groups), dim3(kSortThreads), 0, s, a);
-      hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(kSortThreads), 0, s, st.hist, kDigits * groups);
+      hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(kSortThreads), 0, s, st.hist, d.counters, groups);
       hipLaunchKernelGGL((k_radix_pass<false>), dim3(groups), dim3(kSortThreads), 0, s, a);
     }
     from ^= 1u;

@@ -72,6 +72,8 @@ struct DeviceState {
   uint32_t* binLayers;         // OR of the records' (group | mask << 16) per bin: lets the pair kernel skip a bin unread
   float4* bins;                // [sector][kBinCap][2]: (min.xyz, layers) (max.xyz, id | primary<<31)
   float4* bigList;             // [cap][2] boxes that cannot be binned (too large, outside the rect, bin full)
+  float4* spill;               // [kSpillCap][2] border records whose landing bin was full ...
+  uint32_t* spillSector;       // ... and the sector each was meant for
   uint32_t* bigBits[2];        // per-entity "is in the big list" bit, double-buffered by tick parity
   uint2* pairs;                // (a, b) ids, a < b; id = rank << 24 | dense index; kPairShards segments of shardCap
   uint32_t* pairShardCount;    // [2 parities][kPairShards] counters, one per 128-byte line (kShardStride words apart)
@@ -83,9 +85,15 @@ struct DeviceState {
 };
 
 // Border message layout (uint32 words): [0] records, [1] overflow flag, [2..2+L) per-bin counts,
-// then records (8 words each) packed bin after bin.  L = sectors on that ring side.
+// then records (8 words each) packed bin after bin, then the big-box section: [0] boxes, [1] overflow flag,
+// boxes (8 words each).  L = sectors on that ring side.
 constexpr uint32_t kBorderHeader = 2;
-constexpr uint32_t kBorderRecsPerBin = 16;    // capacity = L * kBorderRecsPerBin records per message
+constexpr uint32_t kBorderRecsPerBin = 16;    // capacity = L * kBorderRecsPerBin records per message, at least one full bin
+constexpr uint32_t kSpillCap = 4096;          // received records that found their landing bin full (kept per sector, see pairsBody)
+constexpr uint32_t kSpillPerSector = 64;      // == kBinCap: the spilled records of a sector reuse the bin's LDS tile
+constexpr uint32_t kBorderBigCap = 128;       // big boxes (wider than 2x2 sectors, outside the rectangle, bin full) per message
+constexpr uint32_t kBorderBigWords = 2u + kBorderBigCap * 8u;
+constexpr float kBigReach = 2.0f;             // sectors around a tile's owned region within which it must know a big box
 
 constexpr uint32_t kBinCap = 64;          // one wave lane per record of a bin
 // Pair output is sharded: a wave buffers its hits in LDS and appends them to the segment of its workgroup's
@@ -93,7 +101,10 @@ constexpr uint32_t kBinCap = 64;          // one wave lane per record of a bin
 constexpr uint32_t kPairShards = 64, kShardStride = 32, kWavePairBuf = 256;
 constexpr uint32_t kPrimary = 0x80000000u;
 // counters[]: 0 visible, 1 culled, 4 draws, 5 dropped, 6 renderables; per tick parity q: 8+8q+{0 pairs, 1 big, 2 bin-full}
-constexpr uint32_t kCtrPar = 8, kCtrPairs = 0, kCtrBig = 1, kCtrBinFull = 2;
+constexpr uint32_t kCtrPar = 8, kCtrPairs = 0, kCtrBig = 1, kCtrBinFull = 2, kCtrBorderLost = 3, kCtrBigLocal = 4, kCtrSpill = 5;
+// (kCtrBig counts the big list: this tile's boxes, then -- after the border merge -- its neighbours' that reach it;
+//  kCtrBigLocal keeps this tile's own count; kCtrBorderLost: records or boxes a border message had no room for, or
+//  big boxes that reach beyond the eight neighbouring tiles -- pairs may be missing)
 
 struct TickParams {
   uint32_t n;               // entities
@@ -111,6 +122,7 @@ struct TickParams {
   uint32_t neighbourMask;   // bit d set: a neighbour tile exists in direction d (its ring side is foreign)
   uint32_t variant;         // kernel variant selector (A/B tuning; 0 = default)
   uint32_t chain;           // min(deepest hierarchy level, kMaxChain): selects the fused kernel's specialisation
+  uint32_t tileX, tileZ, tilesX, tilesZ;   // this tile's place in the grid of equal tiles (tilesX == 0: unknown, no big-box exchange)
   uint32_t bigClearWords;   // words of the other parity's bigBits the previous broadphase tick may have set (its entity count / 32)
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d
@@ -120,7 +132,9 @@ __host__ __device__ inline uint32_t borderLen(uint32_t d, uint32_t coreSX, uint3
 __host__ __device__ inline uint32_t borderDirOf(int dx, int dz) { const uint32_t k9 = (uint32_t)((dz + 1) * 3 + (dx + 1)); return k9 < 4 ? k9 : k9 - 1u; }
 // hasNb(p, dx, dz): a tile exists one step in that direction
 __host__ __device__ inline bool hasNb(const TickParams& p, int dx, int dz) { return (p.neighbourMask >> borderDirOf(dx, dz)) & 1u; }
-__host__ __device__ inline uint32_t borderWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { const uint32_t L = borderLen(d, coreSX, coreSZ); return kBorderHeader + L + L * kBorderRecsPerBin * 8u; }
+__host__ __device__ inline uint32_t borderRecCap(uint32_t L) { return L * kBorderRecsPerBin > 64u ? L * kBorderRecsPerBin : 64u; }     // 64 = kBinCap
+__host__ __device__ inline uint32_t borderBinWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { const uint32_t L = borderLen(d, coreSX, coreSZ); return kBorderHeader + L + borderRecCap(L) * 8u; }
+__host__ __device__ inline uint32_t borderWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { return borderBinWords(d, coreSX, coreSZ) + kBorderBigWords; }
 constexpr uint32_t kFlagHasDeep = 1u << 16;   // write recomp bits for the level kernels
 constexpr uint32_t kFlagDenseAabbs = 1u << 5; // == SC_TICK_DENSE_AABBS
 
@@ -153,6 +167,7 @@ void launchDenseAabbs(const DeviceState& d, uint32_t n, hipStream_t s);
 void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, hipStream_t s);
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);
 void launchMoveEntities(const DeviceState& d, const uint32_t* src, const uint32_t* dst, uint32_t moves, hipStream_t s);
+void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s);
 void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s);
 void launchEmitDraws(const DeviceState& d, uint32_t budget, void* items, hipStream_t s);
 

@@ -621,6 +621,15 @@ __device__ __forceinline__ void sinkPush(const DeviceState& d, const TickParams&
   if (k.count > kWavePairBuf - 64u) sinkFlush(d, p, k);        // keep room for a full wave of hits
 }
 
+// Does this tile own sector (gx, gz) of its bin grid (coordinates may lie outside the grid)?  A sector belongs to
+// the tile nearest to it, so outside the core [1, binS-2] it is ours only on sides where no tile exists.
+__device__ __forceinline__ bool ownsSector(const TickParams& p, float gx, float gz)
+{
+  const int dx = gx < 1.0f ? -1 : (gx > (float)(p.binSX - 2u) ? 1 : 0);
+  const int dz = gz < 1.0f ? -1 : (gz > (float)(p.binSZ - 2u) ? 1 : 0);
+  return !((dx != 0 && hasNb(p, dx, 0)) || (dz != 0 && hasNb(p, 0, dz)));
+}
+
 constexpr uint32_t kPairTabSize = kBinCap * (kBinCap - 1) / 2;
 constexpr uint32_t kFineThreshold = 24;      // bins with more records than this use the 4x4 cell grid
 
@@ -647,6 +656,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   const uint32_t sectors = p.binSX * p.binSZ;
   const uint32_t ctr = kCtrPar + 8u * p.parity;
   const uint32_t nbig = d.counters[ctr + kCtrBig];
+  const uint32_t nspill = min(d.counters[ctr + kCtrSpill], kSpillCap);
   const uint32_t* bigBits = d.bigBits[p.parity];
   float4* T = tile[wave];
   PairSink sink = { pairBuf[wave], 0u, bid % kPairShards };
@@ -804,12 +814,58 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
           sinkPush(d, p, sink, hit, myId, __float_as_uint(gmax.w));
         }
       }
+      // Border records that found this (core-edge) bin full on arrival: they belong to this sector as much as the
+      // records in it, so each meets the bin's records and the other spilled records of the sector under the same
+      // rule (low corner of the intersection in this sector), and -- if it is its box's primary copy -- the big boxes.
+      if (nspill) {
+        const uint32_t gx = s % p.binSX, gz = s / p.binSX;
+        if (gx == 1u || gz == 1u || gx == p.binSX - 2u || gz == p.binSZ - 2u) {
+          float4* X = T;          // the bin's LDS tile is free again here (its records are in registers); kSpillPerSector == kBinCap
+          uint32_t m = 0;
+          for (uint32_t e0 = 0; e0 < nspill; e0 += 64u) {
+            const uint32_t e = e0 + lane;
+            const bool match = e < nspill && d.spillSector[e] == s;
+            const unsigned long long mm = __ballot(match);
+            if (match) {
+              const uint32_t at = m + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+              if (at < kSpillPerSector) { X[2u * at] = d.spill[2u * e]; X[2u * at + 1u] = d.spill[2u * e + 1u]; }
+            }
+            m += (uint32_t)__popcll(mm);
+          }
+          if (m > kSpillPerSector) { if (lane == 0) atomicAdd(&d.counters[ctr + kCtrBorderLost], m - kSpillPerSector); m = kSpillPerSector; }
+          __builtin_amdgcn_wave_barrier();
+          for (uint32_t k = 0; k < m; ++k) {
+            const float4 xmin = X[2u * k], xmax = X[2u * k + 1u];
+            uint32_t ia = 0, ib = 0;
+            bool hit = valid && pairHit(p, xmin, xmax, rmin, rmax, secX, secZ, ia, ib);            // against the bin's records
+            sinkPush(d, p, sink, hit, ia, ib);
+            hit = lane < k && pairHit(p, xmin, xmax, X[2u * lane], X[2u * lane + 1u], secX, secZ, ia, ib);   // against earlier spilled ones
+            sinkPush(d, p, sink, hit, ia, ib);
+            if (__float_as_uint(xmax.w) & kPrimary) {
+              const uint32_t xid = __float_as_uint(xmax.w) & ~kPrimary;
+              for (uint32_t b0 = 0; b0 < nbig; b0 += 64u) {
+                const uint32_t b = b0 + lane;
+                bool bh = false; uint32_t bid2 = 0;
+                if (b < nbig) {
+                  const float4 gmin = d.bigList[2u * (size_t)b], gmax = d.bigList[2u * (size_t)b + 1u];
+                  bid2 = __float_as_uint(gmax.w);
+                  bh = boxesOverlap(xmin, xmax, gmin, gmax) && filterPass(__float_as_uint(xmin.w), __float_as_uint(gmin.w));
+                }
+                sinkPush(d, p, sink, bh, xid, bid2);
+              }
+            }
+          }
+        }
+      }
       __builtin_amdgcn_wave_barrier();
       it = itNext; n = nNext; rmin = nmin; rmax = nmax;
     }
   }
 
-  // big boxes against each other: wave w takes big b = w, w + totalWaves, ...; lanes sweep the partners after b
+  // big boxes against each other: wave w takes big b = w, w + totalWaves, ...; lanes sweep the partners after b.
+  // On a tiled world the list also holds the neighbours' big boxes that reach this tile, every tile that knows both
+  // boxes sees the pair, and the one owning the sector with the low corner of the intersection reports it.
+  const bool tiled = p.neighbourMask != 0u;
   for (uint32_t b = waveGlobal; b < nbig; b += totalWaves) {
     const float4 gmin = d.bigList[2u * (size_t)b], gmax = d.bigList[2u * (size_t)b + 1u];
     for (uint32_t j0 = b + 1u; j0 < nbig; j0 += 64u) {
@@ -819,6 +875,10 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
         const float4 hmin = d.bigList[2u * (size_t)j], hmax = d.bigList[2u * (size_t)j + 1u];
         jid = __float_as_uint(hmax.w);
         hit = boxesOverlap(gmin, gmax, hmin, hmax) && filterPass(__float_as_uint(gmin.w), __float_as_uint(hmin.w));
+        if (hit && tiled) {
+          const float lx = gmin.x > hmin.x ? gmin.x : hmin.x, lz = gmin.z > hmin.z ? gmin.z : hmin.z;
+          hit = ownsSector(p, floorf(lx * p.invSector) - p.binOx, floorf(lz * p.invSector) - p.binOz);
+        }
       }
       sinkPush(d, p, sink, hit, __float_as_uint(gmax.w), jid);
     }
@@ -912,7 +972,7 @@ __global__ __launch_bounds__(kTile) void k_border_pack(const DeviceState d, cons
   int dx, dz; borderDir(dir, dx, dz);
   const uint32_t L = borderLen(dir, p.binSX - 2u, p.binSZ - 2u);
   uint32_t* msg = d.borderSend[dir];
-  const uint32_t cap = L * kBorderRecsPerBin;
+  const uint32_t cap = borderRecCap(L);
   // exclusive scan of the side's bin counts, kTile bins at a time (carry across chunks)
   uint32_t carry = 0;
   for (uint32_t base = 0; base < L; base += kTile) {
@@ -933,12 +993,65 @@ __global__ __launch_bounds__(kTile) void k_border_pack(const DeviceState d, cons
       msg[kBorderHeader + l] = take;
       const float4* src = d.bins + 2u * ((size_t)cell * kBinCap);
       float4* dst = reinterpret_cast<float4*>(msg + kBorderHeader + L) + 2u * (size_t)off;
-      for (uint32_t r = 0; r < take; ++r) { dst[2u * r] = src[2u * r]; dst[2u * r + 1u] = src[2u * r + 1u]; }
+      for (uint32_t r = 0; r < take; ++r) {
+        float4 lo = src[2u * r]; const float4 hi = src[2u * r + 1u];
+        // a box that found some bin full travels in the big section instead: its copies must not take part
+        // over there either (a zero layer word fails every group/mask filter)
+        const uint32_t id = __float_as_uint(hi.w) & ~kPrimary;
+        if ((id & ~kParentMask) == p.rankBits && ((d.bigBits[p.parity][(id & kParentMask) >> 5] >> (id & 31u)) & 1u)) lo.w = 0.0f;
+        dst[2u * r] = lo; dst[2u * r + 1u] = hi;
+      }
     }
     carry = sOff[kTile];
     __syncthreads();
   }
   if (threadIdx.x == 0) { msg[0] = carry < cap ? carry : cap; msg[1] = carry > cap ? 1u : 0u; }
+
+  // ---- big-box section: this tile's big boxes that reach the neighbour's owned region (its core, unbounded on
+  // the sides where the world ends) within kBigReach sectors
+  uint32_t* big = msg + borderBinWords(dir, p.binSX - 2u, p.binSZ - 2u);
+  __shared__ uint32_t bigCount, bigLost;
+  if (threadIdx.x == 0) { bigCount = 0u; bigLost = 0u; }
+  __syncthreads();
+  const uint32_t ctr = kCtrPar + 8u * p.parity;
+  const uint32_t nLocal = d.counters[ctr + kCtrBig];          // the merge has not run yet: only this tile's boxes
+  if (p.tilesX) {
+    const float SX = (float)(p.binSX - 2u), SZ = (float)(p.binSZ - 2u);
+    const float inf = INFINITY;
+    auto reaches = [&](float bx0, float bx1, float bz0, float bz1, int ox, int oz) {
+      // tile at offset (ox, oz): core [1 + ox*SX, SX + ox*SX]; outer sides of the world are open
+      const int tx = (int)p.tileX + ox, tz = (int)p.tileZ + oz;
+      const float x0 = tx == 0 ? -inf : 1.0f + (float)ox * SX - kBigReach, x1 = tx == (int)p.tilesX - 1 ? inf : SX + (float)ox * SX + kBigReach;
+      const float z0 = tz == 0 ? -inf : 1.0f + (float)oz * SZ - kBigReach, z1 = tz == (int)p.tilesZ - 1 ? inf : SZ + (float)oz * SZ + kBigReach;
+      return bx1 >= x0 && bx0 <= x1 && bz1 >= z0 && bz0 <= z1;
+    };
+    const bool firstDir = (p.neighbourMask & ((1u << dir) - 1u)) == 0u;      // one workgroup also looks for boxes out of reach
+    for (uint32_t b = threadIdx.x; b < nLocal; b += kTile) {
+      const float4 lo = d.bigList[2u * (size_t)b], hi = d.bigList[2u * (size_t)b + 1u];
+      const float bx0 = floorf(lo.x * p.invSector) - p.binOx, bx1 = floorf(hi.x * p.invSector) - p.binOx;
+      const float bz0 = floorf(lo.z * p.invSector) - p.binOz, bz1 = floorf(hi.z * p.invSector) - p.binOz;
+      if (reaches(bx0, bx1, bz0, bz1, dx, dz)) {
+        const uint32_t slot = atomicAdd(&bigCount, 1u);
+        if (slot < kBorderBigCap) { float4* o = reinterpret_cast<float4*>(big + 2) + 2u * slot; o[0] = lo; o[1] = hi; }
+        else atomicOr(&bigLost, 1u);
+      }
+      if (firstDir) {
+        bool far = false;
+        for (int tz = 0; tz < (int)p.tilesZ; ++tz)
+          for (int tx = 0; tx < (int)p.tilesX; ++tx) {
+            const int ox = tx - (int)p.tileX, oz = tz - (int)p.tileZ;
+            if (ox >= -1 && ox <= 1 && oz >= -1 && oz <= 1) continue;
+            far = far || reaches(bx0, bx1, bz0, bz1, ox, oz);
+          }
+        if (far) atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    big[0] = bigCount < kBorderBigCap ? bigCount : kBorderBigCap; big[1] = bigLost;
+    d.counters[ctr + kCtrBigLocal] = nLocal;
+  }
 }
 
 __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, const TickParams p)
@@ -949,7 +1062,7 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
   int dx, dz; borderDir(dir, dx, dz);
   const uint32_t L = borderLen(dir, p.binSX - 2u, p.binSZ - 2u);
   const uint32_t* msg = d.borderRecv[dir];
-  if (threadIdx.x == 0 && msg[1]) atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBinFull], 1u);   // sender ran out of message space
+  if (threadIdx.x == 0 && msg[1]) atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBorderLost], 1u);   // sender ran out of message space
   uint32_t carry = 0;
   for (uint32_t base = 0; base < L; base += kTile) {
     const uint32_t l = base + threadIdx.x;
@@ -968,12 +1081,28 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
         if (slot0 + r < kBinCap) {
           float4* dst = d.bins + 2u * ((size_t)sector * kBinCap + slot0 + r);
           dst[0] = src[2u * r]; dst[1] = src[2u * r + 1u];
-        } else atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBinFull], 1u);
+        } else {
+          // the landing bin is full: keep the record on the side, tagged with its sector; the pair search adds it back
+          const uint32_t q = atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrSpill], 1u);
+          if (q < kSpillCap) { d.spill[2u * q] = src[2u * r]; d.spill[2u * q + 1u] = src[2u * r + 1u]; d.spillSector[q] = sector; }
+          else atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBorderLost], 1u);
+        }
       }
     }
     carry = sOff[kTile];
     __syncthreads();
   }
+  // the neighbour's big boxes that reach this tile join the big list behind this tile's own
+  const uint32_t* big = msg + borderBinWords(dir, p.binSX - 2u, p.binSZ - 2u);
+  const uint32_t m = big[0] < kBorderBigCap ? big[0] : kBorderBigCap;
+  if (threadIdx.x == 0) {
+    sOff[0] = m ? atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBig], m) : 0u;
+    if (big[1]) atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBorderLost], 1u);
+  }
+  __syncthreads();
+  const uint32_t at = sOff[0];
+  const float4* src = reinterpret_cast<const float4*>(big + 2);
+  for (uint32_t r = threadIdx.x; r < 2u * m; r += kTile) d.bigList[2u * (size_t)at + r] = src[r];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1096,6 +1225,15 @@ __global__ __launch_bounds__(kTile) void k_move_entities(const DeviceState d, co
   }
 }
 
+// Children of a relocated entity: pairs (entity, new parent index); depth and flags are untouched.
+__global__ __launch_bounds__(kTile) void k_patch_parents(const DeviceState d, const uint32_t* __restrict__ pairs, uint32_t count)
+{
+  const uint32_t t = blockIdx.x * kTile + threadIdx.x;
+  if (t >= count) return;
+  const uint32_t e = pairs[2u * t], q = pairs[2u * t + 1u];
+  d.link[e] = (d.link[e] & ~kParentMask) | (q & kParentMask);
+}
+
 // RenderPrepStreamingSystem draw emission (sc_world_partition.cpp:1306-1329): the first `budget`
 // visible entities, in order, become DrawItem{entity, mesh, material, worldMatrix}.
 struct DrawItem80 { uint32_t dense, mesh, material, pad; float model[16]; };
@@ -1208,6 +1346,11 @@ void launchMoveEntities(const DeviceState& d, const uint32_t* src, const uint32_
   if (!moves) return;
   const uint64_t threads = (uint64_t)moves * kMoveSlots;
   hipLaunchKernelGGL(k_move_entities, dim3((uint32_t)((threads + kTile - 1) / kTile)), dim3(kTile), 0, s, d, src, dst, moves);
+}
+void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s)
+{
+  if (!count) return;
+  hipLaunchKernelGGL(k_patch_parents, dim3((count + kTile - 1) / kTile), dim3(kTile), 0, s, d, pairs, count);
 }
 void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s)
 {

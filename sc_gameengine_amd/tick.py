@@ -263,6 +263,9 @@ class WorldTick:
     def set_tile(self, rank, neighbour_mask):
         self._ok(self.lib.scTickSetTile(self.ctx, rank, neighbour_mask), "scTickSetTile")
 
+    def set_tile_grid(self, tile_x, tile_z, tiles_x, tiles_z):
+        self._ok(self.lib.scTickSetTileGrid(self.ctx, tile_x, tile_z, tiles_x, tiles_z), "scTickSetTileGrid")
+
     def border_bytes(self, direction):
         return int(self.lib.scTickBorderBytes(self.ctx, direction))
 

@@ -73,6 +73,8 @@ class BorderBuffers:
         self.rank, self.grid = rank, grid
         self.send, self.recv = {}, {}
         tick.set_tile(rank, neighbour_mask(rank, grid))
+        tx, tz = tile_of(rank, grid)
+        tick.set_tile_grid(tx, tz, grid[0], grid[1])      # big boxes travel in the border messages too
         for d in neighbours(rank, grid):
             nbytes = tick.border_bytes(d)
             self.send[d] = torch.zeros(nbytes // 4, dtype=torch.int32, device=device)

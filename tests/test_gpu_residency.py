@@ -271,3 +271,38 @@ def test_large_batch_removal_1m():
     c = t.counts()
     assert c.entities == n1 and 0 < c.visible < n1 and c.pairs_truncated == 0
     t.close()
+
+
+def test_whole_sectors_of_a_hierarchical_world_stream_without_relinking(oracle):
+    """Despawning complete subtrees relocates tail entities that are parents and children themselves; their links are
+    patched in place (no O(N) re-link) and every later tick still matches -- moving roots drag the right children."""
+    w = sw.generate(8, 8, 15, hierarchy=True)              # per sector: ground + 15 props in runs root, child, grandchild, root
+    tw = Twin(oracle, w, capacity=w.n)
+    tw.tick_and_compare()
+    relinks0 = tw.t.counts().relinks
+    rng = np.random.default_rng(11)
+    for rnd in range(8):
+        # a sector's 16 entities (complete subtrees) wherever earlier relocations have put them: entity handles of a
+        # bulk-built world are the original dense indices, 16 per sector
+        ents = tw.ow.dense_entities()
+        sector_of = (ents & 0xFFFFFF) // 16
+        pick = rng.choice(np.unique(sector_of), 3, replace=False)
+        idx = np.flatnonzero(np.isin(sector_of, pick))
+        assert len(idx) == 48
+        if rnd % 2:
+            rng.shuffle(idx)
+        tw.remove(idx)
+        tw.ow.nudge_roots_x(0.25); tw.t.nudge_roots_x(0.25)
+        tw.tick_and_compare()
+    c = tw.t.counts()
+    assert c.relinks == relinks0, "complete subtrees must not trigger a world re-link"
+    assert c.max_depth == 2
+    # a removal that orphans a child does re-link (and the orphan becomes a dirty root)
+    parents = tw.ow.parents()
+    ents = tw.ow.dense_entities()
+    dense_of = {int(e): i for i, e in enumerate(ents)}
+    child = next(i for i in range(len(parents)) if parents[i] != 0xFFFFFFFF)
+    tw.remove([dense_of[int(parents[child])]])
+    tw.tick_and_compare()
+    assert tw.t.counts().relinks == relinks0 + 1
+    tw.close()

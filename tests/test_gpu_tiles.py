@@ -105,3 +105,120 @@ def test_context_runs_on_an_external_stream(oracle):
         assert np.array_equal(t.world_matrices(), ow.world_matrices())
         t.close()
     ow.close()
+
+
+def run_tiles(oracle, w, grid, S, steps=2, nudge=0.9):
+    """Whole-world pair set from the oracle vs the union of the tiles' pair lists; returns the tiles' counts."""
+    import torch
+    parts, n = split_world(w, grid, S)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    ticks = [WorldTick.from_world(p, broadphase=True, max_pairs=1 << 16) for p in parts]
+    bufs = [tiles.BorderBuffers(t, r, grid, "cuda") for r, t in enumerate(ticks)]
+    flags = capi.XFORM | capi.BROADPHASE | capi.SPLIT_PAIRS
+    counts = []
+    for step in range(steps):
+        if step:
+            ow.nudge_roots_x(nudge)
+            for t in ticks:
+                t.nudge_roots_x(nudge)
+        ow.transform_system()
+        mn, mx = ow.world_aabbs()
+        want = oracle.broadphase_grid(mn, mx, w.group, w.mask, 16.0)
+        for t in ticks:
+            t.run(flags)
+        for t in ticks:
+            t.sync()
+        for r, b in enumerate(bufs):
+            for d, nb in tiles.neighbours(r, grid).items():
+                bufs[nb].recv[7 - d].copy_(b.send[d])
+        torch.cuda.synchronize()
+        for t in ticks:
+            t.run_pairs()
+        got, counts = [], []
+        for t in ticks:
+            p, total = t.pairs()
+            assert total == len(p)
+            counts.append(t.counts())
+            got.append(tiles.global_pair_ids(p, n))
+        got = np.concatenate(got).astype(np.uint64)
+        lo, hi = np.minimum(got[:, 0], got[:, 1]), np.maximum(got[:, 0], got[:, 1])
+        key = np.sort(lo << np.uint64(32) | hi)
+        wkey = want[:, 0].astype(np.uint64) << np.uint64(32) | want[:, 1].astype(np.uint64)
+        assert len(key) == len(np.unique(key)), "a pair was reported twice"
+        missing, extra = np.setdiff1d(wkey, key), np.setdiff1d(key, wkey)
+        assert len(missing) == 0 and len(extra) == 0, f"step {step}: {len(missing)} pairs missing, {len(extra)} unexpected of {len(wkey)}"
+    for t in ticks:
+        t.close()
+    ow.close()
+    return counts, want, n
+
+
+@pytest.mark.parametrize("grid", [(2, 2), (4, 2)])
+def test_big_boxes_cross_tile_borders(oracle, grid):
+    """Boxes the bins cannot hold -- wider than 2x2 sectors, outside the world, or pushed out of a full bin -- travel
+    in the border messages' big-box section; every pair with them is found once, whichever tiles the two boxes live in."""
+    S = (6, 6)
+    w = sw.generate(S[0] * grid[0], S[1] * grid[1], 15, tiles=grid)
+    rng = np.random.default_rng(17)
+    dyn = rng.random(w.n) < 0.3
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    roots = np.flatnonzero((w.parent < 0) & (np.arange(w.n) % 16 != 0))
+    per_tile = w.n // (grid[0] * grid[1])
+    tile_x, tile_z = (roots // per_tile) % grid[0], (roots // per_tile) // grid[0]      # an entity lives with its own tile
+    TW, TH = 64.0 * S[0], 64.0 * S[1]
+    W = TW * grid[0]
+    # wide slabs (130-190 m) sitting on the edges and corners of their own tile, colliding with everything
+    sel = rng.choice(len(roots), 40, replace=False)
+    wide = roots[sel]
+    w.pos[wide, 0] = ((tile_x[sel] + rng.integers(0, 2, 40)) * TW + rng.uniform(-40, 40, 40)).astype(np.float32)
+    w.pos[wide, 2] = ((tile_z[sel] + rng.integers(0, 2, 40)) * TH + rng.uniform(-40, 40, 40)).astype(np.float32)
+    w.scale[wide] = np.float32([1.0, 1.0, 1.0])
+    w.rot[wide] = 0.0
+    half = rng.uniform(65, 95, (40, 3)).astype(np.float32); half[:, 1] = 2.0
+    w.bmin[wide], w.bmax[wide] = -half, half
+    w.group[wide], w.mask[wide] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    # a crowd in the sector at the corner where tiles (0,0) (1,0) (0,1) (1,1) meet, drawn from those four tiles:
+    # the owner's bin overflows on arrival of the neighbours' copies
+    near = np.flatnonzero((tile_x <= 1) & (tile_z <= 1) & ~np.isin(roots, wide))
+    crowd = roots[rng.choice(near, 44, replace=False)]        # about half of them drag a child and a grandchild along: ~90 boxes
+    w.pos[crowd, 0] = (TW - rng.uniform(0.2, 20.0, 44)).astype(np.float32)
+    w.pos[crowd, 2] = (TH - rng.uniform(0.2, 20.0, 44)).astype(np.float32)
+    w.group[crowd], w.mask[crowd] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    # and a few boxes beyond the world's edge, next to their own (outer) tile
+    outer = np.flatnonzero(((tile_x == 0) | (tile_x == grid[0] - 1)) & ~np.isin(roots, wide) & ~np.isin(roots, crowd))
+    pick = rng.choice(outer, 12, replace=False)
+    out = roots[pick]
+    w.pos[out, 0] = (np.where(tile_x[pick] == 0, -150.0, W + 150.0) + rng.uniform(-30, 30, 12)).astype(np.float32)
+    w.group[out], w.mask[out] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+
+    counts, want, n = run_tiles(oracle, w, grid, S)
+    assert sum(c.big_boxes for c in counts) >= 40
+    assert all(c.border_lost == 0 for c in counts)
+    involved = np.isin(want[:, 0], wide) | np.isin(want[:, 1], wide)
+    crossing = (want[:, 0] // n) != (want[:, 1] // n)
+    assert (involved & crossing).sum() > 20                     # big boxes really pair across tiles
+
+
+def test_big_box_reaching_past_the_neighbours_is_counted(oracle):
+    import torch
+    grid, S = (4, 2), (6, 6)
+    w = sw.generate(S[0] * grid[0], S[1] * grid[1], 15, tiles=grid)
+    w.bmin[1] = np.float32([-2000.0, -1.0, -10.0]); w.bmax[1] = np.float32([2000.0, 1.0, 10.0])      # spans all four tile columns
+    w.scale[1] = 1.0; w.rot[1] = 0.0
+    parts, n = split_world(w, grid, S)
+    ticks = [WorldTick.from_world(p, broadphase=True) for p in parts]
+    bufs = [tiles.BorderBuffers(t, r, grid, "cuda") for r, t in enumerate(ticks)]
+    for t in ticks:
+        t.run(capi.XFORM | capi.BROADPHASE | capi.SPLIT_PAIRS)
+    for t in ticks:
+        t.sync()
+    for r, b in enumerate(bufs):
+        for d, nb in tiles.neighbours(r, grid).items():
+            bufs[nb].recv[7 - d].copy_(b.send[d])
+    torch.cuda.synchronize()
+    for t in ticks:
+        t.run_pairs()
+    lost = [t.counts().border_lost for t in ticks]
+    assert lost[0] >= 1 and sum(lost[1:]) == 0
+    for t in ticks:
+        t.close()
