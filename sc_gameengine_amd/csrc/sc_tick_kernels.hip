@@ -1268,7 +1268,11 @@ static void launchXformCullChain(const DeviceState& d, const TickParams& p, uint
 }
 void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
 {
-  switch (p.chain) {                                          // deepest level a lane walks: min(world depth, kMaxChain)
+  // A flat world with binning goes through the chain-1 instance: hipcc allocates 82-84 VGPRs (5 waves/SIMD) for the
+  // chain-0 one and 71-72 (7 waves) for chain-1, and the unused level costs nothing at run time -- measured on a flat
+  // 1M world: 35.6 vs 44.6 us for the full tick's fused kernel.
+  const uint32_t chain = (p.chain == 0u && (p.flags & SC_TICK_BROADPHASE)) ? 1u : p.chain;
+  switch (chain) {                                            // deepest level a lane walks: min(world depth, kMaxChain)
     case 0: launchXformCullChain<0>(d, p, grid, s); break;
     case 1: launchXformCullChain<1>(d, p, grid, s); break;
     case 2: launchXformCullChain<2>(d, p, grid, s); break;

@@ -11,7 +11,7 @@ from sc_gameengine_amd.tick import WorldTick, camera_view_proj
 # a variant is "BITS[:SPANS]": SC_TICK_VARIANT bits (8 = compaction and pair search as separate launches,
 # bits 8+ = pair-kernel grid cap) and optionally SC_TICK_SPANS (workgroups of the fused kernel)
 variants = [v for v in (sys.argv[1] if len(sys.argv) > 1 else "0,8").split(",")]
-w = sw.config("config3")
+w = sw.config("config3") if os.environ.get("AB_WORLD", "config3") == "config3" else sw.generate(256, 256, 15, hierarchy=False)
 vp = camera_view_proj(w.camera)
 ctxs = {}
 for v in variants:
