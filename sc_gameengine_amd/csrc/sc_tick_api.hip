@@ -52,6 +52,7 @@ struct ScTickContext
 
   Frustum6 frustum{};
   int frustumValid = 0;
+  bool frustumStale = true;          // the device copy (DeviceState::frustum) is behind the host's
   int freeze = 0;
 
   uint32_t spansWanted = 1536;
@@ -334,7 +335,6 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   if (c->levelOffsets.size() > 1 && (flags & SC_TICK_XFORM)) p.flags |= kFlagHasDeep;
   p.freeze = c->freeze ? 1u : 0u;
   p.frustumValid = c->frustumValid ? 1u : 0u;
-  p.fr = c->frustum;
   // the bin grid is the tile plus a ring of one sector: boxes that poke over the tile edge stay
   // binnable, and on a multi-GPU world the ring is where a neighbour's border boxes land
   p.binOx = (float)c->desc.tile_origin_x - 1.0f;
@@ -463,6 +463,7 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
           && dalloc(c, d.blockVis, N / kTile) && dalloc(c, d.blockCand, N / kTile)
           && dalloc(c, d.visibleIdx, N) && dalloc(c, d.culledIdx, N) && dalloc(c, d.counters, 32)
           && dalloc(c, d.aabbMin, N) && dalloc(c, d.aabbMax, N);
+  { float* f = nullptr; ok = ok && dalloc(c, f, 32); d.frustum = f; }
   c->sectors = desc->tile_sectors_x ? (desc->tile_sectors_x + 2u) * (desc->tile_sectors_z + 2u) : 0u;
   c->maxPairs = desc->max_pairs ? desc->max_pairs : desc->capacity * 4u;
   c->maxPairs = ((c->maxPairs + kPairShards - 1u) / kPairShards) * kPairShards;   // equal shard segments
@@ -902,6 +903,7 @@ int scTickSetFrustumPlanes(ScTickContext* c, const float planes[24], int valid)
   if (!c || !planes) return c ? fail(c, "null argument") : 0;
   std::memcpy(c->frustum.p, planes, sizeof c->frustum.p);
   c->frustumValid = valid ? 1 : 0;
+  c->frustumStale = true;
   return 1;
 }
 
@@ -933,6 +935,7 @@ int scTickSetViewProj(ScTickContext* c, const float m[16])
     }
   }
   c->frustumValid = 1;
+  c->frustumStale = true;
   return 1;
 }
 
@@ -958,6 +961,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   TickParams p; uint32_t grid;
   fillParams(c, flags, p, grid);
   c->lastFlags = flags;
+  if (c->frustumStale && (flags & SC_TICK_CULL)) { launchSetFrustum(c->d, c->frustum, c->stream); c->frustumStale = false; }   // outside any graph
 
   const uint32_t q = (flags & SC_TICK_BROADPHASE) ? c->parity : 0u;
   const bool sampledTick = c->profiling && (c->tickIndex % c->profPeriod) == 0;     // events need eager launches

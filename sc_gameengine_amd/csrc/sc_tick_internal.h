@@ -65,6 +65,7 @@ struct DeviceState {
   uint32_t* blockCand;      // candidate count per span
   uint32_t* visibleIdx;     // ordered visible dense indices
   uint32_t* culledIdx;
+  const float* frustum;     // the six planes (nx, ny, nz, d), device copy refreshed when the host sets them
   uint32_t* counters;       // [0] visible total, [1] culled total, [2] pairs, [3] bin overflow, [4] draws, [5] dropped
   // broadphase
   float4 *aabbMin, *aabbMax;   // dense-order world AABBs (debug / read-back only: SC_TICK_DENSE_AABBS)
@@ -112,7 +113,6 @@ struct TickParams {
   uint32_t flags;           // SC_TICK_* | internal bits below
   uint32_t freeze;          // CullingState::freezeCulling
   uint32_t frustumValid;
-  Frustum6 fr;
   // broadphase grid: sectors [binOx, binOx+binSX) x [binOz, binOz+binSZ), keyed like worldToSector
   float binOx, binOz, invSector;
   uint32_t binSX, binSZ;
@@ -167,6 +167,7 @@ void launchDenseAabbs(const DeviceState& d, uint32_t n, hipStream_t s);
 void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, hipStream_t s);
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);
 void launchMoveEntities(const DeviceState& d, const uint32_t* src, const uint32_t* dst, uint32_t moves, hipStream_t s);
+void launchSetFrustum(const DeviceState& d, const Frustum6& fr, hipStream_t s);
 void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s);
 void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s);
 void launchEmitDraws(const DeviceState& d, uint32_t budget, void* items, hipStream_t s);

@@ -138,6 +138,29 @@ __device__ __forceinline__ bool sphereVisible(const Aff& M, const BoundsCE& b, c
   return !out;
 }
 
+// Same test with the planes read through a uniform pointer into the constant address space: scalar loads at
+// the point of use.  The fused kernel uses it so that the 24 coefficients are not held in SGPRs across the tile.
+typedef const __attribute__((address_space(4))) float* ConstF;
+__device__ __forceinline__ bool sphereVisibleAt(const Aff& M, const BoundsCE& b, ConstF fr)
+{
+  const float c0 = M.r0[0] * b.cx + M.r0[1] * b.cy + M.r0[2] * b.cz + M.r0[3];
+  const float c1 = M.r1[0] * b.cx + M.r1[1] * b.cy + M.r1[2] * b.cz + M.r1[3];
+  const float c2 = M.r2[0] * b.cx + M.r2[1] * b.cy + M.r2[2] * b.cz + M.r2[3];
+  const float sx = sqrtf(M.r0[0] * M.r0[0] + M.r1[0] * M.r1[0] + M.r2[0] * M.r2[0]);
+  const float sy = sqrtf(M.r0[1] * M.r0[1] + M.r1[1] * M.r1[1] + M.r2[1] * M.r2[1]);
+  const float sz = sqrtf(M.r0[2] * M.r0[2] + M.r1[2] * M.r1[2] + M.r2[2] * M.r2[2]);
+  const float syz = (sy < sz) ? sz : sy;
+  const float maxScale = (sx < syz) ? syz : sx;
+  const float radius = sqrtf(b.ex * b.ex + b.ey * b.ey + b.ez * b.ez) * maxScale;
+  bool out = false;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float dist = fr[4 * k] * c0 + fr[4 * k + 1] * c1 + fr[4 * k + 2] * c2 + fr[4 * k + 3];
+    out = out || (dist < -radius);
+  }
+  return !out;
+}
+
 // world AABB of the bounds box (broadphase spec): centre as above, half extent
 // h_r = |M[r,0]|*ex + |M[r,1]|*ey + |M[r,2]|*ez
 __device__ __forceinline__ void worldAabb(const Aff& M, const BoundsCE& b, float mn[3], float mx[3])
@@ -396,8 +419,9 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
       if (kCull) {
         bool visible = cand;
         if (cand && hb && !p.freeze && p.frustumValid) {
-          float c0, c1, c2;
-          visible = sphereVisible(M, b, p.fr, c0, c1, c2);
+          const float* fr = d.frustum;
+          asm volatile("" : "+s"(fr));                 // opaque: keeps the plane loads inside the loop, at their use
+          visible = sphereVisibleAt(M, b, (ConstF)fr);
         }
         // deeper entities get their matrix (and their bit) from the level kernels
         if (doXform && depth > kChain && depth != kUnreachable) visible = false;
@@ -459,10 +483,7 @@ __global__ __launch_bounds__(kTile) void k_deep_level(const DeviceState d, const
   if (hb) b = loadBounds(d, i);
   if (p.flags & SC_TICK_CULL) {
     bool visible = (lk & kHasMesh) != 0;
-    if (visible && hb && !p.freeze && p.frustumValid) {
-      float c0, c1, c2;
-      visible = sphereVisible(M, b, p.fr, c0, c1, c2);
-    }
+    if (visible && hb && !p.freeze && p.frustumValid) visible = sphereVisibleAt(M, b, (ConstF)d.frustum);
     if (visible) {
       atomicOr((unsigned long long*)&d.vis[i >> 6], 1ull << (i & 63u));
       atomicAdd(&d.blockVis[i / p.span], 1u);
@@ -1108,6 +1129,13 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
 // ------------------------------------------------------------------------------------------
 // Small producers / accessors
 // ------------------------------------------------------------------------------------------
+// The frame's frustum lives in device memory (the kernels read it with scalar loads at the point of use); the host
+// hands new planes over as kernel arguments, in stream order with the ticks.
+__global__ void k_set_frustum(float* __restrict__ dst, const Frustum6 fr)
+{
+  if (threadIdx.x < 24u) dst[threadIdx.x] = fr.p[threadIdx.x >> 2][threadIdx.x & 3u];
+}
+
 __global__ __launch_bounds__(kTile) void k_nudge_roots_x(const DeviceState d, uint32_t n, float dx)
 {
   const uint32_t i = blockIdx.x * kTile + threadIdx.x;
@@ -1350,6 +1378,10 @@ void launchMoveEntities(const DeviceState& d, const uint32_t* src, const uint32_
   if (!moves) return;
   const uint64_t threads = (uint64_t)moves * kMoveSlots;
   hipLaunchKernelGGL(k_move_entities, dim3((uint32_t)((threads + kTile - 1) / kTile)), dim3(kTile), 0, s, d, src, dst, moves);
+}
+void launchSetFrustum(const DeviceState& d, const Frustum6& fr, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_set_frustum, dim3(1), dim3(64), 0, s, const_cast<float*>(d.frustum), fr);
 }
 void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s)
 {
