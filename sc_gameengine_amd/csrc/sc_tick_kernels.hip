@@ -1136,21 +1136,31 @@ __global__ void k_set_frustum(float* __restrict__ dst, const Frustum6 fr)
   if (threadIdx.x < 24u) dst[threadIdx.x] = fr.p[threadIdx.x >> 2][threadIdx.x & 3u];
 }
 
+// Four consecutive entities per lane (16-byte loads and stores): 8 lanes cover one dirty word.
 __global__ __launch_bounds__(kTile) void k_nudge_roots_x(const DeviceState d, uint32_t n, float dx)
 {
-  const uint32_t i = blockIdx.x * kTile + threadIdx.x;
+  const uint32_t t = blockIdx.x * kTile + threadIdx.x;
+  const uint32_t i0 = 4u * t;                       // capacity is padded to kTile entities: whole quads are addressable
   const uint32_t lane = threadIdx.x & 63u;
-  // one memory round trip: link, position and the wave's dirty word are requested together
-  const bool in = i < n;
-  const uint32_t lk = in ? d.link[i] : ((kUnreachable << kDepthShift) | 1u);
-  const float x = in ? d.px[i] : 0.0f;
+  const bool in = i0 < n;
+  // one memory round trip: links, positions and the dirty word are requested together
+  uint4 lk = make_uint4(0, 0, 0, 0); float4 x = make_float4(0, 0, 0, 0);
+  if (in) { lk = *reinterpret_cast<const uint4*>(d.link + i0); x = *reinterpret_cast<const float4*>(d.px + i0); }
   uint32_t dw = 0;
-  if (in && (lane & 31u) == 0u) dw = d.dirty[i >> 5];           // a wave owns exactly the two dirty words of its 64 entities
-  const bool root = in && (lk & kParentMask) == kNoParent && linkDepth(lk) != kUnreachable;
-  if (root) d.px[i] = x + dx;
-  const unsigned long long m = __ballot(root);
-  const uint32_t mine = lane < 32u ? (uint32_t)m : (uint32_t)(m >> 32);
-  if (in && (lane & 31u) == 0u && mine) d.dirty[i >> 5] = dw | mine;
+  if (in && (lane & 7u) == 0u) dw = d.dirty[i0 >> 5];
+  auto isRoot = [&](uint32_t l, uint32_t k) { return i0 + k < n && (l & kParentMask) == kNoParent && linkDepth(l) != kUnreachable; };
+  const bool r0 = isRoot(lk.x, 0), r1 = isRoot(lk.y, 1), r2 = isRoot(lk.z, 2), r3 = isRoot(lk.w, 3);
+  if (r0) x.x = x.x + dx;
+  if (r1) x.y = x.y + dx;
+  if (r2) x.z = x.z + dx;
+  if (r3) x.w = x.w + dx;
+  if (r0 | r1 | r2 | r3) *reinterpret_cast<float4*>(d.px + i0) = x;
+  // the eight lanes of a dirty word combine their four bits
+  uint32_t bits = ((uint32_t)r0 | (uint32_t)r1 << 1 | (uint32_t)r2 << 2 | (uint32_t)r3 << 3) << (4u * (lane & 7u));
+  bits |= (uint32_t)__shfl_xor((int)bits, 1, 64);
+  bits |= (uint32_t)__shfl_xor((int)bits, 2, 64);
+  bits |= (uint32_t)__shfl_xor((int)bits, 4, 64);
+  if (in && (lane & 7u) == 0u && bits) d.dirty[i0 >> 5] = dw | bits;
 }
 
 // Read-back / debug only (SC_TICK_DENSE_AABBS): per-entity world AABBs in dense order, from the stored
@@ -1350,7 +1360,8 @@ void launchBorderMerge(const DeviceState& d, const TickParams& p, hipStream_t s)
 void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s)
 {
   if (!n) return;
-  hipLaunchKernelGGL(k_nudge_roots_x, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, dx);
+  const uint32_t quads = (n + 3u) / 4u;
+  hipLaunchKernelGGL(k_nudge_roots_x, dim3((quads + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, dx);
 }
 void launchDenseAabbs(const DeviceState& d, uint32_t n, hipStream_t s)
 {
