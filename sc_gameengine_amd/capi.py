@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsc_tick.so")
+LIB_PATH = os.environ.get("SC_TICK_LIB") or os.path.join(HERE, "libsc_tick.so")      # SC_TICK_LIB: A/B builds (tools/)
 
 # scTickRun flags (include/sc_tick.h)
 XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS, DENSE_AABBS, SPLIT_PAIRS, SORT_DRAWS = 1, 2, 4, 8, 16, 32, 64, 128
