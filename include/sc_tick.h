@@ -54,6 +54,7 @@ enum {
   SC_TICK_SPLIT_PAIRS = 1u << 6,   /* with BROADPHASE on a multi-GPU tile: stop after filling the bins and packing the
                                       border messages; the caller exchanges them and calls scTickRunPairs */
   SC_TICK_SORT_DRAWS  = 1u << 7,   /* with DRAWS: the list comes out in the renderer's bind order (scTickSetDrawSortTable) */
+  SC_TICK_RAYS        = 1u << 8,   /* with BROADPHASE: answer the ray queries set by scTickSetRayQueries against this tick's boxes */
   SC_TICK_FULL        = SC_TICK_XFORM | SC_TICK_CULL | SC_TICK_BROADPHASE
 };
 
@@ -298,6 +299,33 @@ int scTickAppendEntities(ScTickContext* ctx, uint32_t count, const float* pos3, 
  * Device cost is O(count) unless a removed or relocated entity has children (then the hierarchy is re-linked). */
 int scTickRemoveEntities(ScTickContext* ctx, const uint32_t* dense_indices, uint32_t count,
                          uint32_t* moved_from, uint32_t* moved_to, uint32_t* moved_count);
+
+/* ---- ray queries over the broadphase bins ----
+ * A batch of rays answered inside the tick, after the bins are filled and before the pair search consumes them --
+ * what the traffic AI asks once per agent and frame (sc_traffic_ai.cpp:319, :644) and the vehicle camera once
+ * (sc_vehicle.cpp:600).  Shaped like PhysicsWorld::raycast (src/engine/physics/sc_physics.cpp:740-777): the
+ * direction is normalised the same way (no hit when |dir|^2 <= 1e-6), the segment runs from origin to
+ * origin + ndir * max_dist, a box takes part when (group & mask) != 0 and its own mask is not empty (Bullet's default
+ * filter with the callback's group 0xFFFF), the closest hit wins.  The reference tests Bullet's exact shapes; here the
+ * candidates are the world AABBs of the broadphase, tested with the reference's own slab arithmetic
+ * (intersectRayAABB, tools/world_editor/editor_core/editor_core.cpp:438-470); equal distances go to the lower id.
+ * On a tiled world a context answers for the boxes registered in its own sectors, which includes the neighbours' boxes
+ * that reach into them (the queries run after the border merge); the part of a ray beyond the tile is the neighbour's. */
+typedef struct ScTickRayHit     /* RaycastHit, sc_physics.h:106-114 */
+{
+  uint32_t hit;                /* 0 / 1 */
+  uint32_t id;                 /* rank << 24 | dense index of the box that was hit (0xFFFFFFFF: none) */
+  float    distance;           /* along the normalised direction */
+  float    position[3];        /* origin + ndir * distance */
+  float    normal[3];          /* axis normal of the face the ray entered through; (0,1,0) when it starts inside the box */
+  uint32_t layer;              /* the box's collision group */
+  uint32_t pad[2];
+} ScTickRayHit;
+/* origin3 / dir3: [count][3]; max_dist, mask: [count].  The set stays until it is replaced (count 0 clears it). */
+int scTickSetRayQueries(ScTickContext* ctx, uint32_t count, const float* origin3, const float* dir3,
+                        const float* max_dist, const uint32_t* mask);
+/* results of the last scTickRun(... | SC_TICK_BROADPHASE | SC_TICK_RAYS) (after scTickRunPairs on a tiled world) */
+int scTickReadRayHits(ScTickContext* ctx, ScTickRayHit* hits, uint32_t capacity, uint32_t* count);
 
 /* ---- measurement ---- */
 /* record HIP events around the kernel launches (on the context's stream) of every `enable`-th tick

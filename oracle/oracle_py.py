@@ -164,6 +164,18 @@ def frustum_from_viewproj(vp):
     return planes, int(fr.valid)
 
 
+def raycast_boxes(mn, mx, group, mask, origin, direction, max_dist, ray_mask):
+    """Brute-force ray queries over world AABBs; returns a structured array like WorldTick.ray_hits()."""
+    L = lib()
+    mn, mx, o, dv, md = _c32(mn), _c32(mx), _c32(origin).reshape(-1, 3), _c32(direction).reshape(-1, 3), _c32(max_dist).reshape(-1)
+    g, m, rm = (np.ascontiguousarray(a, np.uint32) for a in (group, mask, ray_mask))
+    dt = np.dtype([("hit", np.uint32), ("id", np.uint32), ("distance", np.float32), ("position", np.float32, 3),
+                   ("normal", np.float32, 3), ("layer", np.uint32), ("pad", np.uint32, 2)])
+    out = np.zeros(len(o), dt)
+    L.orc_raycast_boxes(len(mn), _f(mn), _f(mx), _u(g), _u(m), len(o), _f(o), _f(dv), _f(md), _u(rm), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def world_to_sector(size, x, z):
     sx, sz = C.c_int32(), C.c_int32()
     lib().orc_world_to_sector(float(size), float(x), float(z), C.byref(sx), C.byref(sz))

@@ -821,6 +821,61 @@ uint32_t orc_renderer_draw_order(const OrcDrawItem* items, uint32_t n, const uin
   return kept;
 }
 
+/* ---- ray queries (own spec, include/sc_tick.h "ray queries"): brute force over every box --------------------
+ * direction handling and result fields after PhysicsWorld::raycast (sc_physics.cpp:740-777), the ray-box test is
+ * intersectRayAABB (tools/world_editor/editor_core/editor_core.cpp:438-470) with the far limit at maxDist, closest
+ * hit wins, equal distances go to the lower index (PickEntity, :487-491). */
+static int ray_box(const float o[3], const float dir[3], float maxDist, const float* mn, const float* mx, float* tOut, int* axisOut)
+{
+  float tmin = 0.0f, tmax = maxDist;
+  int axis = 3;
+  for (int i = 0; i < 3; ++i) {
+    if (fabsf(dir[i]) < 1e-6f) {
+      if (o[i] < mn[i] || o[i] > mx[i]) return 0;
+    } else {
+      const float ood = 1.0f / dir[i];
+      float t1 = (mn[i] - o[i]) * ood, t2 = (mx[i] - o[i]) * ood;
+      if (t1 > t2) { const float k = t1; t1 = t2; t2 = k; }
+      if (t1 > tmin) { tmin = t1; axis = i; }
+      tmax = tmax < t2 ? tmax : t2;
+      if (tmin > tmax) return 0;
+    }
+  }
+  *tOut = tmin; *axisOut = axis;
+  return 1;
+}
+
+void orc_raycast_boxes(uint32_t n, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
+                       uint32_t rays, const float* origin3, const float* dir3, const float* maxDist, const uint32_t* rayMask,
+                       OrcRayHit* out)
+{
+  for (uint32_t r = 0; r < rays; ++r) {
+    OrcRayHit h; memset(&h, 0, sizeof h);
+    h.id = 0xFFFFFFFFu; h.normal[1] = 1.0f;
+    const float* o = origin3 + 3 * r; const float* dv = dir3 + 3 * r;
+    const float lenSq = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+    if (lenSq > 1e-6f && maxDist[r] >= 0.0f) {
+      const float invLen = 1.0f / sqrtf(lenSq);
+      const float dir[3] = { dv[0] * invLen, dv[1] * invLen, dv[2] * invLen };
+      float best = INFINITY; int bestAxis = 3;
+      for (uint32_t i = 0; i < n; ++i) {
+        if (!(min3[3 * i] <= max3[3 * i])) continue;                      /* no Bounds (or NaN): no box */
+        const uint32_t g = group[i] & 0xFFFFu, m = mask[i] & 0xFFFFu;
+        if (!(g & rayMask[r]) || !m) continue;
+        float t; int axis;
+        if (!ray_box(o, dir, maxDist[r], min3 + 3 * i, max3 + 3 * i, &t, &axis)) continue;
+        if (t < best) { best = t; bestAxis = axis; h.hit = 1; h.id = i; h.layer = g; }
+      }
+      if (h.hit) {
+        h.distance = best;
+        for (int k = 0; k < 3; ++k) h.position[k] = o[k] + dir[k] * best;
+        if (bestAxis < 3) { h.normal[0] = h.normal[1] = h.normal[2] = 0.0f; h.normal[bestAxis] = dir[bestAxis] > 0.0f ? -1.0f : 1.0f; }
+      }
+    }
+    out[r] = h;
+  }
+}
+
 /* sc_world_partition.cpp:268-275 */
 void orc_world_to_sector(float sectorSize, float x, float z, int32_t* sx, int32_t* sz)
 {

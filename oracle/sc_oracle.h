@@ -169,6 +169,12 @@ uint64_t orc_broadphase_grid(uint32_t n, const float* min3, const float* max3,
                              const uint32_t* group, const uint32_t* mask, float cellSize,
                              uint32_t* pairs2, uint64_t cap);
 
+/* ---- ray queries (own spec; see sc_oracle.c): brute force over all boxes, group/mask as uploaded (low 16 bits) ---- */
+typedef struct OrcRayHit { uint32_t hit, id; float distance; float position[3]; float normal[3]; uint32_t layer; uint32_t pad[2]; } OrcRayHit;
+void orc_raycast_boxes(uint32_t n, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
+                       uint32_t rays, const float* origin3, const float* dir3, const float* maxDist, const uint32_t* rayMask,
+                       OrcRayHit* out);
+
 /* ---- upstream movers (own spec, include/sc_tick.h "upstream movers"; model after the on-rails tier,
  *      sc_traffic_ai.cpp:434-460): dense-order arrays; vel is updated in place for reflecting peds ---- */
 void orc_advance_movers(OrcWorld* w, const uint8_t* kind, float* vel_xz2, const float* lo_xz2, const float* hi_xz2, float dt);

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SC_TICK_LIB") or os.path.join(HERE, "libsc_tick.so")      # SC_TICK_LIB: A/B builds (tools/)
 
 # scTickRun flags (include/sc_tick.h)
-XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS, DENSE_AABBS, SPLIT_PAIRS, SORT_DRAWS = 1, 2, 4, 8, 16, 32, 64, 128
+XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS, DENSE_AABBS, SPLIT_PAIRS, SORT_DRAWS, RAYS = 1, 2, 4, 8, 16, 32, 64, 128, 256
 FULL = XFORM | CULL | BROADPHASE
 K_XFORM_CULL, K_COMPACT, K_PAIRS, K_NUDGE, K_COUNT = 0, 1, 2, 3, 4
 NO_PARENT = -1
@@ -40,6 +40,11 @@ class Counts(C.Structure):
 class DrawItem(C.Structure):
     _fields_ = [("dense_index", C.c_uint32), ("mesh_id", C.c_uint32), ("material_id", C.c_uint32),
                 ("pad", C.c_uint32), ("model", C.c_float * 16)]
+
+
+class RayHit(C.Structure):
+    _fields_ = [("hit", C.c_uint32), ("id", C.c_uint32), ("distance", C.c_float), ("position", C.c_float * 3),
+                ("normal", C.c_float * 3), ("layer", C.c_uint32), ("pad", C.c_uint32 * 2)]
 
 
 class SectorInfo(C.Structure):
@@ -103,6 +108,8 @@ SYMBOLS = {
     "scTickReadWorldAabbs": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P, F32P]),
     "scTickReadPairs": (C.c_int, [_CTX, U32P, C.c_uint32, U32P]),
     "scTickReadDraws": (C.c_int, [_CTX, C.POINTER(DrawItem), C.c_uint32, U32P]),
+    "scTickSetRayQueries": (C.c_int, [_CTX, C.c_uint32, F32P, F32P, F32P, U32P]),
+    "scTickReadRayHits": (C.c_int, [_CTX, C.POINTER(RayHit), C.c_uint32, U32P]),
     "scTickSetProfiling": (C.c_int, [_CTX, C.c_int]),
     "scTickGetKernelTimes": (C.c_int, [_CTX, C.c_uint32, F32P, C.c_uint32, U32P]),
     "scTickSetGraphMode": (C.c_int, [_CTX, C.c_int]),

@@ -62,6 +62,8 @@ struct ScTickContext
   // scratch device buffers for indexed read-back
   uint32_t* dIdx = nullptr; float* dRows = nullptr; uint32_t scratchCap = 0;
   void* dDraws = nullptr;
+  RayQueryState rays{};                // scTickSetRayQueries: device copies of the batch + the hit buffer
+  uint32_t rayCap = 0;
   DrawSortState sort{};                // renderer draw order (scTickSetDrawSortTable); key/idx buffers allocated on first use
   uint8_t* dPipeline = nullptr; uint32_t pipelineCap = 0;
 
@@ -376,6 +378,7 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
   if ((flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_DENSE_AABBS)) launchDenseAabbs(c->d, c->n, c->stream);   // read-back aid, off the hot path
   const bool needCompact = (flags & (SC_TICK_XFORM | SC_TICK_CULL)) != 0;
   const bool pairsNow = (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS);
+  if (pairsNow && (flags & SC_TICK_RAYS)) launchRayQueries(c->d, p, c->rays, c->stream);      // the bins are full, not yet consumed
   if (needCompact && pairsNow && !(c->variant & 8u)) {
     // both depend only on the fused kernel: one launch, workgroups split by role (timed as K_PAIRS)
     Scoped s(c, SC_TICK_K_PAIRS);
@@ -957,6 +960,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
     return 1;
   }
   if ((flags & SC_TICK_BROADPHASE) && c->desc.tile_sectors_x == 0) return fail(c, "broadphase requested but the context has no tile rectangle");
+  if ((flags & SC_TICK_RAYS) && !(flags & SC_TICK_BROADPHASE)) return fail(c, "SC_TICK_RAYS needs SC_TICK_BROADPHASE in the same run (the queries read this tick's bins)");
   if ((flags & SC_TICK_SORT_DRAWS) && !c->sort.pipeline) return fail(c, "SC_TICK_SORT_DRAWS needs scTickSetDrawSortTable first");
   TickParams p; uint32_t grid;
   fillParams(c, flags, p, grid);
@@ -996,6 +1000,7 @@ int scTickRunPairs(ScTickContext* c)
   if (!bind(c)) return 0;
   if (!c->pairsPending) return fail(c, "scTickRunPairs without a preceding scTickRun(... | SC_TICK_BROADPHASE | SC_TICK_SPLIT_PAIRS)");
   launchBorderMerge(c->d, c->pendingParams, c->stream);
+  if (c->pendingParams.flags & SC_TICK_RAYS) launchRayQueries(c->d, c->pendingParams, c->rays, c->stream);   // sees the neighbours' border boxes too
   {
     Scoped s(c, SC_TICK_K_PAIRS);
     launchPairs(c->d, c->pendingParams, c->stream);
@@ -1301,6 +1306,46 @@ int scTickReadDraws(ScTickContext* c, ScTickDrawItem* items, uint32_t cap, uint3
   *count = have;
   const uint32_t take = std::min(have, cap);
   if (take && items) { if (!d2h(c, items, c->dDraws, (size_t)take * sizeof(ScTickDrawItem)) || !sync(c)) return 0; }
+  return 1;
+}
+
+int scTickSetRayQueries(ScTickContext* c, uint32_t count, const float* origin3, const float* dir3, const float* maxDist, const uint32_t* mask)
+{
+  if (!c) return 0;
+  if (count && (!origin3 || !dir3 || !maxDist || !mask)) return fail(c, "null argument");
+  if (!bind(c) || !sync(c)) return 0;
+  if (count > c->rayCap) {
+    dfree(c, const_cast<float4*>(c->rays.origin)); dfree(c, const_cast<float4*>(c->rays.dir)); dfree(c, c->rays.hits);
+    c->rays = RayQueryState{}; c->rayCap = 0;
+    const uint32_t want = std::max(count, 1024u);
+    float4 *o = nullptr, *dd = nullptr; RayHit48* h = nullptr;
+    if (!dalloc(c, o, want, false) || !dalloc(c, dd, want, false) || !dalloc(c, h, want)) return 0;
+    c->rays.origin = o; c->rays.dir = dd; c->rays.hits = h; c->rayCap = want;
+  }
+  c->rays.count = count;
+  c->topoEpoch++;                      // a captured frame holds the old batch size
+  if (!count) return 1;
+  std::vector<float4> o(count), dd(count);
+  for (uint32_t i = 0; i < count; ++i) {
+    o[i] = make_float4(origin3[3 * i], origin3[3 * i + 1], origin3[3 * i + 2], maxDist[i]);
+    float w; std::memcpy(&w, &mask[i], 4);
+    dd[i] = make_float4(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2], w);
+  }
+  if (!h2d(c, const_cast<float4*>(c->rays.origin), o.data(), (size_t)count * 16u) ||
+      !h2d(c, const_cast<float4*>(c->rays.dir), dd.data(), (size_t)count * 16u)) return 0;
+  return sync(c) ? 1 : 0;
+}
+
+int scTickReadRayHits(ScTickContext* c, ScTickRayHit* hits, uint32_t cap, uint32_t* count)
+{
+  if (!c || !count) return c ? fail(c, "null argument") : 0;
+  if (!bind(c)) return 0;
+  if (!(c->lastFlags & SC_TICK_RAYS)) return fail(c, "the last scTickRun did not request SC_TICK_RAYS");
+  if (c->pairsPending) return fail(c, "ray hits are ready after scTickRunPairs");
+  static_assert(sizeof(ScTickRayHit) == sizeof(RayHit48), "ray hit layouts differ");
+  *count = c->rays.count;
+  const uint32_t take = std::min(c->rays.count, cap);
+  if (take && hits) { if (!d2h(c, hits, c->rays.hits, (size_t)take * sizeof(ScTickRayHit)) || !sync(c)) return 0; }
   return 1;
 }
 

@@ -152,6 +152,16 @@ struct DrawSortState {
 };
 void launchSortedDraws(const DeviceState& d, const DrawSortState& st, uint32_t budget, uint32_t bound, void* items, hipStream_t s);
 
+// ---- ray queries over the bins (sc_tick_queries.hip) ----
+struct RayHit48 { uint32_t hit, id; float distance; float position[3]; float normal[3]; uint32_t layer; uint32_t pad; uint32_t pad2; };   // == ScTickRayHit
+struct RayQueryState {
+  const float4* origin;     // xyz + maxDist
+  const float4* dir;        // xyz + mask (bit pattern)
+  RayHit48* hits;
+  uint32_t count;
+};
+void launchRayQueries(const DeviceState& d, const TickParams& p, const RayQueryState& q, hipStream_t s);
+
 // launchers (sc_tick_kernels.hip)
 void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);

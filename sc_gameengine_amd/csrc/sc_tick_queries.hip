@@ -1,0 +1,138 @@
+// sc_tick_queries.hip -- ray queries over the broadphase bins of the current tick.
+//
+// Shaped like PhysicsWorld::raycast (src/engine/physics/sc_physics.cpp:740-777): direction normalised the same
+// way (rejected when |dir|^2 <= 1e-6), segment from origin to origin + ndir * maxDist, Bullet's default filter
+// with the callback's group 0xFFFF and mask = the caller's mask, closest hit wins.  The reference tests Bullet's
+// exact shapes; Bullet is not in the tree, so -- as for the pair search -- the spec here is this build's own:
+// candidates are the WORLD AABBs the broadphase already holds, and the ray-box arithmetic is the reference's
+// own slab test, intersectRayAABB (tools/world_editor/editor_core/editor_core.cpp:438-470), with the far limit
+// set to maxDist.  Equal distances go to the lower id (PickEntity keeps the first, :487-491).
+//
+// One wave per ray.  The wave walks the sectors under the ray's xz extent, skipping those the segment misses;
+// lanes take one bin record each; then the big list.  Every lane keeps its own best hit; one 64-bit min over
+// (distance bits, id) picks the winner, whose lane writes the result.
+#include "sc_tick_internal.h"
+
+namespace sctick {
+
+namespace {
+
+struct Slab { bool hit; float t; uint32_t axis; };
+
+// intersectRayAABB, editor_core.cpp:438-470 (tmax starts at the ray's length instead of 1e30)
+__device__ __forceinline__ Slab rayBox(const float o[3], const float dir[3], float maxDist, const float4& lo, const float4& hi)
+{
+  const float mn[3] = { lo.x, lo.y, lo.z }, mx[3] = { hi.x, hi.y, hi.z };
+  Slab s; s.hit = true; s.t = 0.0f; s.axis = 3u;
+  float tmin = 0.0f, tmax = maxDist;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (fabsf(dir[i]) < 1e-6f) {
+      if (o[i] < mn[i] || o[i] > mx[i]) s.hit = false;
+    } else {
+      const float ood = 1.0f / dir[i];
+      float t1 = (mn[i] - o[i]) * ood, t2 = (mx[i] - o[i]) * ood;
+      if (t1 > t2) { const float k = t1; t1 = t2; t2 = k; }
+      if (t1 > tmin) { tmin = t1; s.axis = (uint32_t)i; }          // std::max(tmin, t1)
+      tmax = tmax < t2 ? tmax : t2;                                 // std::min(tmax, t2)
+      if (tmin > tmax) s.hit = false;
+    }
+  }
+  s.t = tmin;
+  return s;
+}
+
+__global__ __launch_bounds__(kTile) void k_ray_queries(const DeviceState d, const TickParams p, const RayQueryState q)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t r = blockIdx.x * (kTile / 64u) + (threadIdx.x >> 6);
+  if (r >= q.count) return;
+  const float4 od = q.origin[r], dm = q.dir[r];
+  const float o[3] = { od.x, od.y, od.z };
+  const float maxDist = od.w;
+  const uint32_t rayMask = __float_as_uint(dm.w);
+  RayHit48 out;
+  out.hit = 0u; out.id = 0xFFFFFFFFu; out.distance = 0.0f;
+  out.position[0] = out.position[1] = out.position[2] = 0.0f;
+  out.normal[0] = 0.0f; out.normal[1] = 1.0f; out.normal[2] = 0.0f;           // RaycastHit{} (sc_physics.h:106-114)
+  out.layer = 0u; out.pad = 0u; out.pad2 = 0u;
+
+  const float lenSq = dm.x * dm.x + dm.y * dm.y + dm.z * dm.z;
+  // (a NaN or non-positive length is no segment either)
+  if (!(lenSq > 1e-6f) || !(maxDist >= 0.0f)) { if (lane == 0) q.hits[r] = out; return; }
+  const float invLen = 1.0f / sqrtf(lenSq);
+  const float dir[3] = { dm.x * invLen, dm.y * invLen, dm.z * invLen };
+  const float ex = o[0] + dir[0] * maxDist, ez = o[2] + dir[2] * maxDist;
+
+  // this lane's best so far
+  float bt = INFINITY; uint32_t bid = 0xFFFFFFFFu, baxis = 3u, blayer = 0u;
+  auto consider = [&](const float4& lo, const float4& hi) {
+    const uint32_t lay = __float_as_uint(lo.w);
+    // Bullet's needsCollision with the callback's group 0xFFFF: (proxy.group & mask) && (0xFFFF & proxy.mask)
+    if (!((lay & 0xFFFFu) & rayMask) || !(lay >> 16)) return;
+    const Slab s = rayBox(o, dir, maxDist, lo, hi);
+    if (!s.hit) return;
+    const uint32_t id = __float_as_uint(hi.w) & ~kPrimary;
+    if (s.t < bt || (s.t == bt && id < bid)) { bt = s.t; bid = id; baxis = s.axis; blayer = lay & 0xFFFFu; }
+  };
+
+  // sectors under the segment's xz extent, clamped to the bin grid (boxes outside it are in the big list)
+  const float fx0 = floorf((o[0] < ex ? o[0] : ex) * p.invSector) - p.binOx, fx1 = floorf((o[0] < ex ? ex : o[0]) * p.invSector) - p.binOx;
+  const float fz0 = floorf((o[2] < ez ? o[2] : ez) * p.invSector) - p.binOz, fz1 = floorf((o[2] < ez ? ez : o[2]) * p.invSector) - p.binOz;
+  const float gridX = (float)p.binSX - 1.0f, gridZ = (float)p.binSZ - 1.0f;
+  if (p.binSX && fx1 >= 0.0f && fz1 >= 0.0f && fx0 <= gridX && fz0 <= gridZ) {
+    const uint32_t gx0 = (uint32_t)(fx0 < 0.0f ? 0.0f : fx0), gx1 = (uint32_t)(fx1 > gridX ? gridX : fx1);
+    const uint32_t gz0 = (uint32_t)(fz0 < 0.0f ? 0.0f : fz0), gz1 = (uint32_t)(fz1 > gridZ ? gridZ : fz1);
+    const float size = 1.0f / p.invSector;
+    for (uint32_t gz = gz0; gz <= gz1; ++gz)
+      for (uint32_t gx = gx0; gx <= gx1; ++gx) {
+        if (gx1 - gx0 > 1u || gz1 - gz0 > 1u) {
+          // long ray: skip sectors the segment cannot touch (the sector's square, grown by a metre, as a flat box)
+          const float4 lo = make_float4(((float)gx + p.binOx) * size - 1.0f, -INFINITY, ((float)gz + p.binOz) * size - 1.0f, 0.0f);
+          const float4 hi = make_float4(((float)gx + p.binOx + 1.0f) * size + 1.0f, INFINITY, ((float)gz + p.binOz + 1.0f) * size + 1.0f, 0.0f);
+          if (!rayBox(o, dir, maxDist, lo, hi).hit) continue;
+        }
+        const uint32_t s = gz * p.binSX + gx;
+        uint32_t n = d.binCount[s];
+        if (n > kBinCap) n = kBinCap;
+        if (lane < n) {
+          const float4* rec = d.bins + 2u * ((size_t)s * kBinCap + lane);
+          consider(rec[0], rec[1]);
+        }
+      }
+  }
+  const uint32_t nbig = d.counters[kCtrPar + 8u * p.parity + kCtrBig];
+  for (uint32_t b = lane; b < nbig; b += 64u) consider(d.bigList[2u * (size_t)b], d.bigList[2u * (size_t)b + 1u]);
+
+  // closest hit of the wave: distances are >= 0, so their bit patterns order like the values
+  unsigned long long key = ((unsigned long long)__float_as_uint(bt) << 32) | bid;
+  unsigned long long best = key;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long other = __shfl_xor(best, off, 64);
+    best = other < best ? other : best;
+  }
+  const bool found = bid != 0xFFFFFFFFu && key == best;
+  const unsigned long long winners = __ballot(found);
+  if (!winners) { if (lane == 0) q.hits[r] = out; return; }
+  if (lane == (uint32_t)__ffsll((long long)winners) - 1u) {
+    out.hit = 1u; out.id = bid; out.distance = bt; out.layer = blayer;
+    out.position[0] = o[0] + dir[0] * bt; out.position[1] = o[1] + dir[1] * bt; out.position[2] = o[2] + dir[2] * bt;
+    if (baxis < 3u) {                                   // the face the ray entered through; a ray starting inside keeps (0,1,0)
+      out.normal[0] = out.normal[1] = out.normal[2] = 0.0f;
+      out.normal[baxis] = dir[baxis] > 0.0f ? -1.0f : 1.0f;
+    }
+    q.hits[r] = out;
+  }
+}
+
+} // namespace
+
+void launchRayQueries(const DeviceState& d, const TickParams& p, const RayQueryState& q, hipStream_t s)
+{
+  if (!q.count) return;
+  const uint32_t perBlock = kTile / 64u;
+  hipLaunchKernelGGL(k_ray_queries, dim3((q.count + perBlock - 1) / perBlock), dim3(kTile), 0, s, d, p, q);
+}
+
+} // namespace sctick

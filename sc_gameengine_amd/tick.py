@@ -200,6 +200,23 @@ class WorldTick:
     def nudge_roots_x(self, dx):
         self._ok(self.lib.scTickNudgeRootsX(self.ctx, float(dx)), "scTickNudgeRootsX")
 
+    # ---- ray queries over this tick's boxes ----
+    def set_ray_queries(self, origin, direction, max_dist, mask):
+        o, dd = _c32(origin).reshape(-1, 3), _c32(direction).reshape(-1, 3)
+        md, mk = _c32(max_dist).reshape(-1), np.ascontiguousarray(mask, np.uint32).reshape(-1)
+        self._ok(self.lib.scTickSetRayQueries(self.ctx, len(o), _f(o), _f(dd), _f(md), _u(mk)), "scTickSetRayQueries")
+
+    def ray_hits(self):
+        """Structured array (hit, id, distance, position[3], normal[3], layer) of the last run's ray batch."""
+        n = C.c_uint32()
+        self._ok(self.lib.scTickReadRayHits(self.ctx, None, 0, C.byref(n)), "scTickReadRayHits")
+        buf = (capi.RayHit * max(n.value, 1))()
+        if n.value:
+            self._ok(self.lib.scTickReadRayHits(self.ctx, buf, n.value, C.byref(n)), "scTickReadRayHits")
+        dt = np.dtype([("hit", np.uint32), ("id", np.uint32), ("distance", np.float32), ("position", np.float32, 3),
+                       ("normal", np.float32, 3), ("layer", np.uint32), ("pad", np.uint32, 2)])
+        return np.frombuffer(buf, dtype=dt, count=n.value).copy()
+
     def set_draw_sort_table(self, pipeline_of_material, mesh_count):
         """Material::pipelineId per material handle (0xFF = no such material) and the number of mesh handles:
         what the renderer's filter + sort of the draw list reads (sc_vk.cpp:1842-1864)."""
