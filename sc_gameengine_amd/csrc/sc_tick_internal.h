@@ -163,7 +163,7 @@ struct RayQueryState {
 void launchRayQueries(const DeviceState& d, const TickParams& p, const RayQueryState& q, hipStream_t s);
 
 // launchers (sc_tick_kernels.hip)
-void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
+void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA = nullptr, hipEvent_t evB = nullptr);
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s);

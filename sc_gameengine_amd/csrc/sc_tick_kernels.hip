@@ -9,6 +9,7 @@
 // no inter-workgroup dependency inside the big kernel (a child re-derives its ancestors' matrices
 // instead of waiting for them), and wave-ballot compaction.
 #include "sc_tick_internal.h"
+#include <hip/hip_ext.h>
 #include "../../include/sc_tick.h"
 
 namespace sctick {
@@ -1295,26 +1296,35 @@ __global__ __launch_bounds__(kTile) void k_emit_draws(const DeviceState d, uint3
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+// evA / evB (both or neither): events that take the kernel's own begin / end timestamps (hipExtLaunchKernelGGL), so the
+// duration bench.py reports is the dispatch's, like the kernel trace's -- not the gap-inclusive span between two
+// hipEventRecord calls on the stream
+template <bool kCull, bool kAabb, uint32_t kChain>
+static void launchOne(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA, hipEvent_t evB)
+{
+  if (evA) hipExtLaunchKernelGGL((k_xform_cull<kCull, kAabb, kChain>), dim3(grid), dim3(kTile), 0, s, evA, evB, 0, d, p);
+  else hipLaunchKernelGGL((k_xform_cull<kCull, kAabb, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
+}
 template <uint32_t kChain>
-static void launchXformCullChain(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
+static void launchXformCullChain(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA, hipEvent_t evB)
 {
   const bool cull = (p.flags & SC_TICK_CULL) != 0, aabb = (p.flags & SC_TICK_BROADPHASE) != 0;
-  if (cull && aabb) hipLaunchKernelGGL((k_xform_cull<true, true, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
-  else if (cull)    hipLaunchKernelGGL((k_xform_cull<true, false, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
-  else if (aabb)    hipLaunchKernelGGL((k_xform_cull<false, true, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
-  else              hipLaunchKernelGGL((k_xform_cull<false, false, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
+  if (cull && aabb) launchOne<true, true, kChain>(d, p, grid, s, evA, evB);
+  else if (cull)    launchOne<true, false, kChain>(d, p, grid, s, evA, evB);
+  else if (aabb)    launchOne<false, true, kChain>(d, p, grid, s, evA, evB);
+  else              launchOne<false, false, kChain>(d, p, grid, s, evA, evB);
 }
-void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
+void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA, hipEvent_t evB)
 {
-  // A flat world with binning goes through the chain-1 instance: hipcc allocates 82-84 VGPRs (5 waves/SIMD) for the
-  // chain-0 one and 71-72 (7 waves) for chain-1, and the unused level costs nothing at run time -- measured on a flat
-  // 1M world: 35.6 vs 44.6 us for the full tick's fused kernel.
+  // A flat world with binning goes through the chain-1 instance: hipcc allocates 74-84 VGPRs for the chain-0 one and
+  // 56-72 for chain-1, and the unused level costs nothing at run time -- measured on a flat 1M world: 35.6 vs 44.6 us
+  // for the full tick's fused kernel.
   const uint32_t chain = (p.chain == 0u && (p.flags & SC_TICK_BROADPHASE)) ? 1u : p.chain;
   switch (chain) {                                            // deepest level a lane walks: min(world depth, kMaxChain)
-    case 0: launchXformCullChain<0>(d, p, grid, s); break;
-    case 1: launchXformCullChain<1>(d, p, grid, s); break;
-    case 2: launchXformCullChain<2>(d, p, grid, s); break;
-    default: launchXformCullChain<3>(d, p, grid, s); break;
+    case 0: launchXformCullChain<0>(d, p, grid, s, evA, evB); break;
+    case 1: launchXformCullChain<1>(d, p, grid, s, evA, evB); break;
+    case 2: launchXformCullChain<2>(d, p, grid, s, evA, evB); break;
+    default: launchXformCullChain<3>(d, p, grid, s, evA, evB); break;
   }
 }
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* list, uint32_t count, hipStream_t s)
