@@ -55,6 +55,9 @@ enum {
                                       border messages; the caller exchanges them and calls scTickRunPairs */
   SC_TICK_SORT_DRAWS  = 1u << 7,   /* with DRAWS: the list comes out in the renderer's bind order (scTickSetDrawSortTable) */
   SC_TICK_RAYS        = 1u << 8,   /* with BROADPHASE: answer the ray queries set by scTickSetRayQueries against this tick's boxes */
+  SC_TICK_PRODUCE_NEXT = 1u << 9,  /* with XFORM: the frame producer (scTickSetFrameProducer) is applied at the END of this run, inside
+                                      the end-of-tick kernel, as the producer of the NEXT frame -- instead of at the start of the next
+                                      scTickRun.  Results of this run are unaffected; positions read back are already the next frame's. */
   SC_TICK_FULL        = SC_TICK_XFORM | SC_TICK_CULL | SC_TICK_BROADPHASE
 };
 

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SC_TICK_LIB") or os.path.join(HERE, "libsc_tick.so")      # SC_TICK_LIB: A/B builds (tools/)
 
 # scTickRun flags (include/sc_tick.h)
-XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS, DENSE_AABBS, SPLIT_PAIRS, SORT_DRAWS, RAYS = 1, 2, 4, 8, 16, 32, 64, 128, 256
+XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS, DENSE_AABBS, SPLIT_PAIRS, SORT_DRAWS, RAYS, PRODUCE_NEXT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 FULL = XFORM | CULL | BROADPHASE
 K_XFORM_CULL, K_COMPACT, K_PAIRS, K_NUDGE, K_COUNT = 0, 1, 2, 3, 4
 NO_PARENT = -1

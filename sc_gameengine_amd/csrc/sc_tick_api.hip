@@ -351,6 +351,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.variant = c->variant;
   p.chain = std::min(c->maxDepth, kMaxChain);
   p.bigClearWords = (c->prevBroadphaseN + 31u) >> 5;
+  if (flags & SC_TICK_PRODUCE_NEXT) { p.producerKind = c->producerKind; p.producerParam = c->producerParam; }
   p.tileX = c->tileX; p.tileZ = c->tileZ; p.tilesX = c->tilesX; p.tilesZ = c->tilesZ;
 }
 
@@ -360,7 +361,7 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
   const bool prof = allowProfile && c->profiling;
   const bool saved = c->profiling;
   c->profiling = prof;
-  if (c->producerKind) {
+  if (c->producerKind && !(flags & SC_TICK_PRODUCE_NEXT)) {
     Scoped s(c, SC_TICK_K_NUDGE);
     if (c->producerKind == 1) launchNudgeRootsX(c->d, c->n, c->producerParam, c->stream);
     else launchAdvanceMovers(c->d, c->n, c->producerParam, c->stream);
@@ -964,6 +965,10 @@ int scTickRun(ScTickContext* c, uint32_t flags)
     return 1;
   }
   if ((flags & SC_TICK_BROADPHASE) && c->desc.tile_sectors_x == 0) return fail(c, "broadphase requested but the context has no tile rectangle");
+  if (flags & SC_TICK_PRODUCE_NEXT) {
+    if (!(flags & SC_TICK_XFORM)) return fail(c, "SC_TICK_PRODUCE_NEXT needs SC_TICK_XFORM (the producer rides on the end-of-tick kernel)");
+    if (!c->producerKind) return fail(c, "SC_TICK_PRODUCE_NEXT needs scTickSetFrameProducer first");
+  }
   if ((flags & SC_TICK_RAYS) && !(flags & SC_TICK_BROADPHASE)) return fail(c, "SC_TICK_RAYS needs SC_TICK_BROADPHASE in the same run (the queries read this tick's bins)");
   if ((flags & SC_TICK_SORT_DRAWS) && !c->sort.pipeline) return fail(c, "SC_TICK_SORT_DRAWS needs scTickSetDrawSortTable first");
   TickParams p; uint32_t grid;

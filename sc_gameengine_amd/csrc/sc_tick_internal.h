@@ -27,6 +27,7 @@ constexpr uint32_t kRotTrivialX = 1u << 29, kRotTrivialY = 1u << 30, kRotTrivial
 __host__ __device__ inline uint32_t linkDepth(uint32_t lk) { return (lk >> kDepthShift) & kDepthMask; }
 
 constexpr uint32_t kTile = 256;           // entities per workgroup pass (4 waves of 64)
+constexpr uint32_t kMaxSpanWords = 128;   // spans up to 4096 entities keep the fused producer's ballots in LDS
 
 struct Frustum6 { float p[6][4]; };       // (nx, ny, nz, d) x 6, Frustum (sc_world_partition.h:39-43)
 
@@ -123,6 +124,7 @@ struct TickParams {
   uint32_t variant;         // kernel variant selector (A/B tuning; 0 = default)
   uint32_t chain;           // min(deepest hierarchy level, kMaxChain): selects the fused kernel's specialisation
   uint32_t tileX, tileZ, tilesX, tilesZ;   // this tile's place in the grid of equal tiles (tilesX == 0: unknown, no big-box exchange)
+  uint32_t producerKind; float producerParam;   // with SC_TICK_PRODUCE_NEXT: the frame producer fused into the end-of-tick kernel
   uint32_t bigClearWords;   // words of the other parity's bigBits the previous broadphase tick may have set (its entity count / 32)
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d

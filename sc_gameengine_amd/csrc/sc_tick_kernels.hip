@@ -501,6 +501,53 @@ __global__ __launch_bounds__(kTile) void k_deep_level(const DeviceState d, const
 // Same span partition as K1: workgroup b owns entities [b*span, (b+1)*span); its output offset is
 // the sum of the preceding spans' counts; inside a tile each wave places its lanes by popcount.
 // ------------------------------------------------------------------------------------------
+// ---- frame producers, one entity per lane (a wave owns exactly the two dirty words of its 64 entities) ----
+// SynthWorld dirty regime (ii): localPos.x += dx on every root, marked dirty.
+__device__ __forceinline__ bool nudgePosition(const DeviceState& d, uint32_t i, uint32_t n, float dx)
+{
+  const bool in = i < n;
+  const uint32_t lk = in ? d.link[i] : ((kUnreachable << kDepthShift) | 1u);
+  const float x = in ? d.px[i] : 0.0f;
+  const bool root = in && (lk & kParentMask) == kNoParent && linkDepth(lk) != kUnreachable;
+  if (root) d.px[i] = x + dx;
+  return root;
+}
+// a wave ORs the ballot of its 64 entities into their two dirty words
+__device__ __forceinline__ void markDirtyWave(const DeviceState& d, uint32_t i, uint32_t n, bool moved)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long m = __ballot(moved);
+  const uint32_t mine = lane < 32u ? (uint32_t)m : (uint32_t)(m >> 32);
+  if (i < n && (lane & 31u) == 0u && mine) d.dirty[i >> 5] |= mine;
+}
+// Upstream movers (include/sc_tick.h "upstream movers"): straight-line advance inside the agent's
+// sector, vehicles wrap, peds reflect.  pos + vel*dt is two roundings (no FMA), as the oracle's.
+__device__ __forceinline__ bool moverPosition(const DeviceState& d, uint32_t i, uint32_t n, float dt)
+{
+  const bool in = i < n;
+  // everything is requested at once (one round trip); non-movers just drop what they fetched
+  const uint32_t kind = in ? d.moverKind[i] : 0u;
+  float vx = 0, vz = 0, lox = 0, loz = 0, hix = 0, hiz = 0, x = 0, z = 0;
+  if (in) { vx = d.mvx[i]; vz = d.mvz[i]; lox = d.mlox[i]; loz = d.mloz[i]; hix = d.mhix[i]; hiz = d.mhiz[i]; x = d.px[i]; z = d.pz[i]; }
+  if (kind) {
+    x = x + vx * dt; z = z + vz * dt;
+    if (kind == 1u) {
+      if (x >= hix) x = lox + (x - hix); else if (x < lox) x = hix - (lox - x);
+      if (z >= hiz) z = loz + (z - hiz); else if (z < loz) z = hiz - (loz - z);
+    } else {
+      if (x > hix) { x = hix - (x - hix); vx = -vx; } else if (x < lox) { x = lox + (lox - x); vx = -vx; }
+      if (z > hiz) { z = hiz - (z - hiz); vz = -vz; } else if (z < loz) { z = loz + (loz - z); vz = -vz; }
+      d.mvx[i] = vx; d.mvz[i] = vz;
+    }
+    d.px[i] = x; d.pz[i] = z;
+  }
+  return kind != 0u;
+}
+__device__ __forceinline__ bool producePosition(const DeviceState& d, const TickParams& p, uint32_t i)
+{
+  return p.producerKind == 1u ? nudgePosition(d, i, p.n, p.producerParam) : moverPosition(d, i, p.n, p.producerParam);
+}
+
 __device__ __forceinline__ uint32_t blockSum(uint32_t v, uint32_t* scratch)
 {
 #pragma unroll
@@ -512,7 +559,7 @@ __device__ __forceinline__ uint32_t blockSum(uint32_t v, uint32_t* scratch)
   return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
-__device__ __forceinline__ void compactBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks, uint32_t* scratch)
+__device__ __forceinline__ void compactBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks, uint32_t* scratch, uint32_t* moved)
 {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
@@ -526,6 +573,19 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
   uint32_t dirtyKeep = 0; const uint32_t dirtyWord = wBegin + threadIdx.x;
   const bool clearDirty = (p.flags & SC_TICK_XFORM) && dirtyWord < wEnd;
   if (clearDirty) dirtyKeep = d.dirty[dirtyWord] & d.unreach[dirtyWord];
+
+  // SC_TICK_PRODUCE_NEXT: this tick is over for the span, so the NEXT frame's producer runs here instead of as a
+  // launch of its own.  Its position loads and stores go out first, alongside the loads above (nothing else in this
+  // kernel reads positions); the "moved" ballots wait in LDS and are OR-ed into the cleared dirty words below.
+  const bool produce = (p.flags & SC_TICK_PRODUCE_NEXT) != 0;
+  const bool produceEarly = produce && (wEnd - wBegin) <= kMaxSpanWords;
+  if (produceEarly) {
+    for (uint32_t base = begin; base < end; base += kTile) {
+      const unsigned long long m = __ballot(producePosition(d, p, base + threadIdx.x));
+      if (lane == 0) { moved[((base >> 5) - wBegin) + 2u * wave] = (uint32_t)m; moved[((base >> 5) - wBegin) + 2u * wave + 1u] = (uint32_t)(m >> 32); }
+    }
+    __syncthreads();
+  }
 
   if (doCull) {
     uint32_t pv = 0, pc = 0;
@@ -568,16 +628,25 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
   }
 
   // Transform::dirty = false for every visited entity; entities in a cycle keep theirs (sc_ecs.cpp:201)
-  if (clearDirty) d.dirty[dirtyWord] = dirtyKeep;
+  if (clearDirty) d.dirty[dirtyWord] = dirtyKeep | (produceEarly ? moved[dirtyWord - wBegin] : 0u);
   if (p.flags & SC_TICK_XFORM) {
     for (uint32_t w = wBegin + kTile + threadIdx.x; w < wEnd; w += kTile) d.dirty[w] &= d.unreach[w];   // spans wider than 8192 entities
+  }
+  // spans too wide for the LDS ballots: the producer runs behind the dirty clear, one more pass over the span
+  if (produce && !produceEarly) {
+    __syncthreads();
+    for (uint32_t base = begin; base < end; base += kTile) {
+      const uint32_t i = base + threadIdx.x;
+      markDirtyWave(d, i, p.n, producePosition(d, p, i));
+    }
   }
 }
 
 __global__ __launch_bounds__(kTile) void k_compact(const DeviceState d, const TickParams p)
 {
   __shared__ uint32_t scratch[kTile / 64];
-  compactBody(d, p, blockIdx.x, gridDim.x, scratch);
+  __shared__ uint32_t moved[kMaxSpanWords];
+  compactBody(d, p, blockIdx.x, gridDim.x, scratch, moved);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -945,7 +1014,8 @@ __global__ __launch_bounds__(kTile) void k_compact_pairs(const DeviceState d, co
   __shared__ uint2 pairBuf[kTile / 64][kWavePairBuf];
   __shared__ unsigned long long cellMembers[kTile / 64][16];
   __shared__ uint32_t scratch[kTile / 64];
-  if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, scratch);
+  __shared__ uint32_t moved[kMaxSpanWords];
+  if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, scratch, moved);
   else pairsBody(d, p, blockIdx.x - compactBlocks, gridDim.x - compactBlocks, tile, pairTab, pairBuf, cellMembers);
 }
 
@@ -1177,34 +1247,10 @@ __global__ __launch_bounds__(kTile) void k_dense_aabbs(const DeviceState d, uint
   d.aabbMax[i] = make_float4(mx[0], mx[1], mx[2], 0.0f);
 }
 
-// Upstream movers (include/sc_tick.h "upstream movers"): straight-line advance inside the agent's
-// sector, vehicles wrap, peds reflect.  pos + vel*dt is two roundings (no FMA), as the oracle's.
 __global__ __launch_bounds__(kTile) void k_advance_movers(const DeviceState d, uint32_t n, float dt)
 {
   const uint32_t i = blockIdx.x * kTile + threadIdx.x;
-  const uint32_t lane = threadIdx.x & 63u;
-  const bool in = i < n;
-  // everything is requested at once (one round trip); non-movers just drop what they fetched
-  const uint32_t kind = in ? d.moverKind[i] : 0u;
-  float vx = 0, vz = 0, lox = 0, loz = 0, hix = 0, hiz = 0, x = 0, z = 0;
-  if (in) { vx = d.mvx[i]; vz = d.mvz[i]; lox = d.mlox[i]; loz = d.mloz[i]; hix = d.mhix[i]; hiz = d.mhiz[i]; x = d.px[i]; z = d.pz[i]; }
-  uint32_t dw = 0;
-  if (in && (lane & 31u) == 0u) dw = d.dirty[i >> 5];
-  if (kind) {
-    x = x + vx * dt; z = z + vz * dt;
-    if (kind == 1u) {
-      if (x >= hix) x = lox + (x - hix); else if (x < lox) x = hix - (lox - x);
-      if (z >= hiz) z = loz + (z - hiz); else if (z < loz) z = hiz - (loz - z);
-    } else {
-      if (x > hix) { x = hix - (x - hix); vx = -vx; } else if (x < lox) { x = lox + (lox - x); vx = -vx; }
-      if (z > hiz) { z = hiz - (z - hiz); vz = -vz; } else if (z < loz) { z = loz + (loz - z); vz = -vz; }
-      d.mvx[i] = vx; d.mvz[i] = vz;
-    }
-    d.px[i] = x; d.pz[i] = z;
-  }
-  const unsigned long long m = __ballot(kind != 0u);
-  const uint32_t mine = lane < 32u ? (uint32_t)m : (uint32_t)(m >> 32);
-  if (in && (lane & 31u) == 0u && mine) d.dirty[i >> 5] = dw | mine;
+  markDirtyWave(d, i, n, moverPosition(d, i, n, dt));
 }
 
 __global__ __launch_bounds__(kTile) void k_set_dirty_range(const DeviceState d, uint32_t first, uint32_t count)

@@ -283,3 +283,51 @@ def test_maximum_size_16m_entities():
     _, n2 = t.pairs()
     assert np.array_equal(t.visible(), vis) and n2 == n1
     t.close()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_next_frame_producer_fused_into_the_end_of_tick_kernel(oracle, graph):
+    """SC_TICK_PRODUCE_NEXT: frame k's results are what producer-then-tick gives; the positions read back afterwards
+    are already frame k+1's (the producer ran at the end of the run, on the spans of the end-of-tick kernel)."""
+    w = sw.config("config2")
+    ow = worlds.oracle_world(oracle, w, camera=True)
+    t = WorldTick.from_world(w, broadphase=True)
+    vp = camera_view_proj(w.camera)
+    t.set_view_proj(vp)
+    t.set_frame_producer(1, 0.37)
+    t.set_graph_mode(graph)
+    t.nudge_roots_x(0.37)                                  # frame 1's producer, explicitly
+    for k in range(4):
+        ow.nudge_roots_x(0.37)
+        ow.transform_system(); ow.culling_system(view_proj=vp)
+        t.run(capi.FULL | capi.PRODUCE_NEXT)
+        assert_mats_equal(t.world_matrices(), ow.world_matrices()[:w.n])
+        assert np.array_equal(t.visible(), ow.visible())
+        # every root is already dirty again and one step further along x
+        roots = w.parent < 0
+        assert (t.dirty()[roots] == 1).all() and (t.dirty()[~roots] == 0).all()
+        want_x = w.pos[:, 0].copy()
+        for _ in range(k + 2):
+            want_x[roots] = (want_x[roots] + np.float32(0.37)).astype(np.float32)
+        assert np.array_equal(t.positions()[:, 0], want_x)
+    assert t.lib.scTickRun(t.ctx, capi.CULL | capi.PRODUCE_NEXT) == 0          # needs XFORM
+    t.close(); ow.close()
+
+
+def test_next_frame_movers_fused(oracle):
+    w = sw.generate_config5(8, 8)
+    ow = worlds.oracle_world(oracle, w, camera=True)
+    t = WorldTick.from_world(w, broadphase=True)
+    vp = camera_view_proj(w.camera)
+    t.set_view_proj(vp)
+    dt = 1.0 / 60.0
+    t.set_frame_producer(2, dt)
+    vel = w.mover_vel.copy()
+    t.advance_movers(dt)
+    for k in range(30):
+        ow.advance_movers(w.mover_kind, vel, w.mover_lo, w.mover_hi, dt)
+        ow.transform_system(); ow.culling_system(view_proj=vp)
+        t.run(capi.FULL | capi.PRODUCE_NEXT)
+        assert_mats_equal(t.world_matrices(), ow.world_matrices()[:w.n])
+        assert np.array_equal(t.visible(), ow.visible())
+    t.close(); ow.close()
