@@ -559,12 +559,16 @@ __device__ __forceinline__ uint32_t blockSum(uint32_t v, uint32_t* scratch)
   return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
-__device__ __forceinline__ void compactBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks, uint32_t* scratch, uint32_t* moved)
+// `group`: how many of the fused kernel's spans one compaction workgroup takes (their counts are summed here; fewer,
+// longer workgroups keep the whole end-of-tick kernel resident at once).
+__device__ __forceinline__ void compactBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks, uint32_t group,
+                                            uint32_t* scratch, uint32_t* moved)
 {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t begin = bid * p.span;
-  const uint32_t end = (begin + p.span < p.n) ? begin + p.span : p.n;
+  const uint32_t width = p.span * group;
+  const uint32_t begin = bid * width;
+  const uint32_t end = (begin + width < p.n) ? begin + width : p.n;
   const bool doCull = (p.flags & SC_TICK_CULL) != 0;
   const bool doCulled = (p.flags & SC_TICK_CULLED_LIST) != 0;
 
@@ -589,12 +593,13 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
 
   if (doCull) {
     uint32_t pv = 0, pc = 0;
-    for (uint32_t j = threadIdx.x; j < bid; j += kTile) { pv += d.blockVis[j]; pc += d.blockCand[j]; }
+    for (uint32_t j = threadIdx.x; j < bid * group; j += kTile) { pv += d.blockVis[j]; pc += d.blockCand[j]; }
     uint32_t visBase = blockSum(pv, scratch);
     uint32_t culBase = blockSum(pc, scratch) - visBase;
     if (bid == nblocks - 1 && threadIdx.x == 0) {
-      const uint32_t tv = visBase + d.blockVis[bid];
-      const uint32_t tc = culBase + visBase + d.blockCand[bid];
+      uint32_t tv = visBase, tc = culBase + visBase;
+      const uint32_t spans = (p.n + p.span - 1u) / p.span;
+      for (uint32_t j = bid * group; j < spans; ++j) { tv += d.blockVis[j]; tc += d.blockCand[j]; }
       d.counters[0] = tv;            // CullingStats::visible
       d.counters[1] = tc - tv;       // CullingStats::culled
       d.counters[6] = tc;            // renderablesTotal
@@ -642,11 +647,11 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
   }
 }
 
-__global__ __launch_bounds__(kTile) void k_compact(const DeviceState d, const TickParams p)
+__global__ __launch_bounds__(kTile) void k_compact(const DeviceState d, const TickParams p, uint32_t group)
 {
   __shared__ uint32_t scratch[kTile / 64];
   __shared__ uint32_t moved[kMaxSpanWords];
-  compactBody(d, p, blockIdx.x, gridDim.x, scratch, moved);
+  compactBody(d, p, blockIdx.x, gridDim.x, group, scratch, moved);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1007,7 +1012,7 @@ __global__ __launch_bounds__(kTile) void k_gather_pairs(const DeviceState d, con
 }
 
 // compaction and pair search both depend only on the fused kernel: one launch, workgroups split by role
-__global__ __launch_bounds__(kTile) void k_compact_pairs(const DeviceState d, const TickParams p, uint32_t compactBlocks)
+__global__ __launch_bounds__(kTile) void k_compact_pairs(const DeviceState d, const TickParams p, uint32_t compactBlocks, uint32_t group)
 {
   __shared__ float4 tile[kTile / 64][2 * kBinCap];
   __shared__ uint16_t pairTab[kPairTabSize];
@@ -1015,7 +1020,7 @@ __global__ __launch_bounds__(kTile) void k_compact_pairs(const DeviceState d, co
   __shared__ unsigned long long cellMembers[kTile / 64][16];
   __shared__ uint32_t scratch[kTile / 64];
   __shared__ uint32_t moved[kMaxSpanWords];
-  if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, scratch, moved);
+  if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, group, scratch, moved);
   else pairsBody(d, p, blockIdx.x - compactBlocks, gridDim.x - compactBlocks, tile, pairTab, pairBuf, cellMembers);
 }
 
@@ -1378,9 +1383,19 @@ void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* 
   if (!count) return;
   hipLaunchKernelGGL(k_deep_level, dim3((count + kTile - 1) / kTile), dim3(kTile), 0, s, d, p, list, count);
 }
+// spans of the fused kernel per compaction workgroup (SC_TICK_VARIANT bits 4..6 override, tuning)
+// Measured at 1M entities (1536 spans): alone, one span per workgroup is fastest (8.2 us; 9.2 / 10.9 with 2 / 4 -- the
+// tiles of a workgroup are walked one after the other); sharing the launch with the pair search, two spans per
+// workgroup win (10.5 us against 11.3 / 12.2 with 1 / 4): fewer workgroups leave room for the pair role's.
+static uint32_t compactGroup(const TickParams& p, uint32_t grid, bool merged)
+{
+  const uint32_t forced = (p.variant >> 4) & 7u;
+  return forced ? forced : ((merged && grid >= 512u) ? 2u : 1u);
+}
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_compact, dim3(grid), dim3(kTile), 0, s, d, p);
+  const uint32_t g = compactGroup(p, grid, false);
+  hipLaunchKernelGGL(k_compact, dim3((grid + g - 1) / g), dim3(kTile), 0, s, d, p, g);
 }
 void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s)
 {
@@ -1397,7 +1412,9 @@ void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t comp
   uint32_t pairGrid = (sectors + 3u) / 4u;
   const uint32_t cap = (p.variant >> 8) ? (p.variant >> 8) : 1024u;
   if (pairGrid > cap) pairGrid = cap;
-  hipLaunchKernelGGL(k_compact_pairs, dim3(compactGrid + pairGrid), dim3(kTile), 0, s, d, p, compactGrid);
+  const uint32_t g = compactGroup(p, compactGrid, true);
+  const uint32_t blocks = (compactGrid + g - 1) / g;
+  hipLaunchKernelGGL(k_compact_pairs, dim3(blocks + pairGrid), dim3(kTile), 0, s, d, p, blocks, g);
 }
 void launchGatherPairs(const DeviceState& d, const TickParams& p, uint32_t parity, uint2* dst, uint32_t* total, hipStream_t s)
 {
