@@ -306,3 +306,47 @@ def test_whole_sectors_of_a_hierarchical_world_stream_without_relinking(oracle):
     tw.tick_and_compare()
     assert tw.t.counts().relinks == relinks0 + 1
     tw.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_residency_sequences(oracle, seed):
+    """Random mix of despawns (arbitrary entities: leaves, parents, whole or partial subtrees), activations (roots, children
+    of survivors, children of batch-mates), moves and ticks; everything is compared after every tick."""
+    rng = np.random.default_rng(500 + seed)
+    w = worlds.random_world(int(rng.integers(600, 2500)), seed=200 + seed, spread=float(rng.choice([80.0, 300.0])),
+                            max_depth=int(rng.integers(1, 6)), zero_scales=3)
+    tw = Twin(oracle, w, capacity=8192, max_pairs=1 << 18)
+    tw.tick_and_compare()
+    for step in range(8):
+        n = tw.ow.count()
+        op = rng.integers(0, 4)
+        if op in (0, 1) and n > 200:
+            k = int(rng.integers(1, min(n // 3, 150)))
+            if op == 0:
+                idx = rng.choice(n, k, replace=False)
+            else:                                                   # a tail-heavy batch: many removals need no move
+                idx = np.unique(np.concatenate([np.arange(n - k // 2, n), rng.choice(n, k // 2 + 1, replace=False)]))
+                rng.shuffle(idx)
+            tw.remove(idx)
+        if op in (1, 2, 3):
+            k = int(rng.integers(1, 80))
+            n = tw.ow.count()
+            parent = None
+            if op != 2:
+                parent = np.full(k, -1, np.int32)
+                sel = rng.random(k) < 0.5
+                parent[sel] = rng.integers(0, n + k, int(sel.sum()))
+                parent[parent == n + np.arange(k)] = -1             # no self parents
+            pos = rng.uniform(-250, 250, (k, 3)).astype(np.float32)
+            tw.append(pos, rng.uniform(-3, 3, (k, 3)).astype(np.float32), rng.uniform(0.3, 2.5, (k, 3)).astype(np.float32),
+                      mesh=rng.integers(0, 5, k).astype(np.uint32), material=rng.integers(0, 5, k).astype(np.uint32), parent=parent,
+                      group=rng.choice(np.array([1, 2], np.uint32), k), mask=rng.choice(np.array([0xFFFFFFFF, 1], np.uint32), k))
+        # gameplay moves a few entities
+        n = tw.ow.count()
+        ids = np.sort(rng.choice(n, min(n, 40), replace=False)).astype(np.uint32)
+        newp = rng.uniform(-250, 250, (len(ids), 3)).astype(np.float32)
+        tw.ow.set_local_positions(tw.ow.dense_entities()[ids], newp)
+        for j in range(len(ids)):
+            tw.t.upload_positions(int(ids[j]), newp[j:j + 1])
+        tw.tick_and_compare()
+    tw.close()
