@@ -330,6 +330,13 @@ int scTickSetRayQueries(ScTickContext* ctx, uint32_t count, const float* origin3
 /* results of the last scTickRun(... | SC_TICK_BROADPHASE | SC_TICK_RAYS) (after scTickRunPairs on a tiled world) */
 int scTickReadRayHits(ScTickContext* ctx, ScTickRayHit* hits, uint32_t capacity, uint32_t* count);
 
+/* isOccupiedWorld (src/engine/traffic/sc_traffic_spawner.cpp:93-116), for a batch of at most 256 points: blocked[k] = 1
+ * when some entity whose collision group meets mask[k] has dx*dx + dz*dz < radius[k]*radius[k] to point k, measured on
+ * Transform::localPos in the xz plane like the reference (which walks its TrafficAgent and VehicleComponent pools; the
+ * group mask selects the same entities here).  Answers from the positions as they are on the device now; synchronises. */
+int scTickQueryOccupied(ScTickContext* ctx, uint32_t count, const float* pos3, const float* radius, const uint32_t* mask,
+                        uint8_t* blocked);
+
 /* ---- measurement ---- */
 /* record HIP events around the kernel launches (on the context's stream) of every `enable`-th tick
  * from now on (1 = every tick; event records cost host time, so long runs sample); 0 = stop */

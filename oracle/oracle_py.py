@@ -109,6 +109,9 @@ def lib():
     L.orc_broadphase_grid.restype = C.c_uint64
     L.orc_tick.argtypes = [vp, C.POINTER(CameraState), C.POINTER(CullingState)]
     L.orc_advance_movers.argtypes = [vp, U8P, F32P, F32P, F32P, C.c_float]
+    L.orc_is_occupied.argtypes = [vp, U8P, F32P, C.c_float]
+    L.orc_is_occupied.restype = C.c_int
+    L.orc_raycast_boxes.argtypes = [C.c_uint32, F32P, F32P, U32P, U32P, C.c_uint32, F32P, F32P, F32P, U32P, C.c_void_p]
     _LIB = L
     return L
 
@@ -406,6 +409,11 @@ class OracleWorld:
         mat = np.array([buf[i].materialId for i in range(n)], np.uint32)
         model = np.array([buf[i].model[:] for i in range(n)], np.float32).reshape(n, 16)
         return ent, mesh, mat, model, int(dropped.value)
+
+    def is_occupied(self, is_agent, pos, radius):
+        a = np.ascontiguousarray(is_agent, np.uint8)
+        p3 = _c32(pos)
+        return int(self.L.orc_is_occupied(self.w, a.ctypes.data_as(U8P), _f(p3), float(radius)))
 
     def renderer_draw_order(self, pipeline_of_material, mesh_count):
         """Indices into the last draw_items() list in the renderer's bind order (sc_vk.cpp:1842-1864), stable."""

@@ -876,6 +876,21 @@ void orc_raycast_boxes(uint32_t n, const float* min3, const float* max3, const u
   }
 }
 
+/* isOccupiedWorld, src/engine/traffic/sc_traffic_spawner.cpp:93-116 (distanceSq2d :66-71): some agent with
+ * dx*dx + dz*dz < radius*radius on Transform::localPos.  The reference walks its TrafficAgent and VehicleComponent pools;
+ * agents are given here as a flag per Transform-pool entity. */
+int orc_is_occupied(OrcWorld* w, const uint8_t* isAgent, const float pos[3], float radius)
+{
+  const OrcTransform* d = (const OrcTransform*)w->transforms.data;
+  const float r2 = radius * radius;
+  for (uint32_t i = 0; i < w->transforms.size; ++i) {
+    if (!isAgent[i]) continue;
+    const float dx = d[i].localPos[0] - pos[0], dz = d[i].localPos[2] - pos[2];
+    if (dx * dx + dz * dz < r2) return 1;
+  }
+  return 0;
+}
+
 /* sc_world_partition.cpp:268-275 */
 void orc_world_to_sector(float sectorSize, float x, float z, int32_t* sx, int32_t* sz)
 {

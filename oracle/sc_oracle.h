@@ -175,6 +175,9 @@ void orc_raycast_boxes(uint32_t n, const float* min3, const float* max3, const u
                        uint32_t rays, const float* origin3, const float* dir3, const float* maxDist, const uint32_t* rayMask,
                        OrcRayHit* out);
 
+/* isOccupiedWorld (sc_traffic_spawner.cpp:93-116); isAgent flags the entities of the TrafficAgent / VehicleComponent pools */
+int orc_is_occupied(OrcWorld* w, const uint8_t* isAgent, const float pos[3], float radius);
+
 /* ---- upstream movers (own spec, include/sc_tick.h "upstream movers"; model after the on-rails tier,
  *      sc_traffic_ai.cpp:434-460): dense-order arrays; vel is updated in place for reflecting peds ---- */
 void orc_advance_movers(OrcWorld* w, const uint8_t* kind, float* vel_xz2, const float* lo_xz2, const float* hi_xz2, float dt);

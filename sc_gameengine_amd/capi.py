@@ -110,6 +110,7 @@ SYMBOLS = {
     "scTickReadDraws": (C.c_int, [_CTX, C.POINTER(DrawItem), C.c_uint32, U32P]),
     "scTickSetRayQueries": (C.c_int, [_CTX, C.c_uint32, F32P, F32P, F32P, U32P]),
     "scTickReadRayHits": (C.c_int, [_CTX, C.POINTER(RayHit), C.c_uint32, U32P]),
+    "scTickQueryOccupied": (C.c_int, [_CTX, C.c_uint32, F32P, F32P, U32P, U8P]),
     "scTickSetProfiling": (C.c_int, [_CTX, C.c_int]),
     "scTickGetKernelTimes": (C.c_int, [_CTX, C.c_uint32, F32P, C.c_uint32, U32P]),
     "scTickSetGraphMode": (C.c_int, [_CTX, C.c_int]),

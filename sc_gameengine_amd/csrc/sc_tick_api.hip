@@ -1358,6 +1358,30 @@ int scTickReadRayHits(ScTickContext* c, ScTickRayHit* hits, uint32_t cap, uint32
   return 1;
 }
 
+int scTickQueryOccupied(ScTickContext* c, uint32_t count, const float* pos3, const float* radius, const uint32_t* mask, uint8_t* blocked)
+{
+  if (!c) return 0;
+  if (count && (!pos3 || !radius || !mask || !blocked)) return fail(c, "null argument");
+  if (count > kMaxOccupancyQueries) return fail(c, "at most 256 occupancy queries per call");
+  if (!bind(c)) return 0;
+  if (!count) return 1;
+  std::memset(blocked, 0, count);
+  if (!c->n) return 1;
+  // queries (16 B each) and the answer bits share the scratch row buffer
+  if (!needScratch(c, kMaxOccupancyQueries)) return 0;
+  std::vector<float4> q(count);
+  for (uint32_t k = 0; k < count; ++k) { float w; std::memcpy(&w, &mask[k], 4); q[k] = make_float4(pos3[3 * k], pos3[3 * k + 2], radius[k], w); }
+  float4* dq = reinterpret_cast<float4*>(c->dRows);
+  uint32_t* bits = c->dIdx;
+  uint32_t out[kMaxOccupancyQueries / 32] = {};
+  HIP_OK(c, hipMemsetAsync(bits, 0, sizeof out, c->stream));
+  if (!h2d(c, dq, q.data(), (size_t)count * 16u)) return 0;
+  launchOccupancy(c->d, c->n, dq, count, bits, c->stream);
+  if (!d2h(c, out, bits, sizeof out) || !sync(c)) return 0;
+  for (uint32_t k = 0; k < count; ++k) blocked[k] = (uint8_t)((out[k >> 5] >> (k & 31u)) & 1u);
+  return 1;
+}
+
 int scTickSetProfiling(ScTickContext* c, int enable)
 {
   if (!c) return 0;

@@ -163,6 +163,8 @@ struct RayQueryState {
   uint32_t count;
 };
 void launchRayQueries(const DeviceState& d, const TickParams& p, const RayQueryState& q, hipStream_t s);
+constexpr uint32_t kMaxOccupancyQueries = 256;
+void launchOccupancy(const DeviceState& d, uint32_t n, const float4* q, uint32_t count, uint32_t* blocked, hipStream_t s);
 
 // launchers (sc_tick_kernels.hip)
 void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA = nullptr, hipEvent_t evB = nullptr);

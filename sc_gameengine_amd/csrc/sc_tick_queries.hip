@@ -126,7 +126,36 @@ __global__ __launch_bounds__(kTile) void k_ray_queries(const DeviceState d, cons
   }
 }
 
+// isOccupiedWorld (src/engine/traffic/sc_traffic_spawner.cpp:93-116): is any agent closer than `radius` to the point, in the
+// xz plane, by Transform::localPos -- dx*dx + dz*dz < radius*radius, strictly.  The reference walks the TrafficAgent and
+// VehicleComponent pools; here an entity counts when its collision group meets the query's mask.  A handful of
+// queries per frame (spawn attempts) against every entity: one thread per entity, all queries from LDS.
+__global__ __launch_bounds__(kTile) void k_occupancy(const DeviceState d, uint32_t n, const float4* __restrict__ q, uint32_t count,
+                                                     uint32_t* __restrict__ blocked)
+{
+  __shared__ float4 sq[kMaxOccupancyQueries];
+  for (uint32_t k = threadIdx.x; k < count; k += kTile) sq[k] = q[k];
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kTile + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t group = d.layers[i] & 0xFFFFu;
+  if (!group) return;
+  const float x = d.px[i], z = d.pz[i];
+  for (uint32_t k = 0; k < count; ++k) {
+    const float4 c = sq[k];                              // (x, z, radius, mask)
+    if (!(group & __float_as_uint(c.w))) continue;
+    const float dx = x - c.x, dz = z - c.y;
+    if (dx * dx + dz * dz < c.z * c.z) atomicOr(&blocked[k >> 5], 1u << (k & 31u));
+  }
+}
+
 } // namespace
+
+void launchOccupancy(const DeviceState& d, uint32_t n, const float4* q, uint32_t count, uint32_t* blocked, hipStream_t s)
+{
+  if (!n || !count) return;
+  hipLaunchKernelGGL(k_occupancy, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, q, count, blocked);
+}
 
 void launchRayQueries(const DeviceState& d, const TickParams& p, const RayQueryState& q, hipStream_t s)
 {

@@ -217,6 +217,14 @@ class WorldTick:
                        ("normal", np.float32, 3), ("layer", np.uint32), ("pad", np.uint32, 2)])
         return np.frombuffer(buf, dtype=dt, count=n.value).copy()
 
+    def occupied(self, pos, radius, mask):
+        """isOccupiedWorld for a batch of points (sc_traffic_spawner.cpp:93-116); returns a uint8 array."""
+        p, r = _c32(pos).reshape(-1, 3), _c32(radius).reshape(-1)
+        m = np.ascontiguousarray(mask, np.uint32).reshape(-1)
+        out = np.zeros(len(p), np.uint8)
+        self._ok(self.lib.scTickQueryOccupied(self.ctx, len(p), _f(p), _f(r), _u(m), out.ctypes.data_as(capi.U8P)), "scTickQueryOccupied")
+        return out
+
     def set_draw_sort_table(self, pipeline_of_material, mesh_count):
         """Material::pipelineId per material handle (0xFF = no such material) and the number of mesh handles:
         what the renderer's filter + sort of the draw list reads (sc_vk.cpp:1842-1864)."""

@@ -161,3 +161,41 @@ def test_ray_api_errors():
     assert t.lib.scTickSetRayQueries(t.ctx, 3, None, None, None, None) == 0
     assert t.lib.scTickSetRayQueries(None, 0, None, None, None, None) == 0
     t.close()
+
+
+def test_occupancy_queries_match_is_occupied_world(oracle):
+    """scTickQueryOccupied against the oracle's isOccupiedWorld (sc_traffic_spawner.cpp:93-116) on a config-5 world whose
+    vehicles keep moving: points on, near and far from agents, radii around the decision boundary, strict '<'."""
+    w = sw.generate_config5(8, 8)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    t = WorldTick.from_world(w, broadphase=True)
+    rng = np.random.default_rng(71)
+    veh = np.flatnonzero(w.mover_kind == 1)
+    is_agent = (w.mover_kind == 1).astype(np.uint8)                 # vehicles: group 1; peds share the group, so give them another
+    w.group[w.mover_kind == 2] = 4
+    t.upload_layers(0, w.group, w.mask)
+    vel = w.mover_vel.copy()
+    for rnd in range(3):
+        ow.advance_movers(w.mover_kind, vel, w.mover_lo, w.mover_hi, 1.0 / 60.0)
+        t.advance_movers(1.0 / 60.0)
+        pos_now = t.positions()
+        k = 200
+        pts = rng.uniform(0, 512, (k, 3)).astype(np.float32)
+        near = rng.choice(veh, 120, replace=False)
+        pts[:120] = pos_now[near] + rng.uniform(-3, 3, (120, 3)).astype(np.float32)
+        radius = rng.uniform(0.5, 6.0, k).astype(np.float32)
+        # exactly on the boundary: distance == radius must NOT block
+        pts[0] = pos_now[near[0]] + np.float32([3.0, 0.0, 4.0]); radius[0] = 5.0
+        pts[1] = pos_now[near[1]]; radius[1] = 0.0
+        mask = np.full(k, 1, np.uint32)
+        got = t.occupied(pts, radius, mask)
+        want = np.array([ow.is_occupied(is_agent, pts[j], radius[j]) for j in range(k)], np.uint8)
+        assert np.array_equal(got, want)
+        assert 20 < want.sum() < k and want[1] == 0
+        # the group mask selects the agents: nothing has group 8; peds (group 4) answer for themselves
+        assert t.occupied(pts, radius, np.full(k, 8, np.uint32)).sum() == 0
+    peds = np.flatnonzero(w.mover_kind == 2)
+    p = t.positions()[peds[:5]]
+    assert (t.occupied(p, np.full(5, 0.1, np.float32), np.full(5, 4, np.uint32)) == 1).all()
+    assert t.lib.scTickQueryOccupied(t.ctx, 300, None, None, None, None) == 0
+    t.close(); ow.close()
