@@ -66,40 +66,50 @@ def exchange(send, recv, rank, grid, group=None):
 
 
 class BorderBuffers:
-    """Device message buffers of one tile, owned here (torch tensors) and bound into the context."""
+    """Device message buffers of one tile, owned here (torch tensors) and bound into the context.
 
-    def __init__(self, tick, rank, grid, device):
+    All outgoing messages live in ONE tensor, ordered by destination rank, and all incoming ones in another, ordered by
+    source rank, so that on RCCL the whole exchange is a single `all_to_all_single` with per-rank split sizes (zero for
+    ranks that are not neighbours): one torch operation per step instead of two per neighbour -- the host side of a
+    batched isend/irecv group costs about 25 us per operation, 200 us for eight neighbours, four ticks' worth.
+    send[d] / recv[d] are views of those tensors per direction (what the single-GPU tile tests copy between contexts)."""
+
+    def __init__(self, tick, rank, grid, device, world_size=None):
         import torch
         self.rank, self.grid = rank, grid
         self.send, self.recv = {}, {}
         tick.set_tile(rank, neighbour_mask(rank, grid))
         tx, tz = tile_of(rank, grid)
         tick.set_tile_grid(tx, tz, grid[0], grid[1])      # big boxes travel in the border messages too
-        for d in neighbours(rank, grid):
-            nbytes = tick.border_bytes(d)
-            self.send[d] = torch.zeros(nbytes // 4, dtype=torch.int32, device=device)
-            self.recv[d] = torch.zeros(nbytes // 4, dtype=torch.int32, device=device)
+        nb = neighbours(rank, grid)
+        ranks = grid[0] * grid[1] if world_size is None else world_size
+        words = {d: tick.border_bytes(d) // 4 for d in nb}
+        self.splits = [0] * ranks                          # the same both ways: the message from the neighbour in direction d
+        for d, r in nb.items():                            # is its direction 7-d message, which has the same side length
+            self.splits[r] = words[d]
+        total = max(sum(self.splits), 1)
+        self.send_all = torch.zeros(total, dtype=torch.int32, device=device)
+        self.recv_all = torch.zeros(total, dtype=torch.int32, device=device)
+        offset = {}
+        at = 0
+        for r in range(ranks):
+            offset[r] = at
+            at += self.splits[r]
+        for d, r in nb.items():
+            self.send[d] = self.send_all[offset[r]:offset[r] + words[d]]
+            self.recv[d] = self.recv_all[offset[r]:offset[r] + words[d]]
             tick.bind_border(d, self.send[d].data_ptr(), self.recv[d].data_ptr())
 
-        self._ops = None
-
     def exchange(self, group=None):
-        """Per-step exchange.  On RCCL the batched op list is built once and reused (the tensors are
-        persistent), which keeps the per-step host cost to one batch_isend_irecv call."""
+        """Per-step exchange: one all-to-all with split sizes on RCCL; point-to-point staging elsewhere (gloo has no
+        all-to-all; it is only used for rehearsals and CPU tests)."""
         import torch.distributed as dist
-        nb = neighbours(self.rank, self.grid)
-        if not nb:
+        if not neighbours(self.rank, self.grid):
             return
         if dist.get_backend(group) != "nccl":
             exchange(self.send, self.recv, self.rank, self.grid, group)
             return
-        if self._ops is None:
-            self._ops = []
-            for d in sorted(nb):
-                self._ops.append(dist.P2POp(dist.isend, self.send[d], nb[d], group=group))
-                self._ops.append(dist.P2POp(dist.irecv, self.recv[d], nb[d], group=group))
-        for w in dist.batch_isend_irecv(self._ops):
-            w.wait()
+        dist.all_to_all_single(self.recv_all, self.send_all, self.splits, self.splits, group=group)
 
 
 def global_pair_ids(pairs, entities_per_rank):
