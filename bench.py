@@ -123,6 +123,7 @@ def main():
                          "config5: 16 static + 12 vehicles + 4 peds per sector, agents advanced on device each step")
     ap.add_argument("--sample", type=int, default=8, help="record HIP events on every n-th step (1 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1, help="N>1: pair-search half of tick t on a second stream under the fused kernel of tick t+1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -180,12 +181,18 @@ def main():
     # torch's current stream so the RCCL send/recv group is stream-ordered with the kernels around it
     # (no host synchronisation inside a step).
     borders = None
-    tick_stream = None
+    tick_stream = pairs_stream = None
     if world_size > 1 and (flags & capi.BROADPHASE):
         tick_stream = torch.cuda.Stream(device=local_rank)
         torch.cuda.set_stream(tick_stream)            # torch's current stream for everything below, RCCL ops included
         t.set_stream(tick_stream.cuda_stream, external=True)
-        borders = tiles.BorderBuffers(t, rank, grid, torch.device("cuda", local_rank))
+        if args.pipeline:
+            # the exchange, the merge and the pair search of tick t go to a second stream and run under the fused kernel of
+            # tick t+1 (bins and messages are double-buffered by tick parity; the library orders the halves with events)
+            pairs_stream = torch.cuda.Stream(device=local_rank)
+            t.set_pairs_stream(pairs_stream.cuda_stream)
+        borders = tiles.BorderBuffers(t, rank, grid, torch.device("cuda", local_rank), pipelined=bool(args.pipeline))
+    tick_parity = [0]
 
     # The frame producer (config 3: every root nudged; config 5: vehicles and peds advanced) is part of every step.  It
     # runs fused into the end-of-tick kernel as the producer of the NEXT frame (SC_TICK_PRODUCE_NEXT): same work per
@@ -201,10 +208,16 @@ def main():
     def step():
         if borders is None:
             t.run(flags)
+            return
+        t.run(flags | capi.SPLIT_PAIRS)           # ... bins filled, border messages packed, next frame produced
+        if pairs_stream is None:
+            borders.exchange()                    # neighbour messages over RCCL (xGMI), one all-to-all
         else:
-            t.run(flags | capi.SPLIT_PAIRS)       # ... bins filled, border messages packed, next frame produced
-            borders.exchange()                    # neighbour send/recv over RCCL (xGMI)
-            t.run_pairs()                         # merge what arrived, pair search
+            pairs_stream.wait_stream(tick_stream)
+            with torch.cuda.stream(pairs_stream):
+                borders.exchange(parity=tick_parity[0])
+            tick_parity[0] ^= 1
+        t.run_pairs()                             # merge what arrived, pair search (on the pairs stream when pipelined)
 
     def fence():
         t.sync()
@@ -233,6 +246,9 @@ def main():
             borders = None
             stages = [x for x in stages if x != "broadphase"]
             flags &= ~capi.BROADPHASE
+            if pairs_stream is not None:
+                t.set_pairs_stream(0)
+                pairs_stream = None
             t.set_stream(0, external=False)
     for _ in range(args.warmup):
         step()
@@ -290,7 +306,8 @@ def main():
                 "visible": int(counts.visible),
                 "pairs": int(counts.pairs),
                 "graph": bool(args.graph),
-                "exchange": (exchange_note or ("border AABBs, RCCL send/recv to <=8 neighbour tiles per step" if borders is not None else "none")),
+                "pipelined": bool(pairs_stream is not None),
+                "exchange": (exchange_note or ("border AABBs to <=8 neighbour tiles per step, one RCCL all-to-all with split sizes" if borders is not None else "none")),
                 "resident": "device SoA authoritative; no per-step host transfer",
                 "backend": args.backend if world_size > 1 else None,
                 "rehearsal_same_device": bool(args.same_device),

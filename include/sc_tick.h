@@ -188,6 +188,16 @@ uint32_t scTickBorderBytes(ScTickContext* ctx, uint32_t direction);
 /* caller-owned device buffers (e.g. torch tensors) of at least scTickBorderBytes(d) bytes each */
 int scTickBindBorderBuffers(ScTickContext* ctx, uint32_t direction, void* send_device_ptr, void* recv_device_ptr);
 int scTickRunPairs(ScTickContext* ctx);
+/* Pipelined tiles.  With a pairs stream set (hipStream_t; NULL switches it off), scTickRunPairs queues the merge, the ray
+ * queries and the pair search of tick t on THAT stream, and the next scTickRun may start its fused kernel while they run:
+ * everything the two halves share -- bins, big list, spill list, border messages -- exists twice, selected by tick parity
+ * (counters, big-box bits and the pair output already are).  The library orders the halves with events: the pair half waits
+ * for the pack of its tick, and the end-of-tick kernel of tick t+1, which clears tick t's broadphase state for tick t+2,
+ * waits for the pair half of tick t.  The caller issues the exchange of tick t on the pairs stream after making that stream
+ * wait for the tick stream (border buffers of tick parity t & 1: scTickBindBorderBuffersParity), then calls scTickRunPairs.
+ * Results of tick t stay readable until the next scTickRun.  Not combinable with graph replay. */
+int scTickSetPairsStream(ScTickContext* ctx, void* hip_stream);
+int scTickBindBorderBuffersParity(ScTickContext* ctx, uint32_t parity, uint32_t direction, void* send_device_ptr, void* recv_device_ptr);
 /* external != 0: run all device work of this context on the caller's stream `hip_stream` (hipStream_t;
  * NULL is the legacy default stream), e.g. the stream its RCCL calls are ordered on.
  * external == 0: return to the context's own stream. */

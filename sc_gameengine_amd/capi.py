@@ -85,6 +85,8 @@ SYMBOLS = {
     "scTickBorderBytes": (C.c_uint32, [_CTX, C.c_uint32]),
     "scTickBindBorderBuffers": (C.c_int, [_CTX, C.c_uint32, C.c_void_p, C.c_void_p]),
     "scTickRunPairs": (C.c_int, [_CTX]),
+    "scTickSetPairsStream": (C.c_int, [_CTX, C.c_void_p]),
+    "scTickBindBorderBuffersParity": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "scTickSetStream": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
     "scTickUploadMovers": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P, F32P, F32P, F32P]),
     "scTickAdvanceMovers": (C.c_int, [_CTX, C.c_float]),

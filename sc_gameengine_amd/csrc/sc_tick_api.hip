@@ -93,6 +93,13 @@ struct ScTickContext
   bool pairsPending = false;
   TickParams pendingParams{};
   hipStream_t ownStream = nullptr;
+  // pipelined tiles (scTickSetPairsStream): merge + queries + pair search of tick t run on a second stream under the fused
+  // kernel of tick t+1; everything the two halves share is double-buffered by tick parity (set 0 lives in `d`)
+  hipStream_t pairsStream = nullptr;
+  struct AltSet { uint32_t* binCount = nullptr; uint32_t* binLayers = nullptr; float4* bins = nullptr; float4* bigList = nullptr;
+                  float4* spill = nullptr; uint32_t* spillSector = nullptr; uint32_t* borderSend[8] = {}; uint32_t* borderRecv[8] = {}; } alt;
+  hipEvent_t packed[2] = { nullptr, nullptr }, pairsDone[2] = { nullptr, nullptr };
+  bool pairsInFlight[2] = { false, false };
 };
 
 namespace {
@@ -171,8 +178,34 @@ bool d2h(ScTickContext* c, void* dst, const void* src, size_t bytes)
 }
 bool sync(ScTickContext* c)
 {
-  const hipError_t e = hipStreamSynchronize(c->stream);
+  hipError_t e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) return fail(c, "hipStreamSynchronize", e);
+  if (c->pairsStream) {                       // pipelined tiles: the pair search half runs on its own stream
+    e = hipStreamSynchronize(c->pairsStream);
+    if (e != hipSuccess) return fail(c, "hipStreamSynchronize (pairs stream)", e);
+  }
+  return true;
+}
+
+// the device state a tick of parity q works on: set 0 is `d` itself, set 1 swaps in the second copy of everything the
+// pair search of one tick and the fused kernel of the next would otherwise share
+DeviceState stateFor(const ScTickContext* c, uint32_t q)
+{
+  DeviceState s = c->d;
+  if (c->pairsStream && q == 1u) {
+    s.binCount = c->alt.binCount; s.binLayers = c->alt.binLayers; s.bins = c->alt.bins; s.bigList = c->alt.bigList;
+    s.spill = c->alt.spill; s.spillSector = c->alt.spillSector;
+    for (int k = 0; k < 8; ++k) { s.borderSend[k] = c->alt.borderSend[k]; s.borderRecv[k] = c->alt.borderRecv[k]; }
+  }
+  return s;
+}
+
+// results of the pair half (pairs, ray hits, broadphase counters) are read on the tick stream: let it finish first
+bool joinPairs(ScTickContext* c)
+{
+  if (!c->pairsStream) return true;
+  const hipError_t e = hipStreamSynchronize(c->pairsStream);
+  if (e != hipSuccess) return fail(c, "hipStreamSynchronize (pairs stream)", e);
   return true;
 }
 
@@ -351,6 +384,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.variant = c->variant;
   p.chain = std::min(c->maxDepth, kMaxChain);
   p.bigClearWords = (c->prevBroadphaseN + 31u) >> 5;
+  if (c->pairsStream && (flags & SC_TICK_BROADPHASE)) p.flags |= kFlagDeferredReset;
   if (flags & SC_TICK_PRODUCE_NEXT) { p.producerKind = c->producerKind; p.producerParam = c->producerParam; }
   p.tileX = c->tileX; p.tileZ = c->tileZ; p.tilesX = c->tilesX; p.tilesZ = c->tilesZ;
 }
@@ -358,50 +392,60 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
 void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool allowProfile)
 {
   const uint32_t flags = p.flags;
+  const DeviceState ds = stateFor(c, p.parity);
   const bool prof = allowProfile && c->profiling;
   const bool saved = c->profiling;
   c->profiling = prof;
   if (c->producerKind && !(flags & SC_TICK_PRODUCE_NEXT)) {
     Scoped s(c, SC_TICK_K_NUDGE);
-    if (c->producerKind == 1) launchNudgeRootsX(c->d, c->n, c->producerParam, c->stream);
-    else launchAdvanceMovers(c->d, c->n, c->producerParam, c->stream);
+    if (c->producerKind == 1) launchNudgeRootsX(ds, c->n, c->producerParam, c->stream);
+    else launchAdvanceMovers(ds, c->n, c->producerParam, c->stream);
   }
   if (flags & (SC_TICK_XFORM | SC_TICK_CULL | SC_TICK_BROADPHASE)) {
     // the dominant kernel is timed by its own begin / end timestamps (the figure the roofline uses)
     if (c->profiling && (c->tickIndex % c->profPeriod) == 0) {
       const EventPair ev = takeEvents(c);
-      launchXformCull(c->d, p, grid, c->stream, ev.a, ev.b);
+      launchXformCull(ds, p, grid, c->stream, ev.a, ev.b);
       c->times[SC_TICK_K_XFORM_CULL].push_back(ev);
-    } else launchXformCull(c->d, p, grid, c->stream);
+    } else launchXformCull(ds, p, grid, c->stream);
   }
   if (flags & kFlagHasDeep) {
     for (size_t lv = 0; lv + 1 < c->levelOffsets.size(); ++lv) {
       const uint32_t b = c->levelOffsets[lv], e = c->levelOffsets[lv + 1];
-      launchDeepLevel(c->d, p, c->dLevelList + b, e - b, c->stream);
+      launchDeepLevel(ds, p, c->dLevelList + b, e - b, c->stream);
     }
   }
-  if ((flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_DENSE_AABBS)) launchDenseAabbs(c->d, c->n, c->stream);   // read-back aid, off the hot path
+  if ((flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_DENSE_AABBS)) launchDenseAabbs(ds, c->n, c->stream);   // read-back aid, off the hot path
   const bool needCompact = (flags & (SC_TICK_XFORM | SC_TICK_CULL)) != 0;
   const bool pairsNow = (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS);
-  if (pairsNow && (flags & SC_TICK_RAYS)) launchRayQueries(c->d, p, c->rays, c->stream);      // the bins are full, not yet consumed
+  if (pairsNow && (flags & SC_TICK_RAYS)) launchRayQueries(ds, p, c->rays, c->stream);      // the bins are full, not yet consumed
+  // pipelined tiles: the end-of-tick kernel resets the other parity's broadphase state, which the previous tick's pair search
+  // (on the second stream) may still be reading -- wait for it here, after the fused kernel, where the wait costs nothing
+  if (needCompact && (flags & kFlagDeferredReset) && c->pairsInFlight[p.parity ^ 1u]) {
+    hipStreamWaitEvent(c->stream, c->pairsDone[p.parity ^ 1u], 0);
+    c->pairsInFlight[p.parity ^ 1u] = false;
+  }
   if (needCompact && pairsNow && !(c->variant & 8u)) {
     // both depend only on the fused kernel: one launch, workgroups split by role (timed as K_PAIRS)
     Scoped s(c, SC_TICK_K_PAIRS);
-    launchCompactPairs(c->d, p, grid, c->stream);
+    launchCompactPairs(ds, p, grid, c->stream);
   } else {
     if (needCompact) {
       Scoped s(c, SC_TICK_K_COMPACT);
-      launchCompact(c->d, p, grid, c->stream);
+      launchCompact(ds, p, grid, c->stream);
     }
     if (flags & SC_TICK_BROADPHASE) {
-      if (flags & SC_TICK_SPLIT_PAIRS) launchBorderPack(c->d, p, c->stream);      // the caller exchanges, then scTickRunPairs
-      else { Scoped s(c, SC_TICK_K_PAIRS); launchPairs(c->d, p, c->stream); }
+      if (flags & SC_TICK_SPLIT_PAIRS) {                                            // the caller exchanges, then scTickRunPairs
+        launchBorderPack(ds, p, c->stream);
+        if (c->pairsStream) hipEventRecord(c->packed[p.parity], c->stream);
+      }
+      else { Scoped s(c, SC_TICK_K_PAIRS); launchPairs(ds, p, c->stream); }
     }
   }
   if (flags & SC_TICK_DRAWS) {
     const uint32_t budget = c->desc.max_draws_budget;
-    if (flags & SC_TICK_SORT_DRAWS) launchSortedDraws(c->d, c->sort, budget, (budget && budget < c->n) ? budget : c->n, c->dDraws, c->stream);
-    else launchEmitDraws(c->d, budget, c->dDraws, c->stream);
+    if (flags & SC_TICK_SORT_DRAWS) launchSortedDraws(ds, c->sort, budget, (budget && budget < c->n) ? budget : c->n, c->dDraws, c->stream);
+    else launchEmitDraws(ds, budget, c->dDraws, c->stream);
   }
   c->profiling = saved;
 }
@@ -509,6 +553,7 @@ void scTickDestroyContext(ScTickContext* c)
   dropGraph(c);
   for (auto& v : c->times) for (auto& p : v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : c->eventPool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (int k = 0; k < 2; ++k) { if (c->packed[k]) hipEventDestroy(c->packed[k]); if (c->pairsDone[k]) hipEventDestroy(c->pairsDone[k]); }
   for (void* p : c->allocs) hipFree(p);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -969,6 +1014,8 @@ int scTickRun(ScTickContext* c, uint32_t flags)
     if (!(flags & SC_TICK_XFORM)) return fail(c, "SC_TICK_PRODUCE_NEXT needs SC_TICK_XFORM (the producer rides on the end-of-tick kernel)");
     if (!c->producerKind) return fail(c, "SC_TICK_PRODUCE_NEXT needs scTickSetFrameProducer first");
   }
+  if (c->pairsStream && (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS)) return fail(c, "a pairs stream is set: run the broadphase with SC_TICK_SPLIT_PAIRS + scTickRunPairs");
+  if (c->pairsStream && c->graphMode) return fail(c, "graph replay and a pairs stream cannot be combined");
   if ((flags & SC_TICK_RAYS) && !(flags & SC_TICK_BROADPHASE)) return fail(c, "SC_TICK_RAYS needs SC_TICK_BROADPHASE in the same run (the queries read this tick's bins)");
   if ((flags & SC_TICK_SORT_DRAWS) && !c->sort.pipeline) return fail(c, "SC_TICK_SORT_DRAWS needs scTickSetDrawSortTable first");
   TickParams p; uint32_t grid;
@@ -1008,11 +1055,19 @@ int scTickRunPairs(ScTickContext* c)
   if (!c) return 0;
   if (!bind(c)) return 0;
   if (!c->pairsPending) return fail(c, "scTickRunPairs without a preceding scTickRun(... | SC_TICK_BROADPHASE | SC_TICK_SPLIT_PAIRS)");
-  launchBorderMerge(c->d, c->pendingParams, c->stream);
-  if (c->pendingParams.flags & SC_TICK_RAYS) launchRayQueries(c->d, c->pendingParams, c->rays, c->stream);   // sees the neighbours' border boxes too
-  {
+  const uint32_t q = c->pendingParams.parity;
+  const DeviceState ds = stateFor(c, q);
+  hipStream_t ps = c->pairsStream ? c->pairsStream : c->stream;
+  if (c->pairsStream) HIP_OK(c, hipStreamWaitEvent(ps, c->packed[q], 0));        // (the caller's exchange on this stream waited for it already)
+  launchBorderMerge(ds, c->pendingParams, ps);
+  if (c->pendingParams.flags & SC_TICK_RAYS) launchRayQueries(ds, c->pendingParams, c->rays, ps);   // sees the neighbours' border boxes too
+  if (c->pairsStream) {
+    launchPairs(ds, c->pendingParams, ps);
+    HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
+    c->pairsInFlight[q] = true;
+  } else {
     Scoped s(c, SC_TICK_K_PAIRS);
-    launchPairs(c->d, c->pendingParams, c->stream);
+    launchPairs(ds, c->pendingParams, ps);
   }
   c->pairsPending = false;
   c->lastParity = c->parity; c->parity ^= 1u;
@@ -1056,6 +1111,41 @@ int scTickBindBorderBuffers(ScTickContext* c, uint32_t dir, void* send, void* re
   if (!c || dir > 7u) return c ? fail(c, "bad direction") : 0;
   c->d.borderSend[dir] = static_cast<uint32_t*>(send);
   c->d.borderRecv[dir] = static_cast<uint32_t*>(recv);
+  c->alt.borderSend[dir] = static_cast<uint32_t*>(send);
+  c->alt.borderRecv[dir] = static_cast<uint32_t*>(recv);
+  return 1;
+}
+
+int scTickBindBorderBuffersParity(ScTickContext* c, uint32_t parity, uint32_t dir, void* send, void* recv)
+{
+  if (!c) return 0;
+  if (dir > 7 || parity > 1) return fail(c, "direction must be 0..7 and parity 0 or 1");
+  if (parity == 0) { c->d.borderSend[dir] = static_cast<uint32_t*>(send); c->d.borderRecv[dir] = static_cast<uint32_t*>(recv); }
+  else { c->alt.borderSend[dir] = static_cast<uint32_t*>(send); c->alt.borderRecv[dir] = static_cast<uint32_t*>(recv); }
+  return 1;
+}
+
+int scTickSetPairsStream(ScTickContext* c, void* stream)
+{
+  if (!c) return 0;
+  if (!bind(c)) return 0;
+  if (!sync(c)) return 0;
+  if (c->pairsPending) return fail(c, "scTickRunPairs is pending");
+  if (!stream) { c->pairsStream = nullptr; return 1; }
+  if (!c->sectors) return fail(c, "the context has no broadphase");
+  if (!c->alt.bins) {
+    const size_t N = c->cap;
+    if (!dalloc(c, c->alt.binCount, c->sectors) || !dalloc(c, c->alt.binLayers, c->sectors) ||
+        !dalloc(c, c->alt.bins, (size_t)c->sectors * kBinCap * 2u, false) || !dalloc(c, c->alt.bigList, (N + 8u * kBorderBigCap) * 2u, false) ||
+        !dalloc(c, c->alt.spill, 2u * kSpillCap, false) || !dalloc(c, c->alt.spillSector, kSpillCap)) return 0;
+    for (int k = 0; k < 2; ++k) {
+      HIP_OK(c, hipEventCreateWithFlags(&c->packed[k], hipEventDisableTiming));
+      HIP_OK(c, hipEventCreateWithFlags(&c->pairsDone[k], hipEventDisableTiming));
+    }
+  }
+  c->pairsStream = static_cast<hipStream_t>(stream);
+  c->pairsInFlight[0] = c->pairsInFlight[1] = false;
+  c->topoEpoch++;
   return 1;
 }
 
@@ -1146,7 +1236,7 @@ int scTickReadMoverVelocities(ScTickContext* c, uint32_t first, uint32_t count, 
 int scTickGetCounts(ScTickContext* c, ScTickCounts* out)
 {
   if (!c || !out) return c ? fail(c, "null argument") : 0;
-  if (!bind(c)) return 0;
+  if (!bind(c) || !joinPairs(c)) return 0;
   uint32_t k[32] = {};
   if (!d2h(c, k, c->d.counters, sizeof k) || !sync(c)) return 0;
   std::memset(out, 0, sizeof *out);
@@ -1287,6 +1377,7 @@ int scTickReadPairs(ScTickContext* c, uint32_t* pairs2, uint32_t cap, uint32_t* 
   if (!bind(c)) return 0;
   if (!(c->lastFlags & SC_TICK_BROADPHASE)) return fail(c, "the last scTickRun did not request SC_TICK_BROADPHASE");
   if (c->pairsPending) return fail(c, "scTickRunPairs has not been called for the last tick");
+  if (!joinPairs(c)) return 0;
   // the pair list is kept in per-shard segments on the device; gather them into one list first
   TickParams pp{}; pp.maxPairs = c->maxPairs;
   launchGatherPairs(c->d, pp, c->lastParity, c->dPairsOut, c->dPairTotal, c->stream);
@@ -1351,6 +1442,7 @@ int scTickReadRayHits(ScTickContext* c, ScTickRayHit* hits, uint32_t cap, uint32
   if (!bind(c)) return 0;
   if (!(c->lastFlags & SC_TICK_RAYS)) return fail(c, "the last scTickRun did not request SC_TICK_RAYS");
   if (c->pairsPending) return fail(c, "ray hits are ready after scTickRunPairs");
+  if (!joinPairs(c)) return 0;
   static_assert(sizeof(ScTickRayHit) == sizeof(RayHit48), "ray hit layouts differ");
   *count = c->rays.count;
   const uint32_t take = std::min(c->rays.count, cap);

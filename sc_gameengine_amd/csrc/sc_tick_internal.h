@@ -138,6 +138,8 @@ __host__ __device__ inline uint32_t borderRecCap(uint32_t L) { return L * kBorde
 __host__ __device__ inline uint32_t borderBinWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { const uint32_t L = borderLen(d, coreSX, coreSZ); return kBorderHeader + L + borderRecCap(L) * 8u; }
 __host__ __device__ inline uint32_t borderWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { return borderBinWords(d, coreSX, coreSZ) + kBorderBigWords; }
 constexpr uint32_t kFlagHasDeep = 1u << 16;   // write recomp bits for the level kernels
+constexpr uint32_t kFlagDeferredReset = 1u << 17;   // pipelined tiles: the other parity's counters / big bits are reset by the end-of-tick
+                                                    // kernel (after the pair search that used them), not by this tick's pair kernel
 constexpr uint32_t kFlagDenseAabbs = 1u << 5; // == SC_TICK_DENSE_AABBS
 
 // ---- renderer draw order (sc_tick_drawsort.hip) ----

@@ -559,6 +559,8 @@ __device__ __forceinline__ uint32_t blockSum(uint32_t v, uint32_t* scratch)
   return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
+__device__ __forceinline__ void resetOtherParity(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks);
+
 // `group`: how many of the fused kernel's spans one compaction workgroup takes (their counts are summed here; fewer,
 // longer workgroups keep the whole end-of-tick kernel resident at once).
 __device__ __forceinline__ void compactBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks, uint32_t group,
@@ -637,6 +639,9 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
   if (p.flags & SC_TICK_XFORM) {
     for (uint32_t w = wBegin + kTile + threadIdx.x; w < wEnd; w += kTile) d.dirty[w] &= d.unreach[w];   // spans wider than 8192 entities
   }
+  // pipelined tiles: the pair search of the previous tick has finished by now (the host made this kernel wait for it), so
+  // its parity's state is cleared here, before the next tick's fused kernel starts filling it again
+  if ((p.flags & kFlagDeferredReset) && (p.flags & SC_TICK_BROADPHASE)) resetOtherParity(d, p, bid, nblocks);
   // spans too wide for the LDS ballots: the producer runs behind the dirty clear, one more pass over the span
   if (produce && !produceEarly) {
     __syncthreads();
@@ -717,6 +722,16 @@ __device__ __forceinline__ void sinkPush(const DeviceState& d, const TickParams&
   if (k.count > kWavePairBuf - 64u) sinkFlush(d, p, k);        // keep room for a full wave of hits
 }
 
+// The state of the OTHER tick parity -- counter set, pair shard counters, big-box bits -- back to zero.
+__device__ __forceinline__ void resetOtherParity(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks)
+{
+  if (bid == 0 && threadIdx.x < 8) d.counters[kCtrPar + 8u * (p.parity ^ 1u) + threadIdx.x] = 0u;
+  if (bid == 0 && threadIdx.x < kPairShards) d.pairShardCount[((p.parity ^ 1u) * kPairShards + threadIdx.x) * kShardStride] = 0u;
+  const uint32_t words = p.bigClearWords;      // what the previous tick (other parity) can have set: its entity count, not this one's
+  uint32_t* nextBits = d.bigBits[p.parity ^ 1u];
+  for (uint32_t w = bid * kTile + threadIdx.x; w < words; w += nblocks * kTile) nextBits[w] = 0u;
+}
+
 // Does this tile own sector (gx, gz) of its bin grid (coordinates may lie outside the grid)?  A sector belongs to
 // the tile nearest to it, so outside the core [1, binS-2] it is ours only on sides where no tile exists.
 __device__ __forceinline__ bool ownsSector(const TickParams& p, float gx, float gz)
@@ -761,14 +776,9 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   for (uint32_t i = 1u + threadIdx.x / 64u * 16u; i < kBinCap && i < 17u + threadIdx.x / 64u * 16u; ++i)
     for (uint32_t j = lane; j < i; j += 64u) pairTab[i * (i - 1u) / 2u + j] = (uint16_t)(i << 8 | j);
 
-  // next tick's counter set and big bits start clean
-  if (bid == 0 && threadIdx.x < 8) d.counters[kCtrPar + 8u * (p.parity ^ 1u) + threadIdx.x] = 0u;
-  if (bid == 0 && threadIdx.x < kPairShards) d.pairShardCount[((p.parity ^ 1u) * kPairShards + threadIdx.x) * kShardStride] = 0u;
-  {
-    const uint32_t words = p.bigClearWords;      // what the previous tick (other parity) can have set: its entity count, not this one's
-    uint32_t* nextBits = d.bigBits[p.parity ^ 1u];
-    for (uint32_t w = bid * kTile + threadIdx.x; w < words; w += nblocks * kTile) nextBits[w] = 0u;
-  }
+  // next tick's counter set and big bits start clean (pipelined tiles do this in the end-of-tick kernel instead:
+  // there the next tick's fused kernel may already be filling them while this pair search runs)
+  if (!(p.flags & kFlagDeferredReset)) resetOtherParity(d, p, bid, nblocks);
   __syncthreads();
 
   // a wave visits sectors waveGlobal, +totalWaves, ...; their counts are fetched 64 at a time (lane k

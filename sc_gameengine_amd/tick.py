@@ -297,6 +297,14 @@ class WorldTick:
     def bind_border(self, direction, send_ptr, recv_ptr):
         self._ok(self.lib.scTickBindBorderBuffers(self.ctx, direction, send_ptr, recv_ptr), "scTickBindBorderBuffers")
 
+    def set_pairs_stream(self, hip_stream):
+        """Pipelined tiles: merge + queries + pair search of a tick go to this stream (None / 0 switches it off)."""
+        self._ok(self.lib.scTickSetPairsStream(self.ctx, C.c_void_p(hip_stream or None)), "scTickSetPairsStream")
+
+    def bind_border_parity(self, parity, direction, send_ptr, recv_ptr):
+        self._ok(self.lib.scTickBindBorderBuffersParity(self.ctx, parity, direction, C.c_void_p(send_ptr), C.c_void_p(recv_ptr)),
+                 "scTickBindBorderBuffersParity")
+
     def run_pairs(self):
         self._ok(self.lib.scTickRunPairs(self.ctx), "scTickRunPairs")
 

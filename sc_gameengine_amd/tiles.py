@@ -74,10 +74,9 @@ class BorderBuffers:
     batched isend/irecv group costs about 25 us per operation, 200 us for eight neighbours, four ticks' worth.
     send[d] / recv[d] are views of those tensors per direction (what the single-GPU tile tests copy between contexts)."""
 
-    def __init__(self, tick, rank, grid, device, world_size=None):
+    def __init__(self, tick, rank, grid, device, world_size=None, pipelined=False):
         import torch
         self.rank, self.grid = rank, grid
-        self.send, self.recv = {}, {}
         tick.set_tile(rank, neighbour_mask(rank, grid))
         tx, tz = tile_of(rank, grid)
         tick.set_tile_grid(tx, tz, grid[0], grid[1])      # big boxes travel in the border messages too
@@ -88,28 +87,36 @@ class BorderBuffers:
         for d, r in nb.items():                            # is its direction 7-d message, which has the same side length
             self.splits[r] = words[d]
         total = max(sum(self.splits), 1)
-        self.send_all = torch.zeros(total, dtype=torch.int32, device=device)
-        self.recv_all = torch.zeros(total, dtype=torch.int32, device=device)
-        offset = {}
-        at = 0
+        offset, at = {}, 0
         for r in range(ranks):
             offset[r] = at
             at += self.splits[r]
-        for d, r in nb.items():
-            self.send[d] = self.send_all[offset[r]:offset[r] + words[d]]
-            self.recv[d] = self.recv_all[offset[r]:offset[r] + words[d]]
-            tick.bind_border(d, self.send[d].data_ptr(), self.recv[d].data_ptr())
+        # pipelined tiles keep one set per tick parity: tick t+1 packs its messages while tick t's are still in flight
+        self.sets = []
+        for q in range(2 if pipelined else 1):
+            send_all = torch.zeros(total, dtype=torch.int32, device=device)
+            recv_all = torch.zeros(total, dtype=torch.int32, device=device)
+            send = {d: send_all[offset[r]:offset[r] + words[d]] for d, r in nb.items()}
+            recv = {d: recv_all[offset[r]:offset[r] + words[d]] for d, r in nb.items()}
+            self.sets.append((send_all, recv_all, send, recv))
+            for d in nb:
+                if pipelined:
+                    tick.bind_border_parity(q, d, send[d].data_ptr(), recv[d].data_ptr())
+                else:
+                    tick.bind_border(d, send[d].data_ptr(), recv[d].data_ptr())
+        self.send_all, self.recv_all, self.send, self.recv = self.sets[0]
 
-    def exchange(self, group=None):
+    def exchange(self, group=None, parity=0):
         """Per-step exchange: one all-to-all with split sizes on RCCL; point-to-point staging elsewhere (gloo has no
-        all-to-all; it is only used for rehearsals and CPU tests)."""
+        all-to-all; it is only used for rehearsals and CPU tests).  parity selects the buffer set of a pipelined tile."""
         import torch.distributed as dist
         if not neighbours(self.rank, self.grid):
             return
+        send_all, recv_all, send, recv = self.sets[parity if len(self.sets) > 1 else 0]
         if dist.get_backend(group) != "nccl":
-            exchange(self.send, self.recv, self.rank, self.grid, group)
+            exchange(send, recv, self.rank, self.grid, group)
             return
-        dist.all_to_all_single(self.recv_all, self.send_all, self.splits, self.splits, group=group)
+        dist.all_to_all_single(recv_all, send_all, self.splits, self.splits, group=group)
 
 
 def global_pair_ids(pairs, entities_per_rank):

@@ -222,3 +222,71 @@ def test_big_box_reaching_past_the_neighbours_is_counted(oracle):
     assert lost[0] >= 1 and sum(lost[1:]) == 0
     for t in ticks:
         t.close()
+
+
+@pytest.mark.parametrize("grid", [(2, 2), (4, 2)])
+def test_pipelined_tiles_overlap_pair_search_with_the_next_tick(oracle, grid):
+    """scTickSetPairsStream: tick t's merge + pair search run on a second stream while tick t+1's fused kernel runs; bins,
+    big list, spill list and border messages are double-buffered by parity.  Several ticks are issued back to back
+    without a host synchronisation, then the last tick's pair set must be the whole world's -- a race between the two
+    halves would leave stale or missing records behind."""
+    import torch
+    S = (6, 6)
+    w = sw.generate(S[0] * grid[0], S[1] * grid[1], 15, tiles=grid)
+    rng = np.random.default_rng(27)
+    dyn = rng.random(w.n) < 0.35
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    roots = np.flatnonzero((w.parent < 0) & (np.arange(w.n) % 16 != 0))
+    edge = rng.choice(roots, len(roots) // 6, replace=False)
+    w.pos[edge, 0] = (np.round(w.pos[edge, 0] / (64.0 * S[0])) * 64.0 * S[0] + rng.uniform(-1.0, 1.0, len(edge))).astype(np.float32)
+    big = rng.choice(np.setdiff1d(roots, edge), 12, replace=False)
+    w.bmin[big] *= 150.0; w.bmax[big] *= 150.0                       # ~150 m boxes: big list, travelling in the messages
+    w.group[big], w.mask[big] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    parts, n = split_world(w, grid, S)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    ticks, bufs, s1, s2 = [], [], [], []
+    for r, p in enumerate(parts):
+        t = WorldTick.from_world(p, broadphase=True, max_pairs=1 << 16)
+        a, b = torch.cuda.Stream(), torch.cuda.Stream()
+        t.set_stream(a.cuda_stream, external=True)
+        t.set_pairs_stream(b.cuda_stream)
+        t.set_frame_producer(1, 0.7)
+        ticks.append(t); s1.append(a); s2.append(b)
+        bufs.append(tiles.BorderBuffers(t, r, grid, "cuda", pipelined=True))
+    flags = capi.XFORM | capi.BROADPHASE | capi.SPLIT_PAIRS | capi.PRODUCE_NEXT
+    for t in ticks:
+        t.nudge_roots_x(0.7)
+    steps = 6
+    for step in range(steps):
+        q = step & 1
+        for t in ticks:
+            t.run(flags)                                               # tick stream: fused kernel, end-of-tick kernel, pack
+        for r, b in enumerate(bufs):                                   # the "network", on the receivers' pairs streams
+            for d, nb in tiles.neighbours(r, grid).items():
+                s2[nb].wait_stream(s1[r])
+                with torch.cuda.stream(s2[nb]):
+                    bufs[nb].sets[q][3][7 - d].copy_(b.sets[q][2][d], non_blocking=True)
+        for t in ticks:
+            t.run_pairs()                                              # pairs stream; nothing waits on the host
+    for _ in range(steps):
+        ow.nudge_roots_x(0.7)
+    ow.transform_system()
+    mn, mx = ow.world_aabbs()
+    want = oracle.broadphase_grid(mn, mx, w.group, w.mask, 16.0)
+    got = []
+    for t in ticks:
+        p, total = t.pairs()
+        c = t.counts()
+        assert total == len(p) and c.border_lost == 0 and c.pairs_truncated == 0
+        got.append(tiles.global_pair_ids(p, n))
+    got = np.concatenate(got).astype(np.uint64)
+    lo, hi = np.minimum(got[:, 0], got[:, 1]), np.maximum(got[:, 0], got[:, 1])
+    key = np.sort(lo << np.uint64(32) | hi)
+    wkey = want[:, 0].astype(np.uint64) << np.uint64(32) | want[:, 1].astype(np.uint64)
+    assert len(key) == len(np.unique(key))
+    assert np.array_equal(key, wkey), f"{len(np.setdiff1d(wkey, key))} missing, {len(np.setdiff1d(key, wkey))} unexpected of {len(wkey)}"
+    assert sum(t.counts().big_boxes for t in ticks) >= 12 and len(wkey) > 200
+    torch.cuda.synchronize()
+    for t in ticks:
+        t.close()
+    ow.close()
