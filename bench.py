@@ -183,14 +183,17 @@ def main():
     borders = None
     tick_stream = pairs_stream = None
     if world_size > 1 and (flags & capi.BROADPHASE):
-        tick_stream = torch.cuda.Stream(device=local_rank)
-        torch.cuda.set_stream(tick_stream)            # torch's current stream for everything below, RCCL ops included
-        t.set_stream(tick_stream.cuda_stream, external=True)
         if args.pipeline:
-            # the exchange, the merge and the pair search of tick t go to a second stream and run under the fused kernel of
-            # tick t+1 (bins and messages are double-buffered by tick parity; the library orders the halves with events)
+            # the exchange, the merge and the pair search of tick t run on a second stream under the fused kernel of tick t+1
+            # (bins and messages are double-buffered by tick parity; the library orders the halves with events).  That
+            # second stream is torch's current stream, where the RCCL operation goes; the tick keeps the context's own.
             pairs_stream = torch.cuda.Stream(device=local_rank)
+            torch.cuda.set_stream(pairs_stream)
             t.set_pairs_stream(pairs_stream.cuda_stream)
+        else:
+            tick_stream = torch.cuda.Stream(device=local_rank)
+            torch.cuda.set_stream(tick_stream)        # torch's current stream for everything below, RCCL ops included
+            t.set_stream(tick_stream.cuda_stream, external=True)
         borders = tiles.BorderBuffers(t, rank, grid, torch.device("cuda", local_rank), pipelined=bool(args.pipeline))
     tick_parity = [0]
 
@@ -210,12 +213,8 @@ def main():
             t.run(flags)
             return
         t.run(flags | capi.SPLIT_PAIRS)           # ... bins filled, border messages packed, next frame produced
-        if pairs_stream is None:
-            borders.exchange()                    # neighbour messages over RCCL (xGMI), one all-to-all
-        else:
-            pairs_stream.wait_stream(tick_stream)
-            with torch.cuda.stream(pairs_stream):
-                borders.exchange(parity=tick_parity[0])
+        borders.exchange(parity=tick_parity[0])   # neighbour messages over RCCL (xGMI), one all-to-all, on the current stream
+        if pairs_stream is not None:
             tick_parity[0] ^= 1
         t.run_pairs()                             # merge what arrived, pair search (on the pairs stream when pipelined)
 

@@ -191,11 +191,13 @@ int scTickRunPairs(ScTickContext* ctx);
 /* Pipelined tiles.  With a pairs stream set (hipStream_t; NULL switches it off), scTickRunPairs queues the merge, the ray
  * queries and the pair search of tick t on THAT stream, and the next scTickRun may start its fused kernel while they run:
  * everything the two halves share -- bins, big list, spill list, border messages -- exists twice, selected by tick parity
- * (counters, big-box bits and the pair output already are).  The library orders the halves with events: the pair half waits
- * for the pack of its tick, and the end-of-tick kernel of tick t+1, which clears tick t's broadphase state for tick t+2,
- * waits for the pair half of tick t.  The caller issues the exchange of tick t on the pairs stream after making that stream
- * wait for the tick stream (border buffers of tick parity t & 1: scTickBindBorderBuffersParity), then calls scTickRunPairs.
- * Results of tick t stay readable until the next scTickRun.  Not combinable with graph replay. */
+ * (counters, big-box bits and the pair output already are).  The library orders the halves with events: scTickRun makes the
+ * pairs stream wait for the pack of its tick, and tick t+2, which reuses tick t's bins and counters, first waits for the pair
+ * half of tick t and clears them.  The caller issues the exchange of tick t on the pairs stream after
+ * scTickRun (border buffers of tick parity t & 1: scTickBindBorderBuffersParity), then calls scTickRunPairs -- e.g. the pairs
+ * stream is torch's current stream, where its RCCL operations go, and the tick runs on the context's own stream.
+ * Read the results of tick t (pairs, ray hits, counts) after its scTickRunPairs and before the next scTickRun, as always.
+ * Not combinable with graph replay. */
 int scTickSetPairsStream(ScTickContext* ctx, void* hip_stream);
 int scTickBindBorderBuffersParity(ScTickContext* ctx, uint32_t parity, uint32_t direction, void* send_device_ptr, void* recv_device_ptr);
 /* external != 0: run all device work of this context on the caller's stream `hip_stream` (hipStream_t;

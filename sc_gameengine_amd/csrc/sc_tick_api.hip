@@ -100,6 +100,7 @@ struct ScTickContext
                   float4* spill = nullptr; uint32_t* spillSector = nullptr; uint32_t* borderSend[8] = {}; uint32_t* borderRecv[8] = {}; } alt;
   hipEvent_t packed[2] = { nullptr, nullptr }, pairsDone[2] = { nullptr, nullptr };
   bool pairsInFlight[2] = { false, false };
+  uint32_t parityN[2] = { 0, 0 };          // entity count when a parity's big-box bits were last filled
 };
 
 namespace {
@@ -396,6 +397,13 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
   const bool prof = allowProfile && c->profiling;
   const bool saved = c->profiling;
   c->profiling = prof;
+  // pipelined tiles: this tick refills the bins, counters and big-box bits of its parity, which the pair half of two ticks ago
+  // read.  That half finished long ago unless the exchange is very slow; wait for it, then clear the small state.
+  if (flags & kFlagDeferredReset) {
+    if (c->pairsInFlight[p.parity]) { hipStreamWaitEvent(c->stream, c->pairsDone[p.parity], 0); c->pairsInFlight[p.parity] = false; }
+    launchResetParity(ds, p.parity, (c->parityN[p.parity] + 31u) >> 5, c->stream);
+    c->parityN[p.parity] = c->n;
+  }
   if (c->producerKind && !(flags & SC_TICK_PRODUCE_NEXT)) {
     Scoped s(c, SC_TICK_K_NUDGE);
     if (c->producerKind == 1) launchNudgeRootsX(ds, c->n, c->producerParam, c->stream);
@@ -419,12 +427,6 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
   const bool needCompact = (flags & (SC_TICK_XFORM | SC_TICK_CULL)) != 0;
   const bool pairsNow = (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS);
   if (pairsNow && (flags & SC_TICK_RAYS)) launchRayQueries(ds, p, c->rays, c->stream);      // the bins are full, not yet consumed
-  // pipelined tiles: the end-of-tick kernel resets the other parity's broadphase state, which the previous tick's pair search
-  // (on the second stream) may still be reading -- wait for it here, after the fused kernel, where the wait costs nothing
-  if (needCompact && (flags & kFlagDeferredReset) && c->pairsInFlight[p.parity ^ 1u]) {
-    hipStreamWaitEvent(c->stream, c->pairsDone[p.parity ^ 1u], 0);
-    c->pairsInFlight[p.parity ^ 1u] = false;
-  }
   if (needCompact && pairsNow && !(c->variant & 8u)) {
     // both depend only on the fused kernel: one launch, workgroups split by role (timed as K_PAIRS)
     Scoped s(c, SC_TICK_K_PAIRS);
@@ -437,7 +439,8 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     if (flags & SC_TICK_BROADPHASE) {
       if (flags & SC_TICK_SPLIT_PAIRS) {                                            // the caller exchanges, then scTickRunPairs
         launchBorderPack(ds, p, c->stream);
-        if (c->pairsStream) hipEventRecord(c->packed[p.parity], c->stream);
+        // pipelined: whatever the caller queues on the pairs stream from here on (the exchange) is ordered behind the pack
+        if (c->pairsStream) { hipEventRecord(c->packed[p.parity], c->stream); hipStreamWaitEvent(c->pairsStream, c->packed[p.parity], 0); }
       }
       else { Scoped s(c, SC_TICK_K_PAIRS); launchPairs(ds, p, c->stream); }
     }
@@ -1058,7 +1061,6 @@ int scTickRunPairs(ScTickContext* c)
   const uint32_t q = c->pendingParams.parity;
   const DeviceState ds = stateFor(c, q);
   hipStream_t ps = c->pairsStream ? c->pairsStream : c->stream;
-  if (c->pairsStream) HIP_OK(c, hipStreamWaitEvent(ps, c->packed[q], 0));        // (the caller's exchange on this stream waited for it already)
   launchBorderMerge(ds, c->pendingParams, ps);
   if (c->pendingParams.flags & SC_TICK_RAYS) launchRayQueries(ds, c->pendingParams, c->rays, ps);   // sees the neighbours' border boxes too
   if (c->pairsStream) {
@@ -1139,8 +1141,8 @@ int scTickSetPairsStream(ScTickContext* c, void* stream)
         !dalloc(c, c->alt.bins, (size_t)c->sectors * kBinCap * 2u, false) || !dalloc(c, c->alt.bigList, (N + 8u * kBorderBigCap) * 2u, false) ||
         !dalloc(c, c->alt.spill, 2u * kSpillCap, false) || !dalloc(c, c->alt.spillSector, kSpillCap)) return 0;
     for (int k = 0; k < 2; ++k) {
-      HIP_OK(c, hipEventCreateWithFlags(&c->packed[k], hipEventDisableTiming));
-      HIP_OK(c, hipEventCreateWithFlags(&c->pairsDone[k], hipEventDisableTiming));
+      HIP_OK(c, hipEventCreateWithFlags(&c->packed[k], hipEventDisableTiming | hipEventReleaseToDevice));
+      HIP_OK(c, hipEventCreateWithFlags(&c->pairsDone[k], hipEventDisableTiming | hipEventReleaseToDevice));
     }
   }
   c->pairsStream = static_cast<hipStream_t>(stream);

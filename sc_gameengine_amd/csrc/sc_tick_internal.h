@@ -138,8 +138,8 @@ __host__ __device__ inline uint32_t borderRecCap(uint32_t L) { return L * kBorde
 __host__ __device__ inline uint32_t borderBinWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { const uint32_t L = borderLen(d, coreSX, coreSZ); return kBorderHeader + L + borderRecCap(L) * 8u; }
 __host__ __device__ inline uint32_t borderWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { return borderBinWords(d, coreSX, coreSZ) + kBorderBigWords; }
 constexpr uint32_t kFlagHasDeep = 1u << 16;   // write recomp bits for the level kernels
-constexpr uint32_t kFlagDeferredReset = 1u << 17;   // pipelined tiles: the other parity's counters / big bits are reset by the end-of-tick
-                                                    // kernel (after the pair search that used them), not by this tick's pair kernel
+constexpr uint32_t kFlagDeferredReset = 1u << 17;   // pipelined tiles: a parity's counters / big bits are reset by a kernel of their own right before
+                                                    // the fused kernel that reuses them (after the pair search that read them), not by a pair kernel
 constexpr uint32_t kFlagDenseAabbs = 1u << 5; // == SC_TICK_DENSE_AABBS
 
 // ---- renderer draw order (sc_tick_drawsort.hip) ----
@@ -184,6 +184,7 @@ void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, h
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);
 void launchMoveEntities(const DeviceState& d, const uint32_t* src, const uint32_t* dst, uint32_t moves, hipStream_t s);
 void launchSetFrustum(const DeviceState& d, const Frustum6& fr, hipStream_t s);
+void launchResetParity(const DeviceState& d, uint32_t q, uint32_t words, hipStream_t s);
 void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s);
 void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s);
 void launchEmitDraws(const DeviceState& d, uint32_t budget, void* items, hipStream_t s);
