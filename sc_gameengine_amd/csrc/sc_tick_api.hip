@@ -432,13 +432,17 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     Scoped s(c, SC_TICK_K_PAIRS);
     launchCompactPairs(ds, p, grid, c->stream);
   } else {
-    if (needCompact) {
+    const bool packToo = needCompact && (flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_SPLIT_PAIRS) && !(c->variant & 8u);
+    if (packToo) {
+      Scoped s(c, SC_TICK_K_COMPACT);
+      launchCompactPack(ds, p, grid, c->stream);                                    // compaction and pack share a launch
+    } else if (needCompact) {
       Scoped s(c, SC_TICK_K_COMPACT);
       launchCompact(ds, p, grid, c->stream);
     }
     if (flags & SC_TICK_BROADPHASE) {
       if (flags & SC_TICK_SPLIT_PAIRS) {                                            // the caller exchanges, then scTickRunPairs
-        launchBorderPack(ds, p, c->stream);
+        if (!packToo) launchBorderPack(ds, p, c->stream);
         // pipelined: whatever the caller queues on the pairs stream from here on (the exchange) is ordered behind the pack
         if (c->pairsStream) { hipEventRecord(c->packed[p.parity], c->stream); hipStreamWaitEvent(c->pairsStream, c->packed[p.parity], 0); }
       }

@@ -175,6 +175,7 @@ void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hip
 void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s);
 void launchGatherPairs(const DeviceState& d, const TickParams& p, uint32_t parity, uint2* dst, uint32_t* total, hipStream_t s);
+void launchCompactPack(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchBorderMerge(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s);

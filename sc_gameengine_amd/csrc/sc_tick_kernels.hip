@@ -1092,10 +1092,9 @@ __device__ __forceinline__ uint32_t blockScanExclusive(uint32_t v, uint32_t carr
   return before + incl - v;
 }
 
-__global__ __launch_bounds__(kTile) void k_border_pack(const DeviceState d, const TickParams p)
+__device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickParams& p, uint32_t dir)
 {
   __shared__ uint32_t sWave[4];
-  const uint32_t dir = blockIdx.x;
   if (!((p.neighbourMask >> dir) & 1u) || !d.borderSend[dir]) return;
   int dx, dz; borderDir(dir, dx, dz);
   const uint32_t L = borderLen(dir, p.binSX - 2u, p.binSZ - 2u);
@@ -1181,6 +1180,20 @@ __global__ __launch_bounds__(kTile) void k_border_pack(const DeviceState d, cons
     big[0] = bigCount < kBorderBigCap ? bigCount : kBorderBigCap; big[1] = bigLost;
     d.counters[ctr + kCtrBigLocal] = nLocal;
   }
+}
+
+__global__ __launch_bounds__(kTile) void k_border_pack(const DeviceState d, const TickParams p)
+{
+  borderPackBody(d, p, blockIdx.x);
+}
+
+// split flow: the compaction role and the eight pack workgroups both depend only on the fused kernel -- one launch
+__global__ __launch_bounds__(kTile) void k_compact_pack(const DeviceState d, const TickParams p, uint32_t compactBlocks, uint32_t group)
+{
+  __shared__ uint32_t scratch[kTile / 64];
+  __shared__ uint32_t moved[kMaxSpanWords];
+  if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, group, scratch, moved);
+  else borderPackBody(d, p, blockIdx.x - compactBlocks);
 }
 
 __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, const TickParams p)
@@ -1454,6 +1467,12 @@ void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t comp
 void launchGatherPairs(const DeviceState& d, const TickParams& p, uint32_t parity, uint2* dst, uint32_t* total, hipStream_t s)
 {
   hipLaunchKernelGGL(k_gather_pairs, dim3(kPairShards), dim3(kTile), 0, s, d, p, parity, dst, total);
+}
+void launchCompactPack(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
+{
+  const uint32_t g = compactGroup(p, grid, false);
+  const uint32_t blocks = (grid + g - 1) / g;
+  hipLaunchKernelGGL(k_compact_pack, dim3(blocks + 8u), dim3(kTile), 0, s, d, p, blocks, g);
 }
 void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s)
 {
