@@ -100,7 +100,6 @@ struct ScTickContext
                   float4* spill = nullptr; uint32_t* spillSector = nullptr; uint32_t* borderSend[8] = {}; uint32_t* borderRecv[8] = {}; } alt;
   hipEvent_t packed[2] = { nullptr, nullptr }, pairsDone[2] = { nullptr, nullptr };
   bool pairsInFlight[2] = { false, false };
-  uint32_t parityN[2] = { 0, 0 };          // entity count when a parity's big-box bits were last filled
 };
 
 namespace {
@@ -384,7 +383,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.neighbourMask = c->neighbourMask;
   p.variant = c->variant;
   p.chain = std::min(c->maxDepth, kMaxChain);
-  p.bigClearWords = (c->prevBroadphaseN + 31u) >> 5;
+  p.bigClearWords = ((c->pairsStream ? c->n : c->prevBroadphaseN) + 31u) >> 5;      // pipelined: a pair kernel clears its own parity
   if (c->pairsStream && (flags & SC_TICK_BROADPHASE)) p.flags |= kFlagDeferredReset;
   if (flags & SC_TICK_PRODUCE_NEXT) { p.producerKind = c->producerKind; p.producerParam = c->producerParam; }
   p.tileX = c->tileX; p.tileZ = c->tileZ; p.tilesX = c->tilesX; p.tilesZ = c->tilesZ;
@@ -406,8 +405,6 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
       (void)hipGetLastError();                        // hipErrorNotReady from the query is not an error
       c->pairsInFlight[p.parity] = false;
     }
-    launchResetParity(ds, p.parity, (c->parityN[p.parity] + 31u) >> 5, c->stream);
-    c->parityN[p.parity] = c->n;
   }
   if (c->producerKind && !(flags & SC_TICK_PRODUCE_NEXT)) {
     Scoped s(c, SC_TICK_K_NUDGE);
@@ -536,7 +533,7 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
     ok = ok && dalloc(c, d.binCount, c->sectors) && dalloc(c, d.binLayers, c->sectors) && dalloc(c, d.bins, (size_t)c->sectors * kBinCap * 2u, false)
             && dalloc(c, d.bigList, (N + 8u * kBorderBigCap) * 2u, false) && dalloc(c, d.spill, 2u * kSpillCap, false) && dalloc(c, d.spillSector, kSpillCap)
             && dalloc(c, d.bigBits[0], N / 32) && dalloc(c, d.bigBits[1], N / 32)
-            && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, 2u * kPairShards * kShardStride)
+            && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, 3u * kPairShards * kShardStride)
             && dalloc(c, c->dPairsOut, c->maxPairs, false) && dalloc(c, c->dPairTotal, 4);
   }
   if (ok) { void* p = nullptr; e = hipMalloc(&p, N * sizeof(ScTickDrawItem)); if (e != hipSuccess) ok = fail(c, "hipMalloc draws", e); else { c->allocs.push_back(p); c->dDraws = p; } }
@@ -1251,14 +1248,15 @@ int scTickGetCounts(ScTickContext* c, ScTickCounts* out)
   uint32_t k[32] = {};
   if (!d2h(c, k, c->d.counters, sizeof k) || !sync(c)) return 0;
   std::memset(out, 0, sizeof *out);
-  const uint32_t* bp = k + kCtrPar + 8u * c->lastParity;
+  const uint32_t resultSlot = c->pairsStream ? 2u : c->lastParity;      // pipelined tiles: the snapshot the pair kernel left
+  const uint32_t* bp = k + kCtrPar + 8u * resultSlot;
   out->entities = c->n;
   out->renderables_total = k[6];
   out->visible = k[0];
   out->culled = k[1];
   if (c->sectors && (c->lastFlags & SC_TICK_BROADPHASE) && !c->pairsPending) {
     TickParams pp{}; pp.maxPairs = c->maxPairs;
-    launchGatherPairs(c->d, pp, c->lastParity, c->dPairsOut, c->dPairTotal, c->stream);
+    launchGatherPairs(c->d, pp, resultSlot, c->dPairsOut, c->dPairTotal, c->stream);
     uint32_t tot[2] = {};
     if (!d2h(c, tot, c->dPairTotal, sizeof tot) || !sync(c)) return 0;
     out->pairs = tot[0];
@@ -1391,16 +1389,17 @@ int scTickReadPairs(ScTickContext* c, uint32_t* pairs2, uint32_t cap, uint32_t* 
   if (!joinPairs(c)) return 0;
   // the pair list is kept in per-shard segments on the device; gather them into one list first
   TickParams pp{}; pp.maxPairs = c->maxPairs;
-  launchGatherPairs(c->d, pp, c->lastParity, c->dPairsOut, c->dPairTotal, c->stream);
+  const uint32_t slot = c->pairsStream ? 2u : c->lastParity;          // pipelined tiles: the snapshot the pair kernel left
+  launchGatherPairs(c->d, pp, slot, c->dPairsOut, c->dPairTotal, c->stream);
   uint32_t tot[2] = {};
   if (!d2h(c, tot, c->dPairTotal, sizeof tot) || !sync(c)) return 0;
   *count = tot[0];
   // each shard keeps at most maxPairs / 64 pairs; recount what the gather could place
-  uint32_t sc[2u * kPairShards * kShardStride];
+  uint32_t sc[3u * kPairShards * kShardStride];
   if (!d2h(c, sc, c->d.pairShardCount, sizeof sc) || !sync(c)) return 0;
   uint32_t placed = 0;
   const uint32_t shardCap = c->maxPairs / kPairShards;
-  for (uint32_t s = 0; s < kPairShards; ++s) placed += std::min(sc[(c->lastParity * kPairShards + s) * kShardStride], shardCap);
+  for (uint32_t s = 0; s < kPairShards; ++s) placed += std::min(sc[(slot * kPairShards + s) * kShardStride], shardCap);
   const uint32_t take = std::min(placed, cap);
   if (take && pairs2) { if (!d2h(c, pairs2, c->dPairsOut, (size_t)take * 8u) || !sync(c)) return 0; }
   return 1;

@@ -727,15 +727,6 @@ __device__ __forceinline__ void resetOtherParity(const DeviceState& d, const Tic
   for (uint32_t w = bid * kTile + threadIdx.x; w < words; w += nblocks * kTile) nextBits[w] = 0u;
 }
 
-// pipelined tiles: the state of parity q -- used two ticks ago, its pair search finished -- is cleared right before the
-// fused kernel that fills it again
-__global__ __launch_bounds__(kTile) void k_reset_parity(const DeviceState d, uint32_t q, uint32_t words)
-{
-  if (blockIdx.x == 0 && threadIdx.x < 8) d.counters[kCtrPar + 8u * q + threadIdx.x] = 0u;
-  if (blockIdx.x == 0 && threadIdx.x < kPairShards) d.pairShardCount[(q * kPairShards + threadIdx.x) * kShardStride] = 0u;
-  for (uint32_t w = blockIdx.x * kTile + threadIdx.x; w < words; w += gridDim.x * kTile) d.bigBits[q][w] = 0u;
-}
-
 // Does this tile own sector (gx, gz) of its bin grid (coordinates may lie outside the grid)?  A sector belongs to
 // the tile nearest to it, so outside the core [1, binS-2] it is ours only on sides where no tile exists.
 __device__ __forceinline__ bool ownsSector(const TickParams& p, float gx, float gz)
@@ -994,6 +985,32 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     }
   }
   sinkFlush(d, p, sink);
+
+  // Pipelined tiles: nobody else may clear this parity's state (the next fused kernel of the OTHER parity is already running,
+  // the next of THIS parity starts when this kernel is done), so the last workgroup to finish copies the results to the
+  // snapshot slot the host reads (counter set 2, shard counter set 2) and clears counters, shard counters and big-box bits.
+  if (p.flags & kFlagDeferredReset) {
+    __shared__ uint32_t sLast;
+    // What the last workgroup reads -- counters and shard counters -- is only ever changed by device-scope atomics, so all
+    // that is needed before taking a ticket is that this workgroup's own atomics have completed.  (A __threadfence() here
+    // writes back the whole L2 of the XCD, full of the fused kernel's output: 100 us instead of 5.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) sLast = atomicAdd(&d.counters[kCtrTicket + p.parity], 1u) == nblocks - 1u ? 1u : 0u;
+    __syncthreads();
+    if (sLast) {
+      volatile uint32_t* ctrs = d.counters;
+      volatile uint32_t* shards = d.pairShardCount;
+      uint32_t cv = 0, sv = 0;
+      if (threadIdx.x < 8) cv = ctrs[ctr + threadIdx.x];
+      if (threadIdx.x < kPairShards) sv = shards[(p.parity * kPairShards + threadIdx.x) * kShardStride];
+      if (threadIdx.x < 8) { ctrs[kCtrPar + 16u + threadIdx.x] = cv; ctrs[ctr + threadIdx.x] = 0u; }
+      if (threadIdx.x < kPairShards) { shards[(2u * kPairShards + threadIdx.x) * kShardStride] = sv; shards[(p.parity * kPairShards + threadIdx.x) * kShardStride] = 0u; }
+      uint32_t* bits = d.bigBits[p.parity];
+      for (uint32_t w = threadIdx.x; w < p.bigClearWords; w += kTile) bits[w] = 0u;
+      if (threadIdx.x == 0) ctrs[kCtrTicket + p.parity] = 0u;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const TickParams p)
@@ -1520,11 +1537,6 @@ void launchMoveEntities(const DeviceState& d, const uint32_t* src, const uint32_
 void launchSetFrustum(const DeviceState& d, const Frustum6& fr, hipStream_t s)
 {
   hipLaunchKernelGGL(k_set_frustum, dim3(1), dim3(64), 0, s, const_cast<float*>(d.frustum), fr);
-}
-void launchResetParity(const DeviceState& d, uint32_t q, uint32_t words, hipStream_t s)
-{
-  const uint32_t blocks = std::max(1u, std::min((words + kTile - 1) / kTile, 64u));
-  hipLaunchKernelGGL(k_reset_parity, dim3(blocks), dim3(kTile), 0, s, d, q, words);
 }
 void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s)
 {
