@@ -37,5 +37,30 @@ flag = torch.tensor([1], dtype=torch.int32, device="cuda")
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 dist.barrier()
 torch.cuda.synchronize()
+# the pipelined flow bench.py uses at N > 1: torch's current stream is the PAIRS stream (the RCCL operation goes there),
+# the tick keeps the context's own stream; one all_to_all_single per step
+w2 = sw.generate(32, 32, 15)
+w2.group[::3], w2.mask[::3] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+ref = WorldTick.from_world(w2, broadphase=True, max_pairs=1 << 18)
+ref.set_frame_producer(1, 0.5); ref.nudge_roots_x(0.5)
+for _ in range(12):
+    ref.run(capi.FULL | capi.PRODUCE_NEXT)
+want_pairs = ref.counts().pairs
+p2 = WorldTick.from_world(w2, broadphase=True, max_pairs=1 << 18)
+ps = torch.cuda.Stream(device=0); torch.cuda.set_stream(ps)
+p2.set_pairs_stream(ps.cuda_stream)
+p2.set_tile(0, 0); p2.set_tile_grid(0, 0, 1, 1)
+p2.set_frame_producer(1, 0.5); p2.nudge_roots_x(0.5)
+a2a_in = torch.arange(33000, dtype=torch.int32, device="cuda"); a2a_out = torch.zeros_like(a2a_in)
+t0 = time.perf_counter()
+for _ in range(12):
+    p2.run(capi.FULL | capi.SPLIT_PAIRS | capi.PRODUCE_NEXT)
+    dist.all_to_all_single(a2a_out, a2a_in, [33000], [33000])
+    p2.run_pairs()
+p2.sync(); torch.cuda.synchronize()
+dt2 = (time.perf_counter() - t0) / 12
+got_pairs = p2.counts().pairs
+assert torch.equal(a2a_in, a2a_out) and got_pairs == want_pairs and want_pairs > 100, (got_pairs, want_pairs)
+print(f"pipelined flow with an all-to-all on the pairs stream ok: {got_pairs} pairs after 12 ticks, {dt2 * 1e6:.1f} us per step")
 print(f"rccl self test ok: {nbytes} B message, {dt * 1e6:.1f} us per step (2 ticks + 1 send/recv group), visible {t.counts().visible}")
 dist.destroy_process_group()
