@@ -1071,6 +1071,7 @@ int scTickRunPairs(ScTickContext* c)
   if (c->pendingParams.flags & SC_TICK_RAYS) launchRayQueries(ds, c->pendingParams, c->rays, ps);   // sees the neighbours' border boxes too
   if (c->pairsStream) {
     launchPairs(ds, c->pendingParams, ps);
+    launchSnapshotReset(ds, q, c->pendingParams.bigClearWords, ps);
     HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
     c->pairsInFlight[q] = true;
   } else {

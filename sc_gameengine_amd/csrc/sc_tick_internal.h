@@ -104,8 +104,7 @@ constexpr uint32_t kPairShards = 64, kShardStride = 32, kWavePairBuf = 256;
 constexpr uint32_t kPrimary = 0x80000000u;
 // counters[]: 0 visible, 1 culled, 4 draws, 5 dropped, 6 renderables; per tick parity q: 8+8q+{0 pairs, 1 big, 2 bin-full}
 constexpr uint32_t kCtrPar = 8, kCtrPairs = 0, kCtrBig = 1, kCtrBinFull = 2, kCtrBorderLost = 3, kCtrBigLocal = 4, kCtrSpill = 5;
-constexpr uint32_t kCtrTicket = 2;      // counters[2], [3]: pipelined tiles' "workgroups of the pair kernel done" per parity;
-                                        // counter set 2 (counters[24..31]) and shard counter set 2: snapshot of the last pair search
+// counter set 2 (counters[24..31]) and shard counter set 2: pipelined tiles' snapshot of the last pair search
 // (kCtrBig counts the big list: this tile's boxes, then -- after the border merge -- its neighbours' that reach it;
 //  kCtrBigLocal keeps this tile's own count; kCtrBorderLost: records or boxes a border message had no room for, or
 //  big boxes that reach beyond the eight neighbouring tiles -- pairs may be missing)
@@ -140,8 +139,8 @@ __host__ __device__ inline uint32_t borderRecCap(uint32_t L) { return L * kBorde
 __host__ __device__ inline uint32_t borderBinWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { const uint32_t L = borderLen(d, coreSX, coreSZ); return kBorderHeader + L + borderRecCap(L) * 8u; }
 __host__ __device__ inline uint32_t borderWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { return borderBinWords(d, coreSX, coreSZ) + kBorderBigWords; }
 constexpr uint32_t kFlagHasDeep = 1u << 16;   // write recomp bits for the level kernels
-constexpr uint32_t kFlagDeferredReset = 1u << 17;   // pipelined tiles: a pair kernel clears its OWN parity's counters / big bits when its last workgroup
-                                                    // is done (after copying the results to the snapshot slot), never the other parity's
+constexpr uint32_t kFlagDeferredReset = 1u << 17;   // pipelined tiles: a pair kernel never clears the other parity's counters / big bits; a small kernel
+                                                    // behind it on the pairs stream snapshots the results and clears its OWN parity
 constexpr uint32_t kFlagDenseAabbs = 1u << 5; // == SC_TICK_DENSE_AABBS
 
 // ---- renderer draw order (sc_tick_drawsort.hip) ----
@@ -187,6 +186,7 @@ void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, h
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);
 void launchMoveEntities(const DeviceState& d, const uint32_t* src, const uint32_t* dst, uint32_t moves, hipStream_t s);
 void launchSetFrustum(const DeviceState& d, const Frustum6& fr, hipStream_t s);
+void launchSnapshotReset(const DeviceState& d, uint32_t q, uint32_t words, hipStream_t s);
 void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s);
 void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s);
 void launchEmitDraws(const DeviceState& d, uint32_t budget, void* items, hipStream_t s);

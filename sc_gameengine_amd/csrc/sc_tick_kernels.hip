@@ -727,6 +727,24 @@ __device__ __forceinline__ void resetOtherParity(const DeviceState& d, const Tic
   for (uint32_t w = bid * kTile + threadIdx.x; w < words; w += nblocks * kTile) nextBits[w] = 0u;
 }
 
+// Pipelined tiles: queued on the pairs stream right behind the pair kernel of parity q.  Nobody else may clear this parity's
+// state -- the next fused kernel of the OTHER parity is already running, the next of THIS parity waits for this stream -- so
+// the results are copied to the snapshot slot the host reads (counter set 2, shard counter set 2) and counters, shard
+// counters and big-box bits are cleared here.  (Doing it in the pair kernel's last workgroup needs a ticket per workgroup:
+// a thousand device-scope atomics on one word cost more than this launch.)
+__global__ __launch_bounds__(kTile) void k_snapshot_reset(const DeviceState d, uint32_t q, uint32_t words)
+{
+  const uint32_t ctr = kCtrPar + 8u * q;
+  if (blockIdx.x == 0) {
+    uint32_t cv = 0, sv = 0;
+    if (threadIdx.x < 8) cv = d.counters[ctr + threadIdx.x];
+    if (threadIdx.x < kPairShards) sv = d.pairShardCount[(q * kPairShards + threadIdx.x) * kShardStride];
+    if (threadIdx.x < 8) { d.counters[kCtrPar + 16u + threadIdx.x] = cv; d.counters[ctr + threadIdx.x] = 0u; }
+    if (threadIdx.x < kPairShards) { d.pairShardCount[(2u * kPairShards + threadIdx.x) * kShardStride] = sv; d.pairShardCount[(q * kPairShards + threadIdx.x) * kShardStride] = 0u; }
+  }
+  for (uint32_t w = blockIdx.x * kTile + threadIdx.x; w < words; w += gridDim.x * kTile) d.bigBits[q][w] = 0u;
+}
+
 // Does this tile own sector (gx, gz) of its bin grid (coordinates may lie outside the grid)?  A sector belongs to
 // the tile nearest to it, so outside the core [1, binS-2] it is ours only on sides where no tile exists.
 __device__ __forceinline__ bool ownsSector(const TickParams& p, float gx, float gz)
@@ -985,32 +1003,6 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     }
   }
   sinkFlush(d, p, sink);
-
-  // Pipelined tiles: nobody else may clear this parity's state (the next fused kernel of the OTHER parity is already running,
-  // the next of THIS parity starts when this kernel is done), so the last workgroup to finish copies the results to the
-  // snapshot slot the host reads (counter set 2, shard counter set 2) and clears counters, shard counters and big-box bits.
-  if (p.flags & kFlagDeferredReset) {
-    __shared__ uint32_t sLast;
-    // What the last workgroup reads -- counters and shard counters -- is only ever changed by device-scope atomics, so all
-    // that is needed before taking a ticket is that this workgroup's own atomics have completed.  (A __threadfence() here
-    // writes back the whole L2 of the XCD, full of the fused kernel's output: 100 us instead of 5.)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x == 0) sLast = atomicAdd(&d.counters[kCtrTicket + p.parity], 1u) == nblocks - 1u ? 1u : 0u;
-    __syncthreads();
-    if (sLast) {
-      volatile uint32_t* ctrs = d.counters;
-      volatile uint32_t* shards = d.pairShardCount;
-      uint32_t cv = 0, sv = 0;
-      if (threadIdx.x < 8) cv = ctrs[ctr + threadIdx.x];
-      if (threadIdx.x < kPairShards) sv = shards[(p.parity * kPairShards + threadIdx.x) * kShardStride];
-      if (threadIdx.x < 8) { ctrs[kCtrPar + 16u + threadIdx.x] = cv; ctrs[ctr + threadIdx.x] = 0u; }
-      if (threadIdx.x < kPairShards) { shards[(2u * kPairShards + threadIdx.x) * kShardStride] = sv; shards[(p.parity * kPairShards + threadIdx.x) * kShardStride] = 0u; }
-      uint32_t* bits = d.bigBits[p.parity];
-      for (uint32_t w = threadIdx.x; w < p.bigClearWords; w += kTile) bits[w] = 0u;
-      if (threadIdx.x == 0) ctrs[kCtrTicket + p.parity] = 0u;
-    }
-  }
 }
 
 __global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const TickParams p)
@@ -1119,36 +1111,36 @@ __device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickP
   const uint32_t cap = borderRecCap(L);
   float4* records = reinterpret_cast<float4*>(msg + kBorderHeader + L);
   const bool anyBig = d.counters[kCtrPar + 8u * p.parity + kCtrBig] != 0u;      // else no box was pushed out of a bin: no lookups
-  // kTile ring bins at a time: a thread per bin finds its offset (parallel scan, carry across chunks) and copies its records
+  // 2 * kTile ring bins at a time (one pass for a 256-sector side): a thread takes two neighbouring bins, finds their
+  // offsets (parallel scan, carry across chunks) and copies their records.  Ring bins are sparse, and 512 bins in flight
+  // hide the latency that a wave-per-bin walk would serialise (measured: 59 us against 14).
+  auto copyBin = [&](uint32_t cell, uint32_t off, uint32_t take) {
+    const float4* src = d.bins + 2u * ((size_t)cell * kBinCap);
+    float4* dst = records + 2u * (size_t)off;
+    for (uint32_t r = 0; r < take; ++r) {
+      float4 lo = src[2u * r]; const float4 hi = src[2u * r + 1u];
+      // a box that found some bin full travels in the big section instead: its copies must not take part
+      // over there either (a zero layer word fails every group/mask filter)
+      const uint32_t id = __float_as_uint(hi.w) & ~kPrimary;
+      if (anyBig && (id & ~kParentMask) == p.rankBits && ((d.bigBits[p.parity][(id & kParentMask) >> 5] >> (id & 31u)) & 1u)) lo.w = 0.0f;
+      dst[2u * r] = lo; dst[2u * r + 1u] = hi;
+    }
+  };
   uint32_t carry = 0;
-  for (uint32_t base = 0; base < L; base += kTile) {
-    const uint32_t l = base + threadIdx.x;
-    uint32_t c = 0, cell = 0;
-    if (l < L) {
-      bool send = false;
-      cell = ringCell(p, dx, dz, l, &send);
-      if (send) { c = d.binCount[cell]; if (c > kBinCap) c = kBinCap; }
-    }
+  for (uint32_t base = 0; base < L; base += 2u * kTile) {
+    const uint32_t l0 = base + 2u * threadIdx.x, l1 = l0 + 1u;
+    uint32_t c0 = 0, c1 = 0, cell0 = 0, cell1 = 0;
+    if (l0 < L) { bool send = false; cell0 = ringCell(p, dx, dz, l0, &send); if (send) { c0 = d.binCount[cell0]; if (c0 > kBinCap) c0 = kBinCap; } }
+    if (l1 < L) { bool send = false; cell1 = ringCell(p, dx, dz, l1, &send); if (send) { c1 = d.binCount[cell1]; if (c1 > kBinCap) c1 = kBinCap; } }
     uint32_t total;
-    const uint32_t off = blockScanExclusive(c, carry, sWave, &total);
-    const uint32_t take = (off + c <= cap) ? c : (off < cap ? cap - off : 0u);
-    if (l < L) msg[kBorderHeader + l] = take;
-    // a thread per bin copies its (few) records: ring bins are sparse, and 256 bins in flight hide the latency that a
-    // wave-per-bin walk would serialise (measured: 59 us against 14)
-    if (l < L && take) {
-      const float4* src = d.bins + 2u * ((size_t)cell * kBinCap);
-      float4* dst = records + 2u * (size_t)off;
-      for (uint32_t r = 0; r < take; ++r) {
-        float4 lo = src[2u * r]; const float4 hi = src[2u * r + 1u];
-        // a box that found some bin full travels in the big section instead: its copies must not take part
-        // over there either (a zero layer word fails every group/mask filter)
-        const uint32_t id = __float_as_uint(hi.w) & ~kPrimary;
-        if (anyBig && (id & ~kParentMask) == p.rankBits && ((d.bigBits[p.parity][(id & kParentMask) >> 5] >> (id & 31u)) & 1u)) lo.w = 0.0f;
-        dst[2u * r] = lo; dst[2u * r + 1u] = hi;
-      }
-    }
+    const uint32_t off0 = blockScanExclusive(c0 + c1, carry, sWave, &total), off1 = off0 + c0;
+    const uint32_t take0 = (off0 + c0 <= cap) ? c0 : (off0 < cap ? cap - off0 : 0u);
+    const uint32_t take1 = (off1 + c1 <= cap) ? c1 : (off1 < cap ? cap - off1 : 0u);
+    if (l0 < L) msg[kBorderHeader + l0] = take0;
+    if (l1 < L) msg[kBorderHeader + l1] = take1;
+    if (take0) copyBin(cell0, off0, take0);
+    if (take1) copyBin(cell1, off1, take1);
     carry = total;
-    __syncthreads();
   }
   if (threadIdx.x == 0) { msg[0] = carry < cap ? carry : cap; msg[1] = carry > cap ? 1u : 0u; }
 
@@ -1224,35 +1216,36 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
   const uint32_t ctr = kCtrPar + 8u * p.parity;
   if (threadIdx.x == 0 && msg[1]) atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);   // sender ran out of message space
   const float4* records = reinterpret_cast<const float4*>(msg + kBorderHeader + L);
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < L; base += kTile) {
-    const uint32_t l = base + threadIdx.x;
-    const uint32_t c = l < L ? msg[kBorderHeader + l] : 0u;
-    uint32_t total;
-    const uint32_t off = blockScanExclusive(c, carry, sWave, &total);
+  auto landBin = [&](uint32_t l, uint32_t off, uint32_t c) {
     // the sender's ring cell l on its side (-dx,-dz) is this tile's cell l along its own side (dx,dz)
-    const uint32_t sector = (l < L) ? landingCell(p, dx, dz, l) : 0u;
-    if (c) {
-      const uint32_t slot0 = atomicAdd(&d.binCount[sector], c);
-      const float4* src = records + 2u * (size_t)off;
-      uint32_t lay = 0;
-      for (uint32_t r = 0; r < c; ++r) {
-        const float4 lo = src[2u * r], hi = src[2u * r + 1u];
-        lay |= __float_as_uint(lo.w);
-        if (slot0 + r < kBinCap) {
-          float4* dst = d.bins + 2u * ((size_t)sector * kBinCap + slot0 + r);
-          dst[0] = lo; dst[1] = hi;
-        } else {
-          // the landing bin is full: keep the record on the side, tagged with its sector; the pair search adds it back
-          const uint32_t q = atomicAdd(&d.counters[ctr + kCtrSpill], 1u);
-          if (q < kSpillCap) { d.spill[2u * q] = lo; d.spill[2u * q + 1u] = hi; d.spillSector[q] = sector; }
-          else atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);
-        }
+    const uint32_t sector = landingCell(p, dx, dz, l);
+    const uint32_t slot0 = atomicAdd(&d.binCount[sector], c);
+    const float4* src = records + 2u * (size_t)off;
+    uint32_t lay = 0;
+    for (uint32_t r = 0; r < c; ++r) {
+      const float4 lo = src[2u * r], hi = src[2u * r + 1u];
+      lay |= __float_as_uint(lo.w);
+      if (slot0 + r < kBinCap) {
+        float4* dst = d.bins + 2u * ((size_t)sector * kBinCap + slot0 + r);
+        dst[0] = lo; dst[1] = hi;
+      } else {
+        // the landing bin is full: keep the record on the side, tagged with its sector; the pair search adds it back
+        const uint32_t q = atomicAdd(&d.counters[ctr + kCtrSpill], 1u);
+        if (q < kSpillCap) { d.spill[2u * q] = lo; d.spill[2u * q + 1u] = hi; d.spillSector[q] = sector; }
+        else atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);
       }
-      if (lay) atomicOr(&d.binLayers[sector], lay);
     }
+    if (lay) atomicOr(&d.binLayers[sector], lay);
+  };
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < L; base += 2u * kTile) {
+    const uint32_t l0 = base + 2u * threadIdx.x, l1 = l0 + 1u;
+    const uint32_t c0 = l0 < L ? msg[kBorderHeader + l0] : 0u, c1 = l1 < L ? msg[kBorderHeader + l1] : 0u;
+    uint32_t total;
+    const uint32_t off0 = blockScanExclusive(c0 + c1, carry, sWave, &total);
+    if (c0) landBin(l0, off0, c0);
+    if (c1) landBin(l1, off0 + c0, c1);
     carry = total;
-    __syncthreads();
   }
   // the neighbour's big boxes that reach this tile join the big list behind this tile's own
   const uint32_t* big = msg + borderBinWords(dir, p.binSX - 2u, p.binSZ - 2u);
@@ -1537,6 +1530,11 @@ void launchMoveEntities(const DeviceState& d, const uint32_t* src, const uint32_
 void launchSetFrustum(const DeviceState& d, const Frustum6& fr, hipStream_t s)
 {
   hipLaunchKernelGGL(k_set_frustum, dim3(1), dim3(64), 0, s, const_cast<float*>(d.frustum), fr);
+}
+void launchSnapshotReset(const DeviceState& d, uint32_t q, uint32_t words, hipStream_t s)
+{
+  const uint32_t blocks = std::max(1u, std::min((words + kTile - 1) / kTile, 32u));
+  hipLaunchKernelGGL(k_snapshot_reset, dim3(blocks), dim3(kTile), 0, s, d, q, words);
 }
 void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s)
 {
