@@ -386,6 +386,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.bigClearWords = ((c->pairsStream ? c->n : c->prevBroadphaseN) + 31u) >> 5;      // pipelined: a pair kernel clears its own parity
   if (c->pairsStream && (flags & SC_TICK_BROADPHASE)) p.flags |= kFlagDeferredReset;
   if (flags & SC_TICK_PRODUCE_NEXT) { p.producerKind = c->producerKind; p.producerParam = c->producerParam; }
+  p.bigCap = c->cap + 8u * kBorderBigCap;
   p.tileX = c->tileX; p.tileZ = c->tileZ; p.tilesX = c->tilesX; p.tilesZ = c->tilesZ;
 }
 

@@ -126,6 +126,7 @@ struct TickParams {
   uint32_t chain;           // min(deepest hierarchy level, kMaxChain): selects the fused kernel's specialisation
   uint32_t tileX, tileZ, tilesX, tilesZ;   // this tile's place in the grid of equal tiles (tilesX == 0: unknown, no big-box exchange)
   uint32_t producerKind; float producerParam;   // with SC_TICK_PRODUCE_NEXT: the frame producer fused into the end-of-tick kernel
+  uint32_t bigCap;          // entries the big list can hold (capacity + room for the neighbours' boxes): every index into it is held below this
   uint32_t bigClearWords;   // words of the other parity's bigBits the previous broadphase tick may have set (its entity count / 32)
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d

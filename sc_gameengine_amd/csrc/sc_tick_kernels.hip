@@ -205,6 +205,7 @@ __device__ __forceinline__ BinPlan planBins(const TickParams& p, const float mn[
 __device__ __forceinline__ void appendBig(const DeviceState& d, const TickParams& p, const float4& rmin, const float4& rmax)
 {
   const uint32_t slot = atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBig], 1u);
+  if (slot >= p.bigCap) return;                    // cannot happen with a sane counter (one entry per entity at most): never write outside
   d.bigList[2u * (size_t)slot] = rmin;
   d.bigList[2u * (size_t)slot + 1u] = rmax;
 }
@@ -779,7 +780,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   const uint32_t totalWaves = nblocks * (kTile / 64);
   const uint32_t sectors = p.binSX * p.binSZ;
   const uint32_t ctr = kCtrPar + 8u * p.parity;
-  const uint32_t nbig = d.counters[ctr + kCtrBig];
+  const uint32_t nbig = min(d.counters[ctr + kCtrBig], p.bigCap);      // (bounded whatever the counter holds)
   const uint32_t nspill = min(d.counters[ctr + kCtrSpill], kSpillCap);
   const uint32_t* bigBits = d.bigBits[p.parity];
   float4* T = tile[wave];
@@ -1151,7 +1152,7 @@ __device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickP
   if (threadIdx.x == 0) { bigCount = 0u; bigLost = 0u; }
   __syncthreads();
   const uint32_t ctr = kCtrPar + 8u * p.parity;
-  const uint32_t nLocal = d.counters[ctr + kCtrBig];          // the merge has not run yet: only this tile's boxes
+  const uint32_t nLocal = min(d.counters[ctr + kCtrBig], p.bigCap);          // the merge has not run yet: only this tile's boxes
   if (p.tilesX) {
     const float SX = (float)(p.binSX - 2u), SZ = (float)(p.binSZ - 2u);
     const float inf = INFINITY;
@@ -1240,11 +1241,13 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
   uint32_t carry = 0;
   for (uint32_t base = 0; base < L; base += 2u * kTile) {
     const uint32_t l0 = base + 2u * threadIdx.x, l1 = l0 + 1u;
-    const uint32_t c0 = l0 < L ? msg[kBorderHeader + l0] : 0u, c1 = l1 < L ? msg[kBorderHeader + l1] : 0u;
+    // (counts are what a neighbour wrote: held to what a message can carry whatever arrives)
+    const uint32_t c0 = l0 < L ? min(msg[kBorderHeader + l0], kBinCap) : 0u, c1 = l1 < L ? min(msg[kBorderHeader + l1], kBinCap) : 0u;
     uint32_t total;
     const uint32_t off0 = blockScanExclusive(c0 + c1, carry, sWave, &total);
-    if (c0) landBin(l0, off0, c0);
-    if (c1) landBin(l1, off0 + c0, c1);
+    const uint32_t recCap = borderRecCap(L);
+    if (c0 && off0 + c0 <= recCap) landBin(l0, off0, c0);
+    if (c1 && off0 + c0 + c1 <= recCap) landBin(l1, off0 + c0, c1);
     carry = total;
   }
   // the neighbour's big boxes that reach this tile join the big list behind this tile's own
@@ -1257,7 +1260,7 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
   __syncthreads();
   const uint32_t at = sOff[0];
   const float4* src = reinterpret_cast<const float4*>(big + 2);
-  for (uint32_t r = threadIdx.x; r < 2u * m; r += kTile) d.bigList[2u * (size_t)at + r] = src[r];
+  for (uint32_t r = threadIdx.x; r < 2u * m; r += kTile) if (at + r / 2u < p.bigCap) d.bigList[2u * (size_t)at + r] = src[r];
 }
 
 // ------------------------------------------------------------------------------------------

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kTile) void k_ray_queries(const DeviceState d, cons
         }
       }
   }
-  const uint32_t nbig = d.counters[kCtrPar + 8u * p.parity + kCtrBig];
+  const uint32_t nbig = min(d.counters[kCtrPar + 8u * p.parity + kCtrBig], p.bigCap);
   for (uint32_t b = lane; b < nbig; b += 64u) consider(d.bigList[2u * (size_t)b], d.bigList[2u * (size_t)b + 1u]);
 
   // closest hit of the wave: distances are >= 0, so their bit patterns order like the values
