@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- entities/sec of one world tick on MI355X (BASELINE.json metric).
 
-A step = the upstream producer (every root's localPos.x += 0.01, marked dirty: SynthWorld dirty
-regime (ii)) followed by one pass of the hot path over the resident world: TransformSystem +
-CullingSystem (+ broadphase once built), through the C ABI.  Workload at N=1: SynthWorld v1
-config 3 (256x256 sectors, 15 props + ground slab each = 1 048 576 entities, depths 0/1/2).
-With --gpus N the world is N tiles of that size (weak scaling), one process per GPU.
+A step = one pass of the hot path over the resident world -- TransformSystem + CullingSystem + AABB broadphase,
+through the C ABI -- followed by the upstream producer of the NEXT frame (config 3: every root's localPos.x += 0.01,
+marked dirty: SynthWorld dirty regime (ii); config 5: vehicles and peds advanced), which rides on the end-of-tick kernel.
+Workload at N=1: SynthWorld v1 config 3 (256x256 sectors, 15 props + ground slab each = 1 048 576 entities, depths
+0/1/2).  With --gpus N the world is N tiles of that size (weak scaling), one process per GPU; the only exchange on
+the path, the broadphase's border boxes, is issued by the library itself (its own RCCL communicator: one group of
+ncclSend / ncclRecv per step).  This script's N>1 duties are the rendezvous of the communicator id and the timing.
 
-Prints ONE JSON line (rank 0).  The oracle is used only for the cpu_baseline leg.
+Parity gate IN THE RUN: after the timed region the oracle (liboracle.so, CPU) is brought to the same frame
+-- the same number of producer steps on the same world -- and the visible list, every world matrix and the pair set are
+compared with what the GPU holds.  A mismatch exits non-zero; no number is printed.  The oracle is used for that and
+for the cpu_baseline leg only, never inside the timed region.
+
+Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -20,18 +27,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (vendor peak); the copy ceiling is measured below
 TILE_SECTORS = 256
 PROPS = 15
 
 
-def algorithmic_bytes_per_entity(child_frac, stages):
+def algorithmic_bytes_per_entity(child_frac, stages, dirty_frac=1.0):
     """Per-launch algorithmic bytes of the dominant kernel k_xform_cull:
-    xform 88 + 48*C/N (SURVEY 8d); cull +24 (bounds; the 4*V/N index list is written by k_compact);
+    xform 88 + 48*C/N (SURVEY 8d); cull +24 (bounds; the 4*V/N index list is written by the end-of-tick kernel);
     broadphase +32 (the AABB record written into its sector bin; bounds are read once for both).
     SURVEY 8d's further 96 B/entity of broadphase traffic (dense AABB array, sort scatter) do not
-    exist in this design -- boxes are binned directly -- and are NOT counted anywhere."""
-    b = 88.0 + 48.0 * child_frac
+    exist in this design -- boxes are binned directly -- and are NOT counted anywhere.
+    dirty_frac < 1 (config 5): a clean entity re-reads its stored matrix (48 B) instead of 40 B in / 48 B out."""
+    b = dirty_frac * (88.0 + 48.0 * child_frac) + (1.0 - dirty_frac) * 48.0
     if "cull" in stages or "broadphase" in stages:
         b += 24.0
     if "broadphase" in stages:
@@ -39,11 +47,29 @@ def algorithmic_bytes_per_entity(child_frac, stages):
     return b
 
 
-def pmc_traffic(stages, entities_per_gpu, workload="config3"):
-    """HBM bytes per k_xform_cull launch from the committed rocprofv3 PMC passes (tools/pmc_session.sh ->
-    profiles/pmc_traffic.json): FETCH_SIZE and WRITE_SIZE collected in separate passes and calibrated on
-    known-byte copy kernels of the same access widths (FETCH_SIZE under-counts 2x on gfx950).  None when
-    no profile of this exact workload is committed."""
+def end_of_tick_bytes(n, roots, visible, sectors, records_read, pairs, stages, producer_kind):
+    """Algorithmic bytes of one launch of the end-of-tick kernel (k_compact_pairs): compaction role = visibility words in
+    (N/8), ordered list out (4 V), dirty words in and out (N/4); the next frame's producer = link word in (4 N) + the moved
+    positions in and out (config 3: x of every root, 8 B; config 5: x, z and six mover words of every entity, see
+    DESIGN section 5); pair role = bin counters and layer summaries in and out (16 B per sector), the records of the bins
+    that can hold a pair (32 B each) and the pairs out (8 P)."""
+    b = 0.0
+    if "cull" in stages:
+        b += n / 8.0 + 4.0 * visible
+    b += n / 4.0
+    if producer_kind == 1:
+        b += 4.0 * n + 8.0 * roots
+    elif producer_kind == 2:
+        b += (4.0 + 24.0 + 8.0) * n + 8.0 * roots
+    if "broadphase" in stages:
+        b += 16.0 * sectors + 32.0 * records_read + 8.0 * pairs
+    return b
+
+
+def pmc_traffic(stages, entities_per_gpu, workload="config3", kernel="k_xform_cull"):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_session.sh -> profiles/pmc_traffic.json):
+    FETCH_SIZE and WRITE_SIZE collected in separate passes and calibrated on known-byte copy kernels of the same
+    access widths (FETCH_SIZE under-counts 2x on gfx950).  None when no profile of this exact workload is committed."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(path))
@@ -52,12 +78,12 @@ def pmc_traffic(stages, entities_per_gpu, workload="config3"):
     cfg = d.get("bench_config", {})
     if sorted(cfg.get("stages", [])) != sorted(stages) or cfg.get("entities_per_gpu") != entities_per_gpu or cfg.get("workload", "config3") != workload:
         return None
-    return d.get("kernels", {}).get("k_xform_cull", {}).get("hbm_bytes_per_launch")
+    return d.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
 
 
 def copy_ceiling_gbs(torch, device):
-    """Measured device copy rate (read + write bytes per second) of a 1 GiB buffer, the practical HBM
-    ceiling SURVEY 8d asks to report next to the vendor peak."""
+    """Measured device copy rate (read + write bytes per second) of a 1 GiB buffer with torch's D2D copy: the practical
+    HBM ceiling of THIS box, reported next to the vendor peak (boxes differ: 4.8-5.5 TB/s seen)."""
     n = 1 << 28
     a = torch.empty(n, dtype=torch.float32, device=device)
     b = torch.empty_like(a)
@@ -76,38 +102,104 @@ def copy_ceiling_gbs(torch, device):
     return 2.0 * n * 4 / (ms * 1e-3) / 1e9
 
 
-def cpu_baseline(world, ticks=20, warm=3, workers=None):
-    """Reference-faithful CPU tick (oracle port), timed on this host: Transform + Camera + Culling,
-    hardware_concurrency()-1 workers as the sandbox does (src/sandbox/src/main.cpp:52-54)."""
-    from oracle import oracle_py as oracle
-    oracle.build()
-    hw = os.cpu_count() or 1
-    workers = max(hw - 1, 1) if workers is None else workers
-    oracle.lib().orc_jobs_init(workers)
-    ow = oracle.OracleWorld.from_arrays(world.pos, world.rot, world.scale, world.parent, world.bmin, world.bmax,
-                                        has_mesh=world.has_mesh, has_bounds=world.has_bounds)
-    ow.add_camera_entity(world.camera["pos"], world.camera["rot"], aspect=world.camera["aspect"])
-    times = []
-    vel = None if world.mover_kind is None else world.mover_vel.copy()
-    for k in range(warm + ticks):
-        if vel is None:
-            ow.nudge_roots_x(0.01)
+def make_world(args, rank, grid):
+    from sc_gameengine_amd import synth_world as sw
+    tx, tz = grid
+    S = args.sectors
+    if args.workload == "config5":
+        SX, SZ = S // 2, S                       # 128 x 256 sectors x 32 entities = the same 1 048 576 per GPU
+        origin = ((rank % tx) * SX, (rank // tx) * SZ)
+        w = sw.generate_config5(SX, SZ, origin=origin)
+    else:
+        SX, SZ = S, S
+        origin = ((rank % tx) * S, (rank // tx) * S)
+        w = sw.generate(S, S, PROPS, hierarchy=True, origin=origin)
+        if args.workload == "config3dyn":        # one prop per sector is a dynamic body: every bin holds an admissible pair partner
+            dyn = (np.arange(w.n) % 16) == 4
+            w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    cam = sw.default_camera(float(tx * SX) * 64.0)
+    cam["pos"][2] = np.float32(float(tz * SZ) * 64.0 / 2)
+    w.camera = cam
+    return w, SX, SZ
+
+
+class OracleLeg:
+    """The checker: liboracle.so on the same world.  Used after the timed region only."""
+
+    def __init__(self, world):
+        from oracle import oracle_py as oracle
+        oracle.build()
+        self.oracle = oracle
+        self.world = world
+        self.ow = oracle.OracleWorld.from_arrays(world.pos, world.rot, world.scale, world.parent, world.bmin, world.bmax,
+                                                 has_mesh=world.has_mesh, has_bounds=world.has_bounds)
+        self.has_camera = False
+        self.vel = None if world.mover_kind is None else world.mover_vel.copy()
+
+    def produce(self):
+        if self.vel is None:
+            self.ow.nudge_roots_x(0.01)
         else:
-            ow.advance_movers(world.mover_kind, vel, world.mover_lo, world.mover_hi, 1.0 / 60.0)
-        t0 = time.perf_counter()
-        ow.tick()
-        dt = time.perf_counter() - t0
-        if k >= warm:
-            times.append(dt)
-    vis = len(ow.visible())
-    ow.close()
-    oracle.lib().orc_jobs_init(0)
-    med = float(np.median(times))
-    return {"value": world.n / med, "unit": "entities/s", "cores": workers + 1, "kind": "port",
-            "sample": f"same world ({world.n} entities), {warm} warm-up + {ticks} timed ticks, "
-                      f"{'all roots nudged' if vel is None else 'movers advanced'} each tick, "
-                      f"median tick {med * 1e3:.1f} ms (xform+camera+cull), host cpus {hw}",
-            "visible": vis}
+            w = self.world
+            self.ow.advance_movers(w.mover_kind, self.vel, w.mover_lo, w.mover_hi, 1.0 / 60.0)
+
+    def parity(self, t, producer_steps, stages, view_proj):
+        """Bring the oracle to the frame the GPU ticked last (`producer_steps` producer applications, each exactly the
+        device's arithmetic, applied one after the other) and compare.  viewProj is an INPUT of the path on both sides
+        (CameraSystem stays on the host): the oracle culls with the matrix the GPU was given."""
+        w, ow = self.world, self.ow
+        for _ in range(producer_steps):
+            self.produce()
+        ow.transform_system()
+        ow.culling_system(view_proj=view_proj)
+        out = {"ticks": producer_steps}
+        if "cull" in stages:
+            gv, cv = t.visible(), ow.visible()
+            out["visible_equal"] = bool(np.array_equal(gv, cv))
+            out["visible"] = int(len(cv))
+        gm, cm = t.world_matrices(), ow.world_matrices()[:w.n]
+        out["matrices_equal"] = bool(np.array_equal(gm, cm))    # IEEE equality, element for element (+0 == -0)
+        out["matrices_compared"] = int(w.n)
+        if "broadphase" in stages:
+            mn, mx = ow.world_aabbs()
+            want = self.oracle.broadphase_grid(mn[:w.n], mx[:w.n], w.group, w.mask, 64.0)      # the oracle's search on the oracle's boxes
+            got, total = t.pairs()
+            key = np.sort(got[:, 0].astype(np.uint64) << np.uint64(32) | got[:, 1].astype(np.uint64))
+            wkey = want[:, 0].astype(np.uint64) << np.uint64(32) | want[:, 1].astype(np.uint64)
+            out["pairs_equal"] = bool(total == len(want) and np.array_equal(key, wkey))
+            out["pairs"] = int(len(want))
+        out["ok"] = all(v for k, v in out.items() if k.endswith("_equal"))
+        return out
+
+    def baseline(self, ticks=20, warm=3, workers=None):
+        """Reference-faithful CPU tick (oracle port), timed on this host: Transform + Camera + Culling,
+        hardware_concurrency()-1 workers as the sandbox does (src/sandbox/src/main.cpp:52-54)."""
+        hw = os.cpu_count() or 1
+        workers = max(hw - 1, 1) if workers is None else workers
+        if not self.has_camera:                                 # the timed tick is Transform + Camera + Culling, as the sandbox registers them
+            cam = self.world.camera
+            self.ow.add_camera_entity(cam["pos"], cam["rot"], aspect=cam["aspect"])
+            self.has_camera = True
+        self.oracle.lib().orc_jobs_init(workers)
+        times = []
+        for k in range(warm + ticks):
+            self.produce()
+            t0 = time.perf_counter()
+            self.ow.tick()
+            dt = time.perf_counter() - t0
+            if k >= warm:
+                times.append(dt)
+        self.oracle.lib().orc_jobs_init(0)
+        med = float(np.median(times))
+        n = self.world.n
+        return {"value": n / med, "unit": "entities/s", "cores": workers + 1, "kind": "port",
+                "threading": "pthread range pool over groups of 128 (the reference's per-worker rings / stealing are not restated)" if workers else "single thread",
+                "sample": f"same world ({n} entities), {warm} warm-up + {ticks} timed ticks, "
+                          f"{'all roots nudged' if self.vel is None else 'movers advanced'} each tick, "
+                          f"median tick {med * 1e3:.1f} ms (xform+camera+cull), host cpus {hw}"}
+
+    def close(self):
+        self.ow.close()
 
 
 def main():
@@ -118,50 +210,43 @@ def main():
     ap.add_argument("--sectors", type=int, default=TILE_SECTORS, help="tile side in sectors (default 256 = 1M entities per GPU)")
     ap.add_argument("--stages", default="auto", help="comma list of xform,cull,broadphase (auto = all that are built)")
     ap.add_argument("--graph", type=int, default=0, help="replay the frame from a hipGraph")
-    ap.add_argument("--workload", default="config3", choices=["config3", "config5"],
+    ap.add_argument("--workload", default="config3", choices=["config3", "config3dyn", "config5"],
                     help="config3: 16 static entities per sector, every root nudged each step (the metric's config); "
+                         "config3dyn: the same with one prop per sector a dynamic body (every bin holds pair work); "
                          "config5: 16 static + 12 vehicles + 4 peds per sector, agents advanced on device each step")
-    ap.add_argument("--sample", type=int, default=8, help="record HIP events on every n-th step (1 = all)")
+    ap.add_argument("--sample", type=int, default=0, help="record HIP events on every n-th step (0 = every step up to 64 steps, else every 8th)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity gate (profiling sessions only; the line then says so)")
     ap.add_argument("--pipeline", type=int, default=1, help="N>1: pair-search half of tick t on a second stream under the fused kernel of tick t+1")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
-    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--control", default="gloo", help="torch.distributed backend of the CONTROL plane at N>1 (rendezvous of the RCCL id, barrier, "
+                                                       "max-over-ranks timing); the data path is the library's own RCCL communicator either way")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal on one GPU: every rank uses GPU 0 and the messages move by host staging (no RCCL)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from sc_gameengine_amd import capi, synth_world as sw, tiles
+    from sc_gameengine_amd import capi, tiles
     from sc_gameengine_amd.tick import WorldTick, camera_view_proj
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world_size > 1:
-        if args.backend == "nccl":
+        if args.control == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.control)
+    ctl_device = "cuda" if (world_size > 1 and args.control == "nccl") else "cpu"
 
     grid = tiles.tile_grid(world_size)
     tx, tz = grid
-    S = args.sectors
-    origin = ((rank % tx) * S, (rank // tx) * S)
-    if args.workload == "config5":
-        SX, SZ = S // 2, S                       # 128 x 256 sectors x 32 entities = the same 1 048 576 per GPU
-        origin = ((rank % tx) * SX, (rank // tx) * SZ)
-        w = sw.generate_config5(SX, SZ, origin=origin)
-    else:
-        SX, SZ = S, S
-        w = sw.generate(S, S, PROPS, hierarchy=True, origin=origin)
-    cam = sw.default_camera(float(tx * SX) * 64.0)
-    cam["pos"][2] = np.float32(float(tz * SZ) * 64.0 / 2)
-    w.camera = cam
+    w, SX, SZ = make_world(args, rank, grid)
+    cam = w.camera
 
     built = ["xform", "cull"] + (["broadphase"] if capi.HAVE_PAIR_SEARCH else [])
     stages = built if args.stages == "auto" else args.stages.split(",")
@@ -174,28 +259,27 @@ def main():
         flags |= capi.BROADPHASE
 
     t = WorldTick.from_world(w, device=local_rank, broadphase=("broadphase" in stages))
-    t.set_view_proj(camera_view_proj(cam))
+    view_proj = camera_view_proj(cam)
+    t.set_view_proj(view_proj)
     t.set_graph_mode(bool(args.graph))
 
-    # N > 1: the broadphase's border boxes are the one exchange on the path.  The context runs on
-    # torch's current stream so the RCCL send/recv group is stream-ordered with the kernels around it
-    # (no host synchronisation inside a step).
+    # N > 1: the broadphase's border boxes are the one exchange on the path.  The library owns it: its own RCCL communicator
+    # (ncclCommInitRank from the id rank 0 made), the message buffers of both tick parities, and -- pipelined -- a second
+    # stream on which exchange, merge and pair search of tick t run under the fused kernel of tick t+1.  A step is ONE call
+    # (scTickTileStep).  Any failure here raises: a line is never printed with a stage dropped.
+    exchange = "none"
     borders = None
-    tick_stream = pairs_stream = None
     if world_size > 1 and (flags & capi.BROADPHASE):
-        if args.pipeline:
-            # the exchange, the merge and the pair search of tick t run on a second stream under the fused kernel of tick t+1
-            # (bins and messages are double-buffered by tick parity; the library orders the halves with events).  That
-            # second stream is torch's current stream, where the RCCL operation goes; the tick keeps the context's own.
-            pairs_stream = torch.cuda.Stream(device=local_rank)
-            torch.cuda.set_stream(pairs_stream)
-            t.set_pairs_stream(pairs_stream.cuda_stream)
+        if args.same_device:
+            # rehearsal without RCCL (several ranks on one GPU cannot form a communicator): host-staged point-to-point over the
+            # control plane; exercises the multi-rank bench flow only
+            borders = tiles.BorderBuffers(t, rank, grid, torch.device("cuda", local_rank), pipelined=False)
+            exchange = "REHEARSAL: host-staged point-to-point over the control plane (no RCCL)"
         else:
-            tick_stream = torch.cuda.Stream(device=local_rank)
-            torch.cuda.set_stream(tick_stream)        # torch's current stream for everything below, RCCL ops included
-            t.set_stream(tick_stream.cuda_stream, external=True)
-        borders = tiles.BorderBuffers(t, rank, grid, torch.device("cuda", local_rank), pipelined=bool(args.pipeline))
-    tick_parity = [0]
+            uid = tiles.rendezvous_unique_id(rank, capi.comm_unique_id)
+            tiles.setup_tile(t, rank, grid, uid, pipelined=bool(args.pipeline))
+            exchange = ("border AABBs to <=8 neighbour tiles per step: one group of ncclSend/ncclRecv issued by libsc_tick.so on its own "
+                        "RCCL communicator" + (", on the pairs stream under the next tick's fused kernel" if args.pipeline else ""))
 
     # The frame producer (config 3: every root nudged; config 5: vehicles and peds advanced) is part of every step.  It
     # runs fused into the end-of-tick kernel as the producer of the NEXT frame (SC_TICK_PRODUCE_NEXT): same work per
@@ -207,16 +291,17 @@ def main():
     else:
         t.nudge_roots_x(param)
     flags |= capi.PRODUCE_NEXT
+    ticks_done = [0]
 
     def step():
-        if borders is None:
-            t.run(flags)
-            return
-        t.run(flags | capi.SPLIT_PAIRS)           # ... bins filled, border messages packed, next frame produced
-        borders.exchange(parity=tick_parity[0])   # neighbour messages over RCCL (xGMI), one all-to-all, on the current stream
-        if pairs_stream is not None:
-            tick_parity[0] ^= 1
-        t.run_pairs()                             # merge what arrived, pair search (on the pairs stream when pipelined)
+        ticks_done[0] += 1
+        if borders is not None:
+            t.run(flags | capi.SPLIT_PAIRS)
+            t.sync()
+            borders.exchange()
+            t.run_pairs()
+        else:
+            t.tile_step(flags)                    # N == 1: a plain scTickRun; N > 1: tick + pack, RCCL group, merge + pair search
 
     def fence():
         t.sync()
@@ -225,34 +310,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    exchange_note = None
-    if borders is not None:
-        # one guarded step first: if the RCCL point-to-point group cannot run on this node, every rank learns it
-        # (min-reduce of a flag) and the broadphase stage is dropped -- and reported as dropped -- instead of
-        # crashing the whole scaling measurement
-        ok = 1
-        try:
-            step()
-            fence()
-        except Exception as e:                                  # noqa: BLE001
-            ok = 0
-            exchange_note = f"border exchange failed ({type(e).__name__}: {e}); broadphase stage dropped"
-            print(exchange_note, file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            exchange_note = exchange_note or "border exchange failed on another rank; broadphase stage dropped"
-            borders = None
-            stages = [x for x in stages if x != "broadphase"]
-            flags &= ~capi.BROADPHASE
-            if pairs_stream is not None:
-                t.set_pairs_stream(0)
-                pairs_stream = None
-            t.set_stream(0, external=False)
     for _ in range(args.warmup):
         step()
     fence()
-    t.set_profiling(args.sample)          # HIP events on every n-th tick, inside the timed region
+    sample = args.sample if args.sample > 0 else (1 if args.steps <= 64 else 8)
+    t.set_profiling(sample)               # HIP events on every n-th tick, inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -266,20 +328,44 @@ def main():
     counts = t.counts()
 
     if world_size > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctl_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # ---- parity gate: every rank checks its own tile against the oracle on the same frame ----
+    leg = None
+    parity = {"skipped": "--no-parity"}
+    if not args.no_parity:
+        leg = OracleLeg(w)
+        parity = leg.parity(t, ticks_done[0], [s for s in stages if not (s == "broadphase" and world_size > 1)], view_proj)
+        if world_size > 1:
+            parity["note"] = "per tile: visible list and matrices of every rank's own tile; cross-tile pairs are covered by tests/test_gpu_tiles*.py"
+            ok = torch.tensor([1 if parity["ok"] else 0], dtype=torch.int32, device=ctl_device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            parity["all_ranks_ok"] = bool(int(ok.item()))
+        if not parity["ok"] or not parity.get("all_ranks_ok", True):
+            print(f"PARITY MISMATCH on rank {rank}: {json.dumps(parity)}", file=sys.stderr)
+            t.close()
+            if world_size > 1:
+                dist.destroy_process_group()
+            sys.exit(3)
 
     if rank == 0:
         n_total = w.n * world_size
         child_frac = float((w.parent >= 0).mean())
-        bpe = algorithmic_bytes_per_entity(child_frac, stages)
-        if args.workload == "config5":
-            # only the movers (half the world, all roots) are rebuilt: they read 40 B of locals and write 48 B;
-            # the clean half re-reads its stored matrix (48 B) for the sphere test / AABB instead
-            bpe = 0.5 * 88.0 + 0.5 * 48.0 + (24.0 if ("cull" in stages or "broadphase" in stages) else 0.0) + (32.0 if "broadphase" in stages else 0.0)
+        roots = int((w.parent < 0).sum())
+        dirty_frac = 0.5 if args.workload == "config5" else 1.0      # config 5: only the movers (half the world, all roots) are rebuilt
+        bpe = algorithmic_bytes_per_entity(0.0 if args.workload == "config5" else child_frac, stages, dirty_frac)
         k1_ms = float(np.mean(k1)) if len(k1) else float("nan")
         achieved = (w.n * bpe) / (k1_ms * 1e-3) / 1e9 if len(k1) else None
+        sectors = (SX + 2) * (SZ + 2)
+        # records the pair role has to read: every record of a bin that holds an admissible pair partner (config 3: none)
+        per_sector = 32 if args.workload == "config5" else 16
+        records_read = 0 if args.workload == "config3" else int(round((per_sector + 3.0) / per_sector * w.n))   # + the ground slab's three extra copies
+        eot_ms = float(np.mean(kp)) if len(kp) else None
+        eot_bytes = end_of_tick_bytes(w.n, roots if kind == 1 else int((w.mover_kind > 0).sum()), int(counts.visible), sectors,
+                                      records_read, int(counts.pairs), stages, kind)
+        eot_achieved = (eot_bytes / (eot_ms * 1e-3) / 1e9) if eot_ms else None
         out = {
             "metric": "entities/sec world-tick (xform+broadphase+cull), 1M-entity world",
             "value": n_total * args.steps / elapsed,
@@ -294,10 +380,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"SynthWorld v1 config 3 per GPU: {SX}x{SZ} sectors x (15 props + ground) = {w.n} entities, "
-                             f"depths 0/1/2, every root nudged +0.01 m in x and marked dirty each step") if args.workload == "config3" else
-                            (f"SynthWorld v1 config 5 per GPU: {SX}x{SZ} sectors x (ground + 15 props + 12 vehicles + 4 peds) = {w.n} "
-                             f"entities, vehicles and peds advanced on device each step (dt 1/60), props static"),
+                "workload": {
+                    "config3": f"SynthWorld v1 config 3 per GPU: {SX}x{SZ} sectors x (15 props + ground) = {w.n} entities, depths 0/1/2, every root "
+                               f"nudged +0.01 m in x and marked dirty each step; all bodies static, so the pair pass is filter-skipped (pairs: 0)",
+                    "config3dyn": f"SynthWorld v1 config 3 per GPU with one prop per sector a dynamic body: {SX}x{SZ} sectors x 16 = {w.n} entities, "
+                                  f"every root nudged each step; every bin holds pair work",
+                    "config5": f"SynthWorld v1 config 5 per GPU: {SX}x{SZ} sectors x (ground + 15 props + 12 vehicles + 4 peds) = {w.n} "
+                               f"entities, vehicles and peds advanced on device each step (dt 1/60), props static",
+                }[args.workload],
                 "stages": stages,
                 "producer": "per step, fused into the end-of-tick kernel as the next frame's producer",
                 "tiles": f"{tx}x{tz}",
@@ -305,21 +395,28 @@ def main():
                 "visible": int(counts.visible),
                 "pairs": int(counts.pairs),
                 "graph": bool(args.graph),
-                "pipelined": bool(pairs_stream is not None),
-                "exchange": (exchange_note or ("border AABBs to <=8 neighbour tiles per step, one RCCL all-to-all with split sizes" if borders is not None else "none")),
+                "pipelined": bool(world_size > 1 and args.pipeline and borders is None),
+                "exchange": exchange,
                 "resident": "device SoA authoritative; no per-step host transfer",
-                "backend": args.backend if world_size > 1 else None,
+                "control_plane": args.control if world_size > 1 else None,
                 "rehearsal_same_device": bool(args.same_device),
             },
+            "parity_in_run": parity,
             "roofline": {
                 "bound": "hbm", "kernel": "k_xform_cull",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": pmc_traffic(stages, w.n, args.workload),
                 "bytes_per_entity": bpe, "avg_launch_ms": k1_ms, "launches_timed": int(len(k1)),
+                "end_of_tick_kernel": {
+                    "kernel": "k_compact_pairs (compaction + dirty clear + next frame's producer + pair search, one launch)" if not len(k2) else "k_pairs",
+                    "avg_launch_ms": eot_ms, "launches_timed": int(len(kp)), "algorithmic_bytes": eot_bytes,
+                    "achieved": eot_achieved, "frac": (eot_achieved / HBM_PEAK_GBS) if eot_achieved else None,
+                    "traffic": pmc_traffic(stages, w.n, args.workload, "k_compact_pairs"),
+                    "timing": "hipEventRecord pair around the launch on the context's stream (includes ~2 us of dispatch gap)",
+                },
                 "other_kernels_ms": {"k_compact": float(np.mean(k2)) if len(k2) else None,
-                                     "frame producer": float(np.mean(kn)) if len(kn) else "fused into the end-of-tick kernel (SC_TICK_PRODUCE_NEXT)",
-                                     "k_compact_pairs (one launch, with the next frame's producer)" if not len(k2) else "k_pairs": float(np.mean(kp)) if len(kp) else None},
+                                     "frame producer": float(np.mean(kn)) if len(kn) else "fused into the end-of-tick kernel (SC_TICK_PRODUCE_NEXT)"},
             },
         }
         if world_size == 1:
@@ -334,11 +431,15 @@ def main():
                 out["config"]["readback_ms_visible_list_and_matrices"] = (time.perf_counter() - t0) * 1e3
             del mats
         if world_size == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w)
-            one = cpu_baseline(w, ticks=5, warm=1, workers=0)
+            if leg is None:
+                leg = OracleLeg(w)
+            out["cpu_baseline"] = leg.baseline()
+            one = leg.baseline(ticks=5, warm=1, workers=0)
             out["cpu_baseline"]["single_thread_value"] = one["value"]
             out["cpu_baseline"]["single_thread_sample"] = one["sample"]
         print(json.dumps(out))
+    if leg is not None:
+        leg.close()
     t.close()
     if world_size > 1:
         dist.destroy_process_group()

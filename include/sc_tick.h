@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SC_TICK_API_VERSION 2u
+#define SC_TICK_API_VERSION 3u
 #define SC_TICK_MAX_ENTITIES ((1u << 24) - 1u)   /* Entity::INDEX_BITS = 24 (sc_ecs.h:18-20); index 0xFFFFFF is the "no parent" value */
 #define SC_TICK_NO_PARENT (-1)
 
@@ -197,9 +197,33 @@ int scTickRunPairs(ScTickContext* ctx);
  * scTickRun (border buffers of tick parity t & 1: scTickBindBorderBuffersParity), then calls scTickRunPairs -- e.g. the pairs
  * stream is torch's current stream, where its RCCL operations go, and the tick runs on the context's own stream.
  * Read the results of tick t (pairs, ray hits, counts) after its scTickRunPairs and before the next scTickRun, as always.
- * Not combinable with graph replay. */
+ * Not combinable with graph replay.  Switching the pairs stream on or off synchronises and clears the per-parity broadphase
+ * state (the two flows clear it differently): the previous tick's pairs / counts are no longer readable afterwards. */
 int scTickSetPairsStream(ScTickContext* ctx, void* hip_stream);
 int scTickBindBorderBuffersParity(ScTickContext* ctx, uint32_t parity, uint32_t direction, void* send_device_ptr, void* recv_device_ptr);
+/* ---- the exchange itself, owned by the library (north_star: "Host code stays C++ ... RCCL over xGMI exchanging only
+ * tile-border AABBs").  The reference has no counterpart: it is a single process ("Distributed
+ * communication backend: none"); the tile sharding is this build's, its unit is the sector grid of
+ * src/engine/world/sc_world_partition.cpp:268-287.
+ * One RCCL communicator per context = per GPU = per process.  Rank 0 asks for a unique id, the host hands its 128 bytes
+ * to every rank over whatever channel it has (a file, a socket, MPI, torch.distributed: bench.py), and every rank calls
+ * scTickCommInit after scTickSetTileGrid.  The neighbour in direction d is the rank of tile (tile_x+dx, tile_z+dz) in
+ * row-major tile order unless scTickCommSetPeers says otherwise (-1 = none).  The library then owns the border message
+ * buffers of both tick parities (RCCL is opened with dlopen on first use; a single-GPU host never needs it).
+ * scTickTileStep(flags) is one whole step of a tile in one call: scTickRun(flags | SC_TICK_SPLIT_PAIRS), the exchange as
+ * ONE group of ncclSend / ncclRecv on the stream the pair half runs on (the pairs stream when pipelined), scTickRunPairs.
+ * Nothing in it waits on the host.  A tile without neighbours (1x1 grid) runs scTickRun(flags).  A tile WITH neighbours
+ * and no communicator fails: the exchange is never skipped silently.
+ * scTickSetPipelined(1) = scTickSetPairsStream with a second stream of the library's own. */
+#define SC_TICK_COMM_ID_BYTES 128
+int scTickCommGetUniqueId(uint8_t id[SC_TICK_COMM_ID_BYTES]);
+int scTickCommInit(ScTickContext* ctx, const uint8_t id[SC_TICK_COMM_ID_BYTES], uint32_t world_size, uint32_t rank);
+int scTickCommSetPeers(ScTickContext* ctx, const int32_t peer_rank[8]);
+int scTickCommDestroy(ScTickContext* ctx);
+int scTickSetPipelined(ScTickContext* ctx, int enable);
+int scTickTileStep(ScTickContext* ctx, uint32_t flags);
+/* the middle third of scTickTileStep on its own, for hosts that interleave other work: after scTickRun(... | SC_TICK_SPLIT_PAIRS) */
+int scTickExchangeBorders(ScTickContext* ctx);
 /* external != 0: run all device work of this context on the caller's stream `hip_stream` (hipStream_t;
  * NULL is the legacy default stream), e.g. the stream its RCCL calls are ordered on.
  * external == 0: return to the context's own stream. */

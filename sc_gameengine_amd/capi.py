@@ -14,6 +14,7 @@ XFORM, CULL, BROADPHASE, CULLED_LIST, DRAWS, DENSE_AABBS, SPLIT_PAIRS, SORT_DRAW
 FULL = XFORM | CULL | BROADPHASE
 K_XFORM_CULL, K_COMPACT, K_PAIRS, K_NUDGE, K_COUNT = 0, 1, 2, 3, 4
 NO_PARENT = -1
+COMM_ID_BYTES = 128
 HAVE_PAIR_SEARCH = True       # flipped when the broadphase pair kernels are in the library
 
 F32P = C.POINTER(C.c_float)
@@ -88,6 +89,13 @@ SYMBOLS = {
     "scTickSetPairsStream": (C.c_int, [_CTX, C.c_void_p]),
     "scTickBindBorderBuffersParity": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "scTickSetStream": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
+    "scTickCommGetUniqueId": (C.c_int, [U8P]),
+    "scTickCommInit": (C.c_int, [_CTX, U8P, C.c_uint32, C.c_uint32]),
+    "scTickCommSetPeers": (C.c_int, [_CTX, I32P]),
+    "scTickCommDestroy": (C.c_int, [_CTX]),
+    "scTickSetPipelined": (C.c_int, [_CTX, C.c_int]),
+    "scTickTileStep": (C.c_int, [_CTX, C.c_uint32]),
+    "scTickExchangeBorders": (C.c_int, [_CTX]),
     "scTickUploadMovers": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P, F32P, F32P, F32P]),
     "scTickAdvanceMovers": (C.c_int, [_CTX, C.c_float]),
     "scTickReadMoverVelocities": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
@@ -153,3 +161,11 @@ def load():
         fn.argtypes = args
     _LIB = lib
     return lib
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 calls this; the host hands the bytes to every rank)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    if not load().scTickCommGetUniqueId(buf):
+        raise ScTickError("scTickCommGetUniqueId failed: " + (load().scTickGetLastError(None) or b"").decode())
+    return bytes(buf)

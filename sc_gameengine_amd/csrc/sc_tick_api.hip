@@ -5,6 +5,7 @@
 // as the reference (sc_world_partition.cpp:1071-1103, sc_math.cpp:102-107).
 #include "../../include/sc_tick.h"
 #include "sc_tick_internal.h"
+#include "sc_tick_rccl.h"
 
 #include <algorithm>
 #include <cmath>
@@ -100,6 +101,14 @@ struct ScTickContext
                   float4* spill = nullptr; uint32_t* spillSector = nullptr; uint32_t* borderSend[8] = {}; uint32_t* borderRecv[8] = {}; } alt;
   hipEvent_t packed[2] = { nullptr, nullptr }, pairsDone[2] = { nullptr, nullptr };
   bool pairsInFlight[2] = { false, false };
+  // library-owned exchange (scTickCommInit): one RCCL communicator per context, the border messages of both tick
+  // parities in buffers of the library's own, the neighbour in direction d at rank peer[d]
+  ncclComm_t comm = nullptr;
+  uint32_t commSize = 0, commRank = 0;
+  int32_t peer[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };
+  bool peersSet = false;
+  uint32_t* ownBorder[2][8][2] = {};   // [parity][direction][send, recv]
+  hipStream_t ownPairsStream = nullptr;
 };
 
 namespace {
@@ -564,7 +573,10 @@ void scTickDestroyContext(ScTickContext* c)
   for (auto& v : c->times) for (auto& p : v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : c->eventPool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (int k = 0; k < 2; ++k) { if (c->packed[k]) hipEventDestroy(c->packed[k]); if (c->pairsDone[k]) hipEventDestroy(c->pairsDone[k]); }
+  if (c->pairsStream) hipStreamSynchronize(c->pairsStream);
+  if (c->comm) { std::string why; if (const RcclApi* r = rccl(&why)) r->CommDestroy(c->comm); c->comm = nullptr; }
   for (void* p : c->allocs) hipFree(p);
+  if (c->ownPairsStream) hipStreamDestroy(c->ownPairsStream);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1014,12 +1026,15 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   if (!c) return 0;
   if (!bind(c)) return 0;
   if (!flushLinks(c)) return 0;
-  if (c->n == 0) {                    // nothing to launch: the per-tick counts read as zero
+  if ((flags & SC_TICK_BROADPHASE) && c->desc.tile_sectors_x == 0) return fail(c, "broadphase requested but the context has no tile rectangle");
+  // An empty context without a broadphase has nothing to launch: the per-tick counts read as zero.  With the broadphase
+  // the stages still run (every kernel copes with n == 0): an emptied tile of a multi-GPU world must rewrite its border
+  // messages (header-only) and take part in the exchange, the merge and the pair search of the boxes its neighbours send.
+  if (c->n == 0 && !(flags & SC_TICK_BROADPHASE)) {
     c->lastFlags = flags;
     HIP_OK(c, hipMemsetAsync(c->d.counters, 0, 8 * sizeof(uint32_t), c->stream));
     return 1;
   }
-  if ((flags & SC_TICK_BROADPHASE) && c->desc.tile_sectors_x == 0) return fail(c, "broadphase requested but the context has no tile rectangle");
   if (flags & SC_TICK_PRODUCE_NEXT) {
     if (!(flags & SC_TICK_XFORM)) return fail(c, "SC_TICK_PRODUCE_NEXT needs SC_TICK_XFORM (the producer rides on the end-of-tick kernel)");
     if (!c->producerKind) return fail(c, "SC_TICK_PRODUCE_NEXT needs scTickSetFrameProducer first");
@@ -1141,7 +1156,30 @@ int scTickSetPairsStream(ScTickContext* c, void* stream)
   if (!bind(c)) return 0;
   if (!sync(c)) return 0;
   if (c->pairsPending) return fail(c, "scTickRunPairs is pending");
-  if (!stream) { c->pairsStream = nullptr; return 1; }
+  // The two flows clear the per-parity broadphase state differently (in order: a pair kernel clears the OTHER parity for the
+  // next tick; pipelined: a small kernel behind the pair kernel clears its OWN parity), so a switch in either direction
+  // would leave one parity's counters, shard counters and big-box bits holding the last tick's values.  Everything is idle
+  // here (synchronised above): start both parities from a clean slate.
+  auto resetBroadphaseState = [&]() -> bool {
+    if (!c->sectors) return true;
+    const size_t N = c->cap;
+    hipError_t e = hipMemsetAsync(c->d.counters + kCtrPar, 0, 24u * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d.pairShardCount, 0, 3u * kPairShards * kShardStride * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d.bigBits[0], 0, N / 32 * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d.bigBits[1], 0, N / 32 * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d.binCount, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d.binLayers, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess && c->alt.binCount) e = hipMemsetAsync(c->alt.binCount, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess && c->alt.binLayers) e = hipMemsetAsync(c->alt.binLayers, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
+    if (e != hipSuccess) return fail(c, "hipMemsetAsync (broadphase state)", e);
+    c->parity = 0; c->lastParity = 0; c->prevBroadphaseN = 0;
+    return sync(c);
+  };
+  if (!stream) {
+    if (c->pairsStream && !resetBroadphaseState()) return 0;
+    c->pairsStream = nullptr; c->pairsInFlight[0] = c->pairsInFlight[1] = false; c->topoEpoch++;
+    return 1;
+  }
   if (!c->sectors) return fail(c, "the context has no broadphase");
   if (!c->alt.bins) {
     const size_t N = c->cap;
@@ -1153,6 +1191,7 @@ int scTickSetPairsStream(ScTickContext* c, void* stream)
       HIP_OK(c, hipEventCreateWithFlags(&c->pairsDone[k], hipEventDisableTiming | hipEventReleaseToDevice));
     }
   }
+  if (!c->pairsStream && !resetBroadphaseState()) return 0;
   c->pairsStream = static_cast<hipStream_t>(stream);
   c->pairsInFlight[0] = c->pairsInFlight[1] = false;
   c->topoEpoch++;
@@ -1524,5 +1563,148 @@ int scTickSetGraphMode(ScTickContext* c, int enable)
 }
 
 void* scTickGetStream(ScTickContext* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---- the border exchange, owned by the library -------------------------------------------------------------------
+static const RcclApi* needRccl(ScTickContext* c)
+{
+  std::string why;
+  const RcclApi* r = rccl(&why);
+  if (!r) { if (c) fail(c, why.c_str()); else gCreateError = why; }
+  return r;
+}
+
+static bool ncclOk(ScTickContext* c, const RcclApi* r, ncclResult_t res, const char* what)
+{
+  if (res == ncclSuccess) return true;
+  char buf[256];
+  std::snprintf(buf, sizeof buf, "%s: %s", what, r->GetErrorString(res));
+  if (c) fail(c, buf); else gCreateError = buf;
+  return false;
+}
+
+int scTickCommGetUniqueId(uint8_t id[SC_TICK_COMM_ID_BYTES])
+{
+  if (!id) return 0;
+  const RcclApi* r = needRccl(nullptr);
+  if (!r) return 0;
+  static_assert(sizeof(ncclUniqueId) == SC_TICK_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  ncclUniqueId u;
+  if (!ncclOk(nullptr, r, r->GetUniqueId(&u), "ncclGetUniqueId")) return 0;
+  std::memcpy(id, &u, sizeof u);
+  return 1;
+}
+
+int scTickCommDestroy(ScTickContext* c)
+{
+  if (!c) return 0;
+  if (!c->comm) return 1;
+  if (!bind(c)) return 0;
+  sync(c);
+  const RcclApi* r = needRccl(c);
+  if (r) r->CommDestroy(c->comm);
+  c->comm = nullptr; c->commSize = 0; c->commRank = 0;
+  return 1;
+}
+
+int scTickCommSetPeers(ScTickContext* c, const int32_t peerRank[8])
+{
+  if (!c || !peerRank) return c ? fail(c, "null argument") : 0;
+  for (int d = 0; d < 8; ++d) c->peer[d] = peerRank[d];
+  c->peersSet = true;
+  return 1;
+}
+
+int scTickCommInit(ScTickContext* c, const uint8_t id[SC_TICK_COMM_ID_BYTES], uint32_t worldSize, uint32_t rank)
+{
+  if (!c || !id) return c ? fail(c, "null argument") : 0;
+  if (!worldSize || rank >= worldSize) return fail(c, "need rank < world_size");
+  if (!c->sectors) return fail(c, "the context has no broadphase: nothing to exchange");
+  if (!c->tilesX) return fail(c, "scTickSetTileGrid first (the neighbours' ranks follow from the tile's place in the grid)");
+  if (c->pairsPending) return fail(c, "scTickRunPairs is pending");
+  if (!bind(c) || !sync(c)) return 0;
+  const RcclApi* r = needRccl(c);
+  if (!r) return 0;
+  if (c->comm && !scTickCommDestroy(c)) return 0;
+  if (!c->peersSet) {
+    // tiles in row-major rank order, as the entities are created tile-major
+    if ((uint64_t)c->tilesX * c->tilesZ != worldSize) return fail(c, "world_size differs from the tile grid (use scTickCommSetPeers for another rank layout)");
+    for (uint32_t d = 0; d < 8; ++d) {
+      int dx, dz; borderDir(d, dx, dz);
+      c->peer[d] = ((c->neighbourMask >> d) & 1u) ? (int32_t)(((int)c->tileZ + dz) * (int)c->tilesX + (int)c->tileX + dx) : -1;
+    }
+  }
+  for (uint32_t d = 0; d < 8; ++d)
+    if (((c->neighbourMask >> d) & 1u) && (c->peer[d] < 0 || (uint32_t)c->peer[d] >= worldSize)) return fail(c, "a neighbour's rank lies outside the communicator");
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  if (!ncclOk(c, r, r->CommInitRank(&c->comm, (int)worldSize, u, (int)rank), "ncclCommInitRank")) { c->comm = nullptr; return 0; }
+  c->commSize = worldSize; c->commRank = rank;
+  // the messages of both tick parities live in buffers of the library's own (a caller that runs its own transport binds
+  // its buffers with scTickBindBorderBuffers instead and never comes here)
+  for (uint32_t q = 0; q < 2; ++q)
+    for (uint32_t d = 0; d < 8; ++d) {
+      if (!((c->neighbourMask >> d) & 1u)) continue;
+      const size_t words = borderWords(d, c->desc.tile_sectors_x, c->desc.tile_sectors_z);
+      for (int k = 0; k < 2; ++k) if (!c->ownBorder[q][d][k] && !dalloc(c, c->ownBorder[q][d][k], words)) return 0;
+      if (q == 0) { c->d.borderSend[d] = c->ownBorder[0][d][0]; c->d.borderRecv[d] = c->ownBorder[0][d][1]; }
+      else { c->alt.borderSend[d] = c->ownBorder[1][d][0]; c->alt.borderRecv[d] = c->ownBorder[1][d][1]; }
+    }
+  return sync(c) ? 1 : 0;
+}
+
+int scTickSetPipelined(ScTickContext* c, int enable)
+{
+  if (!c) return 0;
+  if (!bind(c)) return 0;
+  if (!enable) return scTickSetPairsStream(c, nullptr);
+  if (!c->ownPairsStream) HIP_OK(c, hipStreamCreateWithFlags(&c->ownPairsStream, hipStreamNonBlocking));
+  return scTickSetPairsStream(c, c->ownPairsStream);
+}
+
+// send[d] of this tile -> recv[7-d] of the neighbour in direction d, every existing neighbour, one RCCL group on `s`.
+// A pair of ranks normally shares one edge or corner, i.e. one message each way; should a rank layout put several
+// neighbours on one rank (scTickCommSetPeers: a periodic world, the loop-back test), point-to-point operations between
+// two ranks match in posting order: sends go out by ascending direction, so the receives are posted by DESCENDING
+// direction -- what a peer sent as its direction d arrives here as direction 7-d.
+static int exchangeBorders(ScTickContext* c, uint32_t parity, hipStream_t s)
+{
+  const RcclApi* r = needRccl(c);
+  if (!r) return 0;
+  const DeviceState ds = stateFor(c, parity);
+  if (!ncclOk(c, r, r->GroupStart(), "ncclGroupStart")) return 0;
+  ncclResult_t res = ncclSuccess;
+  for (int d = 0; d < 8 && res == ncclSuccess; ++d) {
+    if (!((c->neighbourMask >> d) & 1u)) continue;
+    if (!ds.borderSend[d] || !ds.borderRecv[d]) { r->GroupEnd(); return fail(c, "border buffers are not bound"); }
+    res = r->Send(ds.borderSend[d], (size_t)borderWords((uint32_t)d, c->desc.tile_sectors_x, c->desc.tile_sectors_z), ncclUint32, c->peer[d], c->comm, s);
+  }
+  for (int d = 7; d >= 0 && res == ncclSuccess; --d) {
+    if (!((c->neighbourMask >> d) & 1u)) continue;
+    res = r->Recv(ds.borderRecv[d], (size_t)borderWords((uint32_t)d, c->desc.tile_sectors_x, c->desc.tile_sectors_z), ncclUint32, c->peer[d], c->comm, s);
+  }
+  const ncclResult_t end = r->GroupEnd();
+  if (!ncclOk(c, r, res, "ncclSend/ncclRecv")) return 0;
+  return ncclOk(c, r, end, "ncclGroupEnd") ? 1 : 0;
+}
+
+int scTickExchangeBorders(ScTickContext* c)
+{
+  if (!c) return 0;
+  if (!bind(c)) return 0;
+  if (!c->pairsPending) return fail(c, "scTickExchangeBorders without a preceding scTickRun(... | SC_TICK_BROADPHASE | SC_TICK_SPLIT_PAIRS)");
+  if (!c->neighbourMask) return 1;
+  if (!c->comm) return fail(c, "no communicator: scTickCommInit first");
+  return exchangeBorders(c, c->pendingParams.parity, c->pairsStream ? c->pairsStream : c->stream);
+}
+
+int scTickTileStep(ScTickContext* c, uint32_t flags)
+{
+  if (!c) return 0;
+  if (!(flags & SC_TICK_BROADPHASE) || !c->neighbourMask) return scTickRun(c, flags & ~(uint32_t)SC_TICK_SPLIT_PAIRS);   // nothing to exchange
+  if (!c->comm) return fail(c, "no communicator: scTickCommInit first (a tile with neighbours cannot skip the exchange)");
+  if (!scTickRun(c, flags | SC_TICK_SPLIT_PAIRS)) return 0;
+  if (!exchangeBorders(c, c->pendingParams.parity, c->pairsStream ? c->pairsStream : c->stream)) return 0;
+  return scTickRunPairs(c);
+}
 
 } // extern "C"

@@ -308,6 +308,31 @@ class WorldTick:
     def run_pairs(self):
         self._ok(self.lib.scTickRunPairs(self.ctx), "scTickRunPairs")
 
+    # ---- library-owned exchange (RCCL communicator inside libsc_tick.so) ----
+    def comm_init(self, unique_id, world_size, rank, peers=None):
+        """unique_id: 128 bytes from capi.comm_unique_id() of rank 0, handed to every rank by the host's own channel.
+        peers (optional): rank of the neighbour in each of the 8 directions, -1 = none (default: row-major tile order)."""
+        if peers is not None:
+            pr = np.ascontiguousarray(peers, np.int32)
+            assert len(pr) == 8
+            self._ok(self.lib.scTickCommSetPeers(self.ctx, pr.ctypes.data_as(capi.I32P)), "scTickCommSetPeers")
+        uid = np.frombuffer(bytes(unique_id), np.uint8).copy()
+        assert len(uid) == capi.COMM_ID_BYTES
+        self._ok(self.lib.scTickCommInit(self.ctx, uid.ctypes.data_as(capi.U8P), int(world_size), int(rank)), "scTickCommInit")
+
+    def comm_destroy(self):
+        self._ok(self.lib.scTickCommDestroy(self.ctx), "scTickCommDestroy")
+
+    def set_pipelined(self, on):
+        self._ok(self.lib.scTickSetPipelined(self.ctx, 1 if on else 0), "scTickSetPipelined")
+
+    def tile_step(self, flags):
+        """One whole step of a tile: tick + pack, RCCL exchange, merge + pair search -- one call, nothing waits on the host."""
+        self._ok(self.lib.scTickTileStep(self.ctx, flags), "scTickTileStep")
+
+    def exchange_borders(self):
+        self._ok(self.lib.scTickExchangeBorders(self.ctx), "scTickExchangeBorders")
+
     def set_stream(self, hip_stream, external=True):
         """external=True: run on the caller's hipStream_t (0 = the legacy default stream); False: own stream"""
         self._ok(self.lib.scTickSetStream(self.ctx, hip_stream, 1 if external else 0), "scTickSetStream")

@@ -123,3 +123,29 @@ def global_pair_ids(pairs, entities_per_rank):
     """rank << 24 | dense index  ->  global dense index (tile-major creation order)."""
     p = np.asarray(pairs, np.uint64)
     return ((p >> np.uint64(24)) & np.uint64(0x7F)) * np.uint64(entities_per_rank) + (p & np.uint64(0xFFFFFF))
+
+
+def rendezvous_unique_id(rank, make_id, group=None):
+    """The one thing the host's own channel has to carry: rank 0's 128-byte communicator id, to every rank.
+    Here the channel is torch.distributed (any backend: the payload is a CPU object broadcast); `make_id` is called on
+    rank 0 only (capi.comm_unique_id).  Every rank returns the same bytes."""
+    import torch.distributed as dist
+    box = [make_id() if rank == 0 else None]
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    uid = bytes(box[0])
+    if len(uid) != 128:
+        raise ValueError(f"communicator id must be 128 bytes, got {len(uid)}")
+    return uid
+
+
+def setup_tile(tick, rank, grid, unique_id=None, pipelined=True):
+    """Place a context in the tile grid and, when it has neighbours, give it its communicator (library-owned exchange)."""
+    tick.set_tile(rank, neighbour_mask(rank, grid))
+    tx, tz = tile_of(rank, grid)
+    tick.set_tile_grid(tx, tz, grid[0], grid[1])
+    if grid[0] * grid[1] > 1:
+        if unique_id is None:
+            raise ValueError("a tile with neighbours needs the communicator id")
+        tick.comm_init(unique_id, grid[0] * grid[1], rank)
+        tick.set_pipelined(pipelined)

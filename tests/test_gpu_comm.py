@@ -1,0 +1,112 @@
+"""The library-owned exchange (scTickCommInit / scTickTileStep) on ONE GPU: a one-rank RCCL communicator whose eight
+neighbours are all the rank itself.  What a tile sends in direction d comes back as what it receives from direction 7-d,
+through real ncclSend / ncclRecv groups on the streams the tick uses.  A twin context does the same loop-back with device
+copies; both must report the same pairs, tick after tick, in the in-order and in the pipelined flow -- so the transport
+(buffers, group, posting order, stream order against the kernels around it) is what is being compared."""
+import numpy as np
+import pytest
+
+from sc_gameengine_amd import capi, synth_world as sw, tiles
+from sc_gameengine_amd.tick import WorldTick, camera_view_proj
+
+pytestmark = pytest.mark.gpu
+
+GRID, RANK = (3, 3), 4                 # the centre tile of a 3x3 world: neighbours in all eight directions
+
+
+def centre_tile_world(S=8, seed=9):
+    w = sw.generate(S, S, 15, origin=(S, S))
+    rng = np.random.default_rng(seed)
+    dyn = rng.random(w.n) < 0.4
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    roots = np.flatnonzero((w.parent < 0) & (np.arange(w.n) % 16 != 0))
+    # boxes straddling all four edges of the tile, so every one of the eight messages carries records
+    lo, hi = 64.0 * S, 128.0 * S
+    for axis, k in ((0, 0), (0, 1), (2, 2), (2, 3)):
+        sel = rng.choice(roots, len(roots) // 12, replace=False)
+        w.pos[sel, axis] = ((lo if k % 2 == 0 else hi) + rng.uniform(-1.0, 1.0, len(sel))).astype(np.float32)
+    big = rng.choice(roots, 6, replace=False)
+    w.bmin[big] *= 120.0; w.bmax[big] *= 120.0          # big boxes travel in the messages' big section
+    w.group[big], w.mask[big] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    return w
+
+
+def keys(t):
+    p, total = t.pairs()
+    assert total == len(p)
+    return np.sort(p[:, 0].astype(np.uint64) << np.uint64(32) | p[:, 1].astype(np.uint64))
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_rccl_loopback_equals_device_copy_loopback(pipelined):
+    import torch
+    w = centre_tile_world()
+    vp = camera_view_proj(w.camera)
+    flags = capi.FULL | capi.PRODUCE_NEXT
+
+    # A: the library's own exchange
+    a = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 17)
+    a.set_view_proj(vp)
+    a.set_tile(RANK, 0xFF); a.set_tile_grid(1, 1, 3, 3)
+    a.comm_init(capi.comm_unique_id(), 1, 0, peers=[0] * 8)
+    a.set_pipelined(pipelined)
+    # B: the twin, messages moved by device copies
+    b = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 17)
+    b.set_view_proj(vp)
+    s2 = torch.cuda.Stream()
+    if pipelined:
+        b.set_pairs_stream(s2.cuda_stream)
+    bufs = tiles.BorderBuffers(b, RANK, GRID, "cuda", pipelined=pipelined)
+    for t in (a, b):
+        t.set_frame_producer(1, 0.6)
+        t.nudge_roots_x(0.6)
+
+    seen = 0
+    for step in range(6):
+        a.tile_step(flags)
+        b.run(flags | capi.SPLIT_PAIRS)
+        q = (step & 1) if pipelined else 0
+        send, recv = bufs.sets[q][2], bufs.sets[q][3]
+        if pipelined:
+            with torch.cuda.stream(s2):                     # ordered behind the pack by the library's event
+                for d in range(8):
+                    recv[7 - d].copy_(send[d], non_blocking=True)
+        else:
+            b.sync()
+            for d in range(8):
+                recv[7 - d].copy_(send[d])
+            torch.cuda.synchronize()
+        b.run_pairs()
+        if step >= 3:                                       # reading results joins the streams: do it on the later steps only
+            ka, kb = keys(a), keys(b)
+            assert np.array_equal(ka, kb), f"step {step}: {len(ka)} vs {len(kb)} pairs"
+            assert np.array_equal(a.visible(), b.visible())
+            ca, cb = a.counts(), b.counts()
+            assert (ca.big_boxes, ca.border_lost, ca.bin_overflow) == (cb.big_boxes, cb.border_lost, cb.bin_overflow)
+            assert ca.big_boxes >= 6 and len(ka) > 100
+            seen += 1
+    assert seen == 3
+    a.close(); b.close()
+
+
+def test_tile_with_neighbours_and_no_communicator_fails_loudly():
+    w = sw.generate(4, 4, 15)
+    t = WorldTick.from_world(w, broadphase=True)
+    t.set_tile(0, 0); t.set_tile_grid(0, 0, 2, 1)
+    with pytest.raises(capi.ScTickError, match="no communicator"):
+        t.tile_step(capi.FULL)
+    t.close()
+
+
+def test_single_tile_step_is_a_plain_tick(oracle):
+    from tests import worlds
+    w = sw.generate(8, 8, 15)
+    ow = worlds.oracle_world(oracle, w)
+    vp = camera_view_proj(w.camera)
+    t = WorldTick.from_world(w, broadphase=True)
+    t.set_view_proj(vp)
+    tiles.setup_tile(t, 0, (1, 1))
+    ow.transform_system(); ow.culling_system(view_proj=vp)
+    t.tile_step(capi.FULL)
+    assert np.array_equal(t.visible(), ow.visible())
+    t.close(); ow.close()

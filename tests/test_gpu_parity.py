@@ -244,10 +244,41 @@ def test_full_size_1m_properties():
     m1 = t.world_matrices()
     assert np.array_equal(m1[roots, 12], (w.pos[roots, 0] + np.float32(0.25)).astype(np.float32))
     assert np.allclose(m1[:, 12] - m0[:, 12], 0.25, atol=2e-3) and np.array_equal(m1[:, :12], m0[:, :12])
-    # checksum of the visible list is reproducible run to run
+    # a second run without changes reproduces the list (nothing was dirty: no matrix is rebuilt, every mask is re-derived)
+    v1 = t.visible()
     t.run(XC)
-    assert np.array_equal(t.visible(), t.visible())
+    assert np.array_equal(t.visible(), v1)
     t.close()
+
+
+def test_config3_full_size_full_tick_matches_oracle(oracle):
+    """BASELINE config 3 at FULL size (1 048 576 entities), SC_TICK_FULL, three nudged ticks: every world matrix, the
+    visible list and -- with one prop per sector made dynamic -- the pair set are compared with liboracle.so run on the
+    same world (pairs from the ORACLE's boxes, through its own grid search)."""
+    w = sw.config("config3")
+    dyn = (np.arange(w.n) % 16) == 4                              # one prop per sector is dynamic: the pair pass has work
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    ow = worlds.oracle_world(oracle, w)
+    t = WorldTick.from_world(w, broadphase=True)
+    vp = camera_view_proj(w.camera)
+    t.set_view_proj(vp)
+    for k in range(3):
+        if k:
+            ow.nudge_roots_x(0.01); t.nudge_roots_x(0.01)
+        ow.transform_system(); ow.culling_system(view_proj=vp)
+        t.run(capi.FULL)
+        assert np.array_equal(t.visible(), ow.visible()), f"tick {k}: visible list differs"
+        assert_mats_equal(t.world_matrices(), ow.world_matrices()[:w.n])
+        mn, mx = ow.world_aabbs()
+        want = oracle.broadphase_grid(mn[:w.n], mx[:w.n], w.group, w.mask, 64.0)
+        got, total = t.pairs()
+        key = np.sort(got[:, 0].astype(np.uint64) << np.uint64(32) | got[:, 1].astype(np.uint64))
+        wkey = want[:, 0].astype(np.uint64) << np.uint64(32) | want[:, 1].astype(np.uint64)
+        assert total == len(want) and np.array_equal(key, wkey), f"tick {k}: pair set differs ({total} vs {len(want)})"
+        assert len(want) > 1000
+    c = t.counts()
+    assert c.big_boxes == 0 and c.bin_overflow == 0 and 0 < c.visible < w.n
+    t.close(); ow.close()
 
 
 def test_maximum_size_16m_entities():

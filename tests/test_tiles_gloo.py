@@ -69,3 +69,51 @@ def test_border_exchange_over_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(r, "ok") for r in range(world)], results
+
+
+def _rendezvous_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def make_id():                                       # stands in for capi.comm_unique_id (needs a GPU): rank 0 only
+            calls.append(rank)
+            return bytes((7 * i + 3) % 256 for i in range(128))
+
+        uid = tiles.rendezvous_unique_id(rank, make_id)
+        assert uid == bytes((7 * i + 3) % 256 for i in range(128))
+        assert calls == ([0] if rank == 0 else [])
+        try:
+            tiles.rendezvous_unique_id(rank, lambda: b"short")
+            bad = False
+        except ValueError:
+            bad = True
+        assert bad                                           # a malformed id is refused on every rank
+        out.put((rank, "ok"))
+    except Exception as e:                                   # noqa: BLE001
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_communicator_id_rendezvous_over_gloo():
+    """bench.py's only N>1 host duty besides launching: rank 0's 128-byte RCCL id reaches every rank unchanged."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_rendezvous_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, "ok") for r in range(world)], results
+
+
+def test_rendezvous_without_a_process_group_is_local():
+    assert tiles.rendezvous_unique_id(0, lambda: bytes(128)) == bytes(128)
