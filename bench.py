@@ -413,7 +413,7 @@ def main():
                     "avg_launch_ms": eot_ms, "launches_timed": int(len(kp)), "algorithmic_bytes": eot_bytes,
                     "achieved": eot_achieved, "frac": (eot_achieved / HBM_PEAK_GBS) if eot_achieved else None,
                     "traffic": pmc_traffic(stages, w.n, args.workload, "k_compact_pairs"),
-                    "timing": "hipEventRecord pair around the launch on the context's stream (includes ~2 us of dispatch gap)",
+                    "timing": "begin / end timestamps of the dispatch itself (hipExtLaunchKernelGGL events), as for the fused kernel",
                 },
                 "other_kernels_ms": {"k_compact": float(np.mean(k2)) if len(k2) else None,
                                      "frame producer": float(np.mean(kn)) if len(kn) else "fused into the end-of-tick kernel (SC_TICK_PRODUCE_NEXT)"},

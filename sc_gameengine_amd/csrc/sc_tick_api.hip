@@ -396,6 +396,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   if (c->pairsStream && (flags & SC_TICK_BROADPHASE)) p.flags |= kFlagDeferredReset;
   if (flags & SC_TICK_PRODUCE_NEXT) { p.producerKind = c->producerKind; p.producerParam = c->producerParam; }
   p.bigCap = c->cap + 8u * kBorderBigCap;
+  p.pairRunLog2 = pairRunLog2(p.binSX * p.binSZ);
   p.tileX = c->tileX; p.tileZ = c->tileZ; p.tilesX = c->tilesX; p.tilesZ = c->tilesZ;
 }
 
@@ -440,9 +441,13 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
   const bool pairsNow = (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS);
   if (pairsNow && (flags & SC_TICK_RAYS)) launchRayQueries(ds, p, c->rays, c->stream);      // the bins are full, not yet consumed
   if (needCompact && pairsNow && !(c->variant & 8u)) {
-    // both depend only on the fused kernel: one launch, workgroups split by role (timed as K_PAIRS)
-    Scoped s(c, SC_TICK_K_PAIRS);
-    launchCompactPairs(ds, p, grid, c->stream);
+    // both depend only on the fused kernel: one launch, workgroups split by role (timed as K_PAIRS, by the dispatch's own
+    // begin / end timestamps like the fused kernel: no marker packets on the queue)
+    if (c->profiling && (c->tickIndex % c->profPeriod) == 0) {
+      const EventPair ev = takeEvents(c);
+      launchCompactPairs(ds, p, grid, c->stream, ev.a, ev.b);
+      c->times[SC_TICK_K_PAIRS].push_back(ev);
+    } else launchCompactPairs(ds, p, grid, c->stream);
   } else {
     const bool packToo = needCompact && (flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_SPLIT_PAIRS) && !(c->variant & 8u);
     if (packToo) {

@@ -128,6 +128,7 @@ struct TickParams {
   uint32_t producerKind; float producerParam;   // with SC_TICK_PRODUCE_NEXT: the frame producer fused into the end-of-tick kernel
   uint32_t bigCap;          // entries the big list can hold (capacity + room for the neighbours' boxes): every index into it is held below this
   uint32_t bigClearWords;   // words of the other parity's bigBits the previous broadphase tick may have set (its entity count / 32)
+  uint32_t pairRunLog2;     // pair role: a wave takes its sectors in runs of 2^pairRunLog2 consecutive ones (pairRunLog2())
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d
 __host__ __device__ inline void borderDir(uint32_t d, int& dx, int& dz) { const uint32_t k = d < 4 ? d : d + 1; dx = (int)(k % 3) - 1; dz = (int)(k / 3) - 1; }
@@ -175,7 +176,8 @@ void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, h
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s);
-void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s);
+uint32_t pairRunLog2(uint32_t sectors);
+void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s, hipEvent_t evA = nullptr, hipEvent_t evB = nullptr);
 void launchGatherPairs(const DeviceState& d, const TickParams& p, uint32_t parity, uint2* dst, uint32_t* total, hipStream_t s);
 void launchCompactPack(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s);

@@ -38,9 +38,21 @@ __device__ __forceinline__ float4 ldRow(const DeviceState& d, uint32_t row, uint
 {
   return *reinterpret_cast<const float4*>(d.rslab + (row * d.capBytes16 + i * 16u));
 }
+typedef float V4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void storeStream16(void* p, const float4& v)
+{
+  // written once per tick and not read again before the NEXT launch: a non-temporal store does not leave the line dirty in
+  // L2, which the following kernel boundary would otherwise have to write back before the end-of-tick kernel starts
+  V4f x = { v.x, v.y, v.z, v.w };
+  __builtin_nontemporal_store(x, reinterpret_cast<V4f*>(p));
+}
 __device__ __forceinline__ void stRow(const DeviceState& d, uint32_t row, uint32_t i, const float4& v)
 {
+#ifdef SC_NT_ROWS
+  storeStream16(d.rslab + (row * d.capBytes16 + i * 16u), v);
+#else
   *reinterpret_cast<float4*>(d.rslab + (row * d.capBytes16 + i * 16u)) = v;
+#endif
 }
 
 // local = T * (R * S) with R = (Rz * Ry) * Rx  (sc_math.cpp:100-142).
@@ -245,7 +257,11 @@ __device__ __forceinline__ void binInsertWave(const DeviceState& d, bool want, u
     const uint32_t slot = base + (lane - myHead);
     if (slot < kBinCap) {
       float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
+#ifdef SC_NT_BINS
+      storeStream16(r, rmin); storeStream16(r + 1, rmax);
+#else
       r[0] = rmin; r[1] = rmax;
+#endif
     } else binFull = true;
   }
 }
@@ -797,13 +813,19 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
 
   // a wave visits sectors waveGlobal, +totalWaves, ...; their counts are fetched 64 at a time (lane k
   // holds the k-th) and zeroed at once: this wave is the only consumer of those bins this tick
-  for (uint32_t chunk = waveGlobal; chunk < sectors; chunk += 64u * totalWaves) {
-    const uint32_t mySector = chunk + lane * totalWaves;
+  // 64 sectors per wave and round, as runs of R = 2^pairRunLog2 consecutive sectors (R = 16 on a large world): a wave's
+  // counter loads and stores touch 64/R segments instead of 64 separate cache lines.  The runs of one wave are totalWaves
+  // runs apart, so a dense district of the world is still spread over many waves; inside a run the lanes are rotated by the
+  // wave's index, so waves that start together do not all read bins at the same offset of a 2^k-byte stride.  The launcher
+  // sizes the grid so that every wave gets the same number of runs (within one): the slowest wave ends the kernel.
+  const uint32_t runLog = p.pairRunLog2, runLen = 1u << runLog, runsPerRound = 64u >> runLog;
+  for (uint32_t round = 0; ((round * runsPerRound) * totalWaves + waveGlobal) << runLog < sectors; ++round) {
+    const uint32_t mySector = (((round * runsPerRound + (lane >> runLog)) * totalWaves + waveGlobal) << runLog) + ((lane + waveGlobal) & (runLen - 1u));
     uint32_t myCount = 0;
     if (mySector < sectors) {
       myCount = d.binCount[mySector];
+      const uint32_t lay = d.binLayers[mySector];      // requested together with the count: one round trip, not two
       if (myCount) {
-        const uint32_t lay = d.binLayers[mySector];
         d.binCount[mySector] = 0u; d.binLayers[mySector] = 0u;
         // no record of this bin can pass the group/mask filter against another one: nothing to read
         if (nbig == 0u && ((lay & 0xFFFFu) & (lay >> 16)) == 0u) myCount = 0u;
@@ -817,21 +839,23 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     int it = __ffsll((long long)work) - 1;
     uint32_t n = __shfl(myCount, it, 64);
     float4 rmin = make_float4(0, 0, 0, 0), rmax = make_float4(0, 0, 0, 0);
+    uint32_t s = __shfl(mySector, it, 64);            // (cross-lane reads stay outside divergent code: every lane takes part)
     if (lane < n) {
-      const float4* r = d.bins + 2u * ((size_t)(chunk + (uint32_t)it * totalWaves) * kBinCap + lane);
+      const float4* r = d.bins + 2u * ((size_t)s * kBinCap + lane);
       rmin = r[0]; rmax = r[1];
     }
     unsigned long long rest = work & ~(1ull << it);
     while (it >= 0) {
-      const uint32_t s = chunk + (uint32_t)it * totalWaves;
       const int itNext = rest ? __ffsll((long long)rest) - 1 : -1;
       uint32_t nNext = 0;
       float4 nmin = make_float4(0, 0, 0, 0), nmax = make_float4(0, 0, 0, 0);
+      uint32_t sNext = 0;
       if (itNext >= 0) {
         rest &= ~(1ull << itNext);
         nNext = __shfl(myCount, itNext, 64);
+        sNext = __shfl(mySector, itNext, 64);
         if (lane < nNext) {
-          const float4* r = d.bins + 2u * ((size_t)(chunk + (uint32_t)itNext * totalWaves) * kBinCap + lane);
+          const float4* r = d.bins + 2u * ((size_t)sNext * kBinCap + lane);
           nmin = r[0]; nmax = r[1];
         }
       }
@@ -978,7 +1002,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
         }
       }
       __builtin_amdgcn_wave_barrier();
-      it = itNext; n = nNext; rmin = nmin; rmax = nmax;
+      it = itNext; n = nNext; s = sNext; rmin = nmin; rmax = nmax;
     }
   }
 
@@ -1458,24 +1482,37 @@ void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hip
   const uint32_t g = compactGroup(p, grid, false);
   hipLaunchKernelGGL(k_compact, dim3((grid + g - 1) / g), dim3(kTile), 0, s, d, p, g);
 }
+// Pair-role geometry: runs of R consecutive sectors (R = 16 when that still leaves ~4096 waves, smaller on smaller worlds),
+// and as many waves as give every wave the same number of runs: with W waves for U runs a wave takes ceil or floor of U / W
+// runs, and a grid just short of U (say 4096 waves for 4161 runs) would leave a few waves with twice the work of the rest --
+// measured on config 5: 80 us instead of 60 for the end-of-tick kernel.  SC_TICK_VARIANT bits 8+: workgroup cap (tuning).
+uint32_t pairRunLog2(uint32_t sectors)
+{
+  uint32_t lg = 4;
+  while (lg > 0 && (sectors >> lg) < 4096u) --lg;
+  return lg;
+}
+static uint32_t pairGridFor(const TickParams& p)
+{
+  const uint32_t sectors = p.binSX * p.binSZ;
+  const uint32_t runs = (sectors + (1u << p.pairRunLog2) - 1u) >> p.pairRunLog2;
+  const uint32_t capWaves = ((p.variant >> 8) ? (p.variant >> 8) : 2048u) * (kTile / 64u);
+  const uint32_t rounds = (runs + capWaves - 1u) / capWaves;
+  const uint32_t waves = (runs + rounds - 1u) / rounds;
+  return std::max(1u, (waves + kTile / 64u - 1u) / (kTile / 64u));
+}
 void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s)
 {
-  const uint32_t sectors = p.binSX * p.binSZ;
-  if (!sectors) return;
-  uint32_t grid = (sectors + 3u) / 4u;
-  const uint32_t cap = (p.variant >> 8) ? (p.variant >> 8) : 1024u;     // SC_TICK_VARIANT bits 8+: pair-kernel grid cap (tuning)
-  if (grid > cap) grid = cap;
-  hipLaunchKernelGGL(k_pairs, dim3(grid), dim3(kTile), 0, s, d, p);
+  if (!(p.binSX * p.binSZ)) return;
+  hipLaunchKernelGGL(k_pairs, dim3(pairGridFor(p)), dim3(kTile), 0, s, d, p);
 }
-void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s)
+void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s, hipEvent_t evA, hipEvent_t evB)
 {
-  const uint32_t sectors = p.binSX * p.binSZ;
-  uint32_t pairGrid = (sectors + 3u) / 4u;
-  const uint32_t cap = (p.variant >> 8) ? (p.variant >> 8) : 1024u;
-  if (pairGrid > cap) pairGrid = cap;
+  const uint32_t pairGrid = pairGridFor(p);
   const uint32_t g = compactGroup(p, compactGrid, true);
   const uint32_t blocks = (compactGrid + g - 1) / g;
-  hipLaunchKernelGGL(k_compact_pairs, dim3(blocks + pairGrid), dim3(kTile), 0, s, d, p, blocks, g);
+  if (evA) hipExtLaunchKernelGGL(k_compact_pairs, dim3(blocks + pairGrid), dim3(kTile), 0, s, evA, evB, 0, d, p, blocks, g);
+  else hipLaunchKernelGGL(k_compact_pairs, dim3(blocks + pairGrid), dim3(kTile), 0, s, d, p, blocks, g);
 }
 void launchGatherPairs(const DeviceState& d, const TickParams& p, uint32_t parity, uint2* dst, uint32_t* total, hipStream_t s)
 {

@@ -1,50 +1,67 @@
 #!/usr/bin/env python3
-"""On-device effect of pipelining a tile's step (no network: the neighbours' messages stay empty): one 1M-entity tile set up
-as tile (0,0) of a 2x2 world, split flow, with and without a pairs stream.  An artificial delay kernel on the pairs stream
-stands in for the exchange latency."""
-import os, sys, time, json
-import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from sc_gameengine_amd import capi, synth_world as sw, tiles
-from sc_gameengine_amd.tick import WorldTick, camera_view_proj
+"""What ONE GPU can show of a tile's step at N > 1: a 1M-entity tile set up as the centre of a 3x3 world (eight neighbours),
+its exchange a real RCCL group issued by the library on a one-rank communicator whose peers are all the rank itself
+(loop-back: the messages come back as the opposite directions').  Reports, per flow (in order / pipelined):
+  us_per_step      wall time per step, device-bound
+  host_issue_us    host time to ISSUE one step (scTickTileStep: tick + pack, ncclSend/ncclRecv group, merge + pair search)
+and for comparison the old Python-driven step (scTickRun + torch all_to_all_single + scTickRunPairs) when --torch is given."""
+import argparse
+import json
+import os
+import sys
+import time
 
-w = sw.config("config3")
-out = {}
-only = sys.argv[1] if len(sys.argv) > 1 else None          # e.g. "40p": one case (for a kernel trace)
-for delay_us in (0, 40):
-    for pipelined in (False, True):
-        if only and only != f"{delay_us}{'p' if pipelined else 'i'}":
-            continue
-        t = WorldTick.from_world(w, broadphase=True)
-        t.set_view_proj(camera_view_proj(w.camera))
-        s2 = torch.cuda.Stream()
-        torch.cuda.set_stream(s2)                       # torch's current stream: where the exchange is issued
-        if pipelined:
-            t.set_pairs_stream(s2.cuda_stream)          # the tick itself stays on the context's own stream
-        else:
-            t.set_stream(s2.cuda_stream, external=True)
-        b = tiles.BorderBuffers(t, 0, (2, 2), "cuda", pipelined=pipelined)
-        t.set_frame_producer(1, 0.01); t.nudge_roots_x(0.01)
-        flags = capi.FULL | capi.SPLIT_PAIRS | capi.PRODUCE_NEXT
-        spin = torch.zeros(1, device="cuda")
-        def fake_exchange():
-            if delay_us:
-                torch.cuda._sleep(int(delay_us * 2100))          # ~cycles at 2.1 GHz
-        def step():
-            t.run(flags)
-            fake_exchange()
-            t.run_pairs()
-        for _ in range(30): step()
-        t.sync(); torch.cuda.synchronize()
-        n = 300 if not only else 20
-        t0 = time.perf_counter()
-        for _ in range(n): step()
-        issued = time.perf_counter() - t0
-        t.sync(); torch.cuda.synchronize()
-        key = f"delay{delay_us}us_{'pipelined' if pipelined else 'in_order'}"
-        out[key + "_us_per_step"] = round((time.perf_counter() - t0) / n * 1e6, 2)
-        out[key + "_host_issue_us"] = round(issued / n * 1e6, 2)
-        c = t.counts(); assert c.visible > 0
-        t.close()
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sc_gameengine_amd import capi, synth_world as sw, tiles          # noqa: E402
+from sc_gameengine_amd.tick import WorldTick, camera_view_proj         # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=400)
+ap.add_argument("--workload", default="config3")
+ap.add_argument("--graph", type=int, default=0)
+args = ap.parse_args()
+
+S = 256
+w = sw.generate(S, S, 15, origin=(S, S))
+if args.workload == "config3dyn":
+    dyn = (np.arange(w.n) % 16) == 4
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+out = {"world": f"{w.n} entities, centre tile of a 3x3 grid, loop-back RCCL (8 sends + 8 receives per step)"}
+flags = capi.FULL | capi.PRODUCE_NEXT
+for pipelined in (False, True):
+    t = WorldTick.from_world(w, broadphase=True)
+    t.set_view_proj(camera_view_proj(w.camera))
+    t.set_tile(4, 0xFF); t.set_tile_grid(1, 1, 3, 3)
+    t.comm_init(capi.comm_unique_id(), 1, 0, peers=[0] * 8)
+    t.set_pipelined(pipelined)
+    t.set_frame_producer(1, 0.01); t.nudge_roots_x(0.01)
+    if args.graph:
+        t.set_graph_mode(True)
+    for _ in range(30):
+        t.tile_step(flags)
+    t.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t.tile_step(flags)
+    issued = time.perf_counter() - t0
+    t.sync()
+    total = time.perf_counter() - t0
+    key = "pipelined" if pipelined else "in_order"
+    out[key + "_us_per_step"] = round(total / args.steps * 1e6, 2)
+    out[key + "_host_issue_us"] = round(issued / args.steps * 1e6, 2)
+    # host issue alone, with the device idle between steps (the queue never fills up: what the call itself costs)
+    lone = []
+    for _ in range(50):
+        t.sync()
+        t1 = time.perf_counter()
+        t.tile_step(flags)
+        lone.append(time.perf_counter() - t1)
+    t.sync()
+    out[key + "_host_issue_idle_queue_us"] = round(float(np.median(lone)) * 1e6, 2)
+    c = t.counts()
+    assert c.visible > 0 and c.border_lost == 0
+    out[key + "_visible"] = int(c.visible)
+    t.close()
 print(json.dumps(out))
