@@ -190,11 +190,13 @@ int scTickBindBorderBuffers(ScTickContext* ctx, uint32_t direction, void* send_d
 int scTickRunPairs(ScTickContext* ctx);
 /* Pipelined tiles.  With a pairs stream set (hipStream_t; NULL switches it off), scTickRunPairs queues the merge, the ray
  * queries and the pair search of tick t on THAT stream, and the next scTickRun may start its fused kernel while they run:
- * everything the two halves share -- bins, big list, spill list, border messages -- exists twice, selected by tick parity
- * (counters, big-box bits and the pair output already are).  The library orders the halves with events: scTickRun makes the
- * pairs stream wait for the pack of its tick, and tick t+2, which reuses tick t's bins and counters, first waits for the pair
- * half of tick t and clears them.  The caller issues the exchange of tick t on the pairs stream after
- * scTickRun (border buffers of tick parity t & 1: scTickBindBorderBuffersParity), then calls scTickRunPairs -- e.g. the pairs
+ * everything the two halves share -- bins, big list, spill list, border messages -- exists `depth` times (3 unless
+ * scTickSetPipelined chose otherwise, at most 4), selected by tick parity t mod depth (counters, big-box bits and the pair
+ * output already are).  The library orders the halves with events: scTickRun makes the pairs stream wait for the pack of its
+ * tick, and tick t+depth, which reuses tick t's bins and counters, first waits for the pair half of tick t.  With depth 3 the
+ * pair half (exchange latency included) may take up to two ticks before it holds anything up.  The caller issues the exchange
+ * of tick t on the pairs stream after scTickRun (border buffers of parity t mod depth, counted from the moment the pairs stream
+ * was set: scTickBindBorderBuffersParity), then calls scTickRunPairs -- e.g. the pairs
  * stream is torch's current stream, where its RCCL operations go, and the tick runs on the context's own stream.
  * Read the results of tick t (pairs, ray hits, counts) after its scTickRunPairs and before the next scTickRun, as always.
  * Not combinable with graph replay.  Switching the pairs stream on or off synchronises and clears the per-parity broadphase
@@ -214,7 +216,8 @@ int scTickBindBorderBuffersParity(ScTickContext* ctx, uint32_t parity, uint32_t 
  * ONE group of ncclSend / ncclRecv on the stream the pair half runs on (the pairs stream when pipelined), scTickRunPairs.
  * Nothing in it waits on the host.  A tile without neighbours (1x1 grid) runs scTickRun(flags).  A tile WITH neighbours
  * and no communicator fails: the exchange is never skipped silently.
- * scTickSetPipelined(1) = scTickSetPairsStream with a second stream of the library's own. */
+ * scTickSetPipelined(n) = scTickSetPairsStream with a second stream of the library's own: n = 0 off, 1 = on with the default
+ * depth (3 copies of the per-tick broadphase state), 2..4 = on with that depth. */
 #define SC_TICK_COMM_ID_BYTES 128
 int scTickCommGetUniqueId(uint8_t id[SC_TICK_COMM_ID_BYTES]);
 int scTickCommInit(ScTickContext* ctx, const uint8_t id[SC_TICK_COMM_ID_BYTES], uint32_t world_size, uint32_t rank);

@@ -8,6 +8,7 @@
 #include "sc_tick_rccl.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -98,16 +99,18 @@ struct ScTickContext
   // kernel of tick t+1; everything the two halves share is double-buffered by tick parity (set 0 lives in `d`)
   hipStream_t pairsStream = nullptr;
   struct AltSet { uint32_t* binCount = nullptr; uint32_t* binLayers = nullptr; float4* bins = nullptr; float4* bigList = nullptr;
-                  float4* spill = nullptr; uint32_t* spillSector = nullptr; uint32_t* borderSend[8] = {}; uint32_t* borderRecv[8] = {}; } alt;
-  hipEvent_t packed[2] = { nullptr, nullptr }, pairsDone[2] = { nullptr, nullptr };
-  bool pairsInFlight[2] = { false, false };
+                  float4* spill = nullptr; uint32_t* spillSector = nullptr; uint32_t* borderSend[8] = {}; uint32_t* borderRecv[8] = {}; };
+  AltSet alt[kMaxParity - 1];          // parity q > 0 works on alt[q - 1]
+  uint32_t pipeDepth = 3;              // copies a pipelined tile rotates through (scTickSetPipelined)
+  hipEvent_t packed[kMaxParity] = {}, pairsDone[kMaxParity] = {};
+  bool pairsInFlight[kMaxParity] = {};
   // library-owned exchange (scTickCommInit): one RCCL communicator per context, the border messages of both tick
   // parities in buffers of the library's own, the neighbour in direction d at rank peer[d]
   ncclComm_t comm = nullptr;
   uint32_t commSize = 0, commRank = 0;
   int32_t peer[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };
   bool peersSet = false;
-  uint32_t* ownBorder[2][8][2] = {};   // [parity][direction][send, recv]
+  uint32_t* ownBorder[kMaxParity][8][2] = {};   // [parity][direction][send, recv]
   hipStream_t ownPairsStream = nullptr;
 };
 
@@ -201,10 +204,11 @@ bool sync(ScTickContext* c)
 DeviceState stateFor(const ScTickContext* c, uint32_t q)
 {
   DeviceState s = c->d;
-  if (c->pairsStream && q == 1u) {
-    s.binCount = c->alt.binCount; s.binLayers = c->alt.binLayers; s.bins = c->alt.bins; s.bigList = c->alt.bigList;
-    s.spill = c->alt.spill; s.spillSector = c->alt.spillSector;
-    for (int k = 0; k < 8; ++k) { s.borderSend[k] = c->alt.borderSend[k]; s.borderRecv[k] = c->alt.borderRecv[k]; }
+  if (c->pairsStream && q >= 1u && q < kMaxParity) {
+    const ScTickContext::AltSet& a = c->alt[q - 1u];
+    s.binCount = a.binCount; s.binLayers = a.binLayers; s.bins = a.bins; s.bigList = a.bigList;
+    s.spill = a.spill; s.spillSector = a.spillSector;
+    for (int k = 0; k < 8; ++k) { s.borderSend[k] = a.borderSend[k]; s.borderRecv[k] = a.borderRecv[k]; }
   }
   return s;
 }
@@ -516,7 +520,13 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
   if (const char* s = std::getenv("SC_TICK_VARIANT")) c->variant = (uint32_t)std::atoi(s);
 
   bool ok = bind(c);
-  if (ok) { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) ok = fail(c, "hipStreamCreate", e); c->ownStream = c->stream; }
+  if (ok) {
+    // (keeping compute units out of the tick stream's reach with a CU mask, so that the RCCL kernel of the pair half finds
+    //  free ones at once, was measured: 124-232 us per step against 89 -- masked queues schedule badly here)
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) ok = fail(c, "hipStreamCreate", e);
+    c->ownStream = c->stream;
+  }
   DeviceState& d = c->d;
   const size_t N = c->cap;
   // one slab for every 4-byte stream, one for the matrix rows (see Stream in sc_tick_internal.h)
@@ -537,7 +547,7 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
   ok = ok && dalloc(c, d.dirty, N / 32) && dalloc(c, d.unreach, N / 32)
           && dalloc(c, d.vis, N / 64) && dalloc(c, d.cand, N / 64) && dalloc(c, d.recomp, N / 64)
           && dalloc(c, d.blockVis, N / kTile) && dalloc(c, d.blockCand, N / kTile)
-          && dalloc(c, d.visibleIdx, N) && dalloc(c, d.culledIdx, N) && dalloc(c, d.counters, 32)
+          && dalloc(c, d.visibleIdx, N) && dalloc(c, d.culledIdx, N) && dalloc(c, d.counters, kCounterWords)
           && dalloc(c, d.aabbMin, N) && dalloc(c, d.aabbMax, N);
   { float* f = nullptr; ok = ok && dalloc(c, f, 32); d.frustum = f; }
   c->sectors = desc->tile_sectors_x ? (desc->tile_sectors_x + 2u) * (desc->tile_sectors_z + 2u) : 0u;
@@ -548,7 +558,7 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
     ok = ok && dalloc(c, d.binCount, c->sectors) && dalloc(c, d.binLayers, c->sectors) && dalloc(c, d.bins, (size_t)c->sectors * kBinCap * 2u, false)
             && dalloc(c, d.bigList, (N + 8u * kBorderBigCap) * 2u, false) && dalloc(c, d.spill, 2u * kSpillCap, false) && dalloc(c, d.spillSector, kSpillCap)
             && dalloc(c, d.bigBits[0], N / 32) && dalloc(c, d.bigBits[1], N / 32)
-            && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, 3u * kPairShards * kShardStride)
+            && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, (kMaxParity + 1u) * kPairShards * kShardStride)
             && dalloc(c, c->dPairsOut, c->maxPairs, false) && dalloc(c, c->dPairTotal, 4);
   }
   if (ok) { void* p = nullptr; e = hipMalloc(&p, N * sizeof(ScTickDrawItem)); if (e != hipSuccess) ok = fail(c, "hipMalloc draws", e); else { c->allocs.push_back(p); c->dDraws = p; } }
@@ -577,7 +587,7 @@ void scTickDestroyContext(ScTickContext* c)
   dropGraph(c);
   for (auto& v : c->times) for (auto& p : v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : c->eventPool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-  for (int k = 0; k < 2; ++k) { if (c->packed[k]) hipEventDestroy(c->packed[k]); if (c->pairsDone[k]) hipEventDestroy(c->pairsDone[k]); }
+  for (uint32_t k = 0; k < kMaxParity; ++k) { if (c->packed[k]) hipEventDestroy(c->packed[k]); if (c->pairsDone[k]) hipEventDestroy(c->pairsDone[k]); }
   if (c->pairsStream) hipStreamSynchronize(c->pairsStream);
   if (c->comm) { std::string why; if (const RcclApi* r = rccl(&why)) r->CommDestroy(c->comm); c->comm = nullptr; }
   for (void* p : c->allocs) hipFree(p);
@@ -1072,7 +1082,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   if (flags & SC_TICK_BROADPHASE) {
     c->prevBroadphaseN = c->n;
     if (flags & SC_TICK_SPLIT_PAIRS) { c->pairsPending = true; c->pendingParams = p; }
-    else { c->lastParity = c->parity; c->parity ^= 1u; }
+    else { c->lastParity = c->parity; c->parity ^= 1u; }           // (in-order flows alternate between two copies)
   }
   c->tickIndex++;
   const hipError_t e = hipGetLastError();
@@ -1100,7 +1110,8 @@ int scTickRunPairs(ScTickContext* c)
     launchPairs(ds, c->pendingParams, ps);
   }
   c->pairsPending = false;
-  c->lastParity = c->parity; c->parity ^= 1u;
+  c->lastParity = c->parity;
+  c->parity = c->pairsStream ? (c->parity + 1u) % c->pipeDepth : (c->parity ^ 1u);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, "kernel launch", e);
   return 1;
@@ -1141,17 +1152,16 @@ int scTickBindBorderBuffers(ScTickContext* c, uint32_t dir, void* send, void* re
   if (!c || dir > 7u) return c ? fail(c, "bad direction") : 0;
   c->d.borderSend[dir] = static_cast<uint32_t*>(send);
   c->d.borderRecv[dir] = static_cast<uint32_t*>(recv);
-  c->alt.borderSend[dir] = static_cast<uint32_t*>(send);
-  c->alt.borderRecv[dir] = static_cast<uint32_t*>(recv);
+  for (auto& a : c->alt) { a.borderSend[dir] = static_cast<uint32_t*>(send); a.borderRecv[dir] = static_cast<uint32_t*>(recv); }
   return 1;
 }
 
 int scTickBindBorderBuffersParity(ScTickContext* c, uint32_t parity, uint32_t dir, void* send, void* recv)
 {
   if (!c) return 0;
-  if (dir > 7 || parity > 1) return fail(c, "direction must be 0..7 and parity 0 or 1");
+  if (dir > 7 || parity >= kMaxParity) return fail(c, "direction must be 0..7 and parity 0..3");
   if (parity == 0) { c->d.borderSend[dir] = static_cast<uint32_t*>(send); c->d.borderRecv[dir] = static_cast<uint32_t*>(recv); }
-  else { c->alt.borderSend[dir] = static_cast<uint32_t*>(send); c->alt.borderRecv[dir] = static_cast<uint32_t*>(recv); }
+  else { c->alt[parity - 1u].borderSend[dir] = static_cast<uint32_t*>(send); c->alt[parity - 1u].borderRecv[dir] = static_cast<uint32_t*>(recv); }
   return 1;
 }
 
@@ -1168,37 +1178,42 @@ int scTickSetPairsStream(ScTickContext* c, void* stream)
   auto resetBroadphaseState = [&]() -> bool {
     if (!c->sectors) return true;
     const size_t N = c->cap;
-    hipError_t e = hipMemsetAsync(c->d.counters + kCtrPar, 0, 24u * sizeof(uint32_t), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d.pairShardCount, 0, 3u * kPairShards * kShardStride * sizeof(uint32_t), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d.bigBits[0], 0, N / 32 * sizeof(uint32_t), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d.bigBits[1], 0, N / 32 * sizeof(uint32_t), c->stream);
+    hipError_t e = hipMemsetAsync(c->d.counters + kCtrPar, 0, (kCounterWords - kCtrPar) * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d.pairShardCount, 0, (kMaxParity + 1u) * kPairShards * kShardStride * sizeof(uint32_t), c->stream);
+    for (uint32_t q = 0; q < kMaxParity && e == hipSuccess; ++q) if (c->d.bigBits[q]) e = hipMemsetAsync(c->d.bigBits[q], 0, N / 32 * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d.binCount, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d.binLayers, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
-    if (e == hipSuccess && c->alt.binCount) e = hipMemsetAsync(c->alt.binCount, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
-    if (e == hipSuccess && c->alt.binLayers) e = hipMemsetAsync(c->alt.binLayers, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
+    for (auto& a : c->alt) {
+      if (e == hipSuccess && a.binCount) e = hipMemsetAsync(a.binCount, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
+      if (e == hipSuccess && a.binLayers) e = hipMemsetAsync(a.binLayers, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
+    }
     if (e != hipSuccess) return fail(c, "hipMemsetAsync (broadphase state)", e);
     c->parity = 0; c->lastParity = 0; c->prevBroadphaseN = 0;
     return sync(c);
   };
   if (!stream) {
     if (c->pairsStream && !resetBroadphaseState()) return 0;
-    c->pairsStream = nullptr; c->pairsInFlight[0] = c->pairsInFlight[1] = false; c->topoEpoch++;
+    c->pairsStream = nullptr; for (bool& f : c->pairsInFlight) f = false; c->topoEpoch++;
     return 1;
   }
   if (!c->sectors) return fail(c, "the context has no broadphase");
-  if (!c->alt.bins) {
+  for (uint32_t q = 1; q < c->pipeDepth; ++q) {
+    ScTickContext::AltSet& a = c->alt[q - 1u];
     const size_t N = c->cap;
-    if (!dalloc(c, c->alt.binCount, c->sectors) || !dalloc(c, c->alt.binLayers, c->sectors) ||
-        !dalloc(c, c->alt.bins, (size_t)c->sectors * kBinCap * 2u, false) || !dalloc(c, c->alt.bigList, (N + 8u * kBorderBigCap) * 2u, false) ||
-        !dalloc(c, c->alt.spill, 2u * kSpillCap, false) || !dalloc(c, c->alt.spillSector, kSpillCap)) return 0;
-    for (int k = 0; k < 2; ++k) {
-      HIP_OK(c, hipEventCreateWithFlags(&c->packed[k], hipEventDisableTiming | hipEventReleaseToDevice));
-      HIP_OK(c, hipEventCreateWithFlags(&c->pairsDone[k], hipEventDisableTiming | hipEventReleaseToDevice));
-    }
+    if (!a.bins && (!dalloc(c, a.binCount, c->sectors) || !dalloc(c, a.binLayers, c->sectors) ||
+        !dalloc(c, a.bins, (size_t)c->sectors * kBinCap * 2u, false) || !dalloc(c, a.bigList, (N + 8u * kBorderBigCap) * 2u, false) ||
+        !dalloc(c, a.spill, 2u * kSpillCap, false) || !dalloc(c, a.spillSector, kSpillCap))) return 0;
+    if (!c->d.bigBits[q] && !dalloc(c, c->d.bigBits[q], N / 32)) return 0;
+    if (q > 1u && !a.borderSend[0] && !a.borderRecv[0])      // (buffers bound without a parity serve every copy)
+      for (int k = 0; k < 8; ++k) { a.borderSend[k] = c->alt[0].borderSend[k]; a.borderRecv[k] = c->alt[0].borderRecv[k]; }
+  }
+  for (uint32_t k = 0; k < kMaxParity; ++k) {
+    if (!c->packed[k]) HIP_OK(c, hipEventCreateWithFlags(&c->packed[k], hipEventDisableTiming | hipEventReleaseToDevice));
+    if (!c->pairsDone[k]) HIP_OK(c, hipEventCreateWithFlags(&c->pairsDone[k], hipEventDisableTiming | hipEventReleaseToDevice));
   }
   if (!c->pairsStream && !resetBroadphaseState()) return 0;
   c->pairsStream = static_cast<hipStream_t>(stream);
-  c->pairsInFlight[0] = c->pairsInFlight[1] = false;
+  for (bool& f : c->pairsInFlight) f = false;
   c->topoEpoch++;
   return 1;
 }
@@ -1291,10 +1306,10 @@ int scTickGetCounts(ScTickContext* c, ScTickCounts* out)
 {
   if (!c || !out) return c ? fail(c, "null argument") : 0;
   if (!bind(c) || !joinPairs(c)) return 0;
-  uint32_t k[32] = {};
+  uint32_t k[kCounterWords] = {};
   if (!d2h(c, k, c->d.counters, sizeof k) || !sync(c)) return 0;
   std::memset(out, 0, sizeof *out);
-  const uint32_t resultSlot = c->pairsStream ? 2u : c->lastParity;      // pipelined tiles: the snapshot the pair kernel left
+  const uint32_t resultSlot = c->pairsStream ? kSnapSet : c->lastParity;      // pipelined tiles: the snapshot the pair kernel left
   const uint32_t* bp = k + kCtrPar + 8u * resultSlot;
   out->entities = c->n;
   out->renderables_total = k[6];
@@ -1435,14 +1450,14 @@ int scTickReadPairs(ScTickContext* c, uint32_t* pairs2, uint32_t cap, uint32_t* 
   if (!joinPairs(c)) return 0;
   // the pair list is kept in per-shard segments on the device; gather them into one list first
   TickParams pp{}; pp.maxPairs = c->maxPairs;
-  const uint32_t slot = c->pairsStream ? 2u : c->lastParity;          // pipelined tiles: the snapshot the pair kernel left
+  const uint32_t slot = c->pairsStream ? kSnapSet : c->lastParity;          // pipelined tiles: the snapshot the pair kernel left
   launchGatherPairs(c->d, pp, slot, c->dPairsOut, c->dPairTotal, c->stream);
   uint32_t tot[2] = {};
   if (!d2h(c, tot, c->dPairTotal, sizeof tot) || !sync(c)) return 0;
   *count = tot[0];
   // each shard keeps at most maxPairs / 64 pairs; recount what the gather could place
-  uint32_t sc[3u * kPairShards * kShardStride];
-  if (!d2h(c, sc, c->d.pairShardCount, sizeof sc) || !sync(c)) return 0;
+  std::vector<uint32_t> sc((kMaxParity + 1u) * kPairShards * kShardStride);
+  if (!d2h(c, sc.data(), c->d.pairShardCount, sc.size() * sizeof(uint32_t)) || !sync(c)) return 0;
   uint32_t placed = 0;
   const uint32_t shardCap = c->maxPairs / kPairShards;
   for (uint32_t s = 0; s < kPairShards; ++s) placed += std::min(sc[(slot * kPairShards + s) * kShardStride], shardCap);
@@ -1646,13 +1661,13 @@ int scTickCommInit(ScTickContext* c, const uint8_t id[SC_TICK_COMM_ID_BYTES], ui
   c->commSize = worldSize; c->commRank = rank;
   // the messages of both tick parities live in buffers of the library's own (a caller that runs its own transport binds
   // its buffers with scTickBindBorderBuffers instead and never comes here)
-  for (uint32_t q = 0; q < 2; ++q)
+  for (uint32_t q = 0; q < kMaxParity; ++q)
     for (uint32_t d = 0; d < 8; ++d) {
       if (!((c->neighbourMask >> d) & 1u)) continue;
       const size_t words = borderWords(d, c->desc.tile_sectors_x, c->desc.tile_sectors_z);
       for (int k = 0; k < 2; ++k) if (!c->ownBorder[q][d][k] && !dalloc(c, c->ownBorder[q][d][k], words)) return 0;
       if (q == 0) { c->d.borderSend[d] = c->ownBorder[0][d][0]; c->d.borderRecv[d] = c->ownBorder[0][d][1]; }
-      else { c->alt.borderSend[d] = c->ownBorder[1][d][0]; c->alt.borderRecv[d] = c->ownBorder[1][d][1]; }
+      else { c->alt[q - 1u].borderSend[d] = c->ownBorder[q][d][0]; c->alt[q - 1u].borderRecv[d] = c->ownBorder[q][d][1]; }
     }
   return sync(c) ? 1 : 0;
 }
@@ -1662,6 +1677,13 @@ int scTickSetPipelined(ScTickContext* c, int enable)
   if (!c) return 0;
   if (!bind(c)) return 0;
   if (!enable) return scTickSetPairsStream(c, nullptr);
+  if (enable > (int)kMaxParity) return fail(c, "pipeline depth must be 2..4 (1 = the default, 3)");
+  const uint32_t depth = enable == 1 ? 3u : (uint32_t)enable;
+  if (depth != c->pipeDepth) {
+    if (c->pairsStream && !scTickSetPairsStream(c, nullptr)) return 0;     // re-enter with the new depth
+    c->pipeDepth = depth;
+  }
+  // (a high-priority pairs stream was measured: no gain, 94 against 90 us per step with the loop-back exchange)
   if (!c->ownPairsStream) HIP_OK(c, hipStreamCreateWithFlags(&c->ownPairsStream, hipStreamNonBlocking));
   return scTickSetPairsStream(c, c->ownPairsStream);
 }
@@ -1707,9 +1729,20 @@ int scTickTileStep(ScTickContext* c, uint32_t flags)
   if (!c) return 0;
   if (!(flags & SC_TICK_BROADPHASE) || !c->neighbourMask) return scTickRun(c, flags & ~(uint32_t)SC_TICK_SPLIT_PAIRS);   // nothing to exchange
   if (!c->comm) return fail(c, "no communicator: scTickCommInit first (a tile with neighbours cannot skip the exchange)");
+  static const bool prof = std::getenv("SC_TICK_HOSTPROF") != nullptr;
+  static double acc[3] = { 0, 0, 0 }; static uint64_t calls = 0;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = prof ? now() : 0.0;
   if (!scTickRun(c, flags | SC_TICK_SPLIT_PAIRS)) return 0;
+  const double t1 = prof ? now() : 0.0;
   if (!exchangeBorders(c, c->pendingParams.parity, c->pairsStream ? c->pairsStream : c->stream)) return 0;
-  return scTickRunPairs(c);
+  const double t2 = prof ? now() : 0.0;
+  const int ok = scTickRunPairs(c);
+  if (prof) {
+    acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += now() - t2;
+    if (++calls % 200 == 0) { std::fprintf(stderr, "[sc_tick hostprof] per step over 200: run %.1f us, exchange %.1f us, run_pairs %.1f us\n", acc[0] / 200, acc[1] / 200, acc[2] / 200); acc[0] = acc[1] = acc[2] = 0; }
+  }
+  return ok;
 }
 
 } // extern "C"

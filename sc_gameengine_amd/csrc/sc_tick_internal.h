@@ -76,9 +76,9 @@ struct DeviceState {
   float4* bigList;             // [cap][2] boxes that cannot be binned (too large, outside the rect, bin full)
   float4* spill;               // [kSpillCap][2] border records whose landing bin was full ...
   uint32_t* spillSector;       // ... and the sector each was meant for
-  uint32_t* bigBits[2];        // per-entity "is in the big list" bit, double-buffered by tick parity
+  uint32_t* bigBits[4];        // per-entity "is in the big list" bit, one buffer per tick parity (kMaxParity)
   uint2* pairs;                // (a, b) ids, a < b; id = rank << 24 | dense index; kPairShards segments of shardCap
-  uint32_t* pairShardCount;    // [2 parities][kPairShards] counters, one per 128-byte line (kShardStride words apart)
+  uint32_t* pairShardCount;    // [kMaxParity parities + snapshot][kPairShards] counters, one per 128-byte line (kShardStride words apart)
   // upstream movers (allocated on first scTickUploadMovers)
   uint32_t* moverKind; float *mvx, *mvz, *mlox, *mloz, *mhix, *mhiz;
   // multi-GPU border exchange: one message per neighbour direction (caller-owned device buffers)
@@ -104,7 +104,11 @@ constexpr uint32_t kPairShards = 64, kShardStride = 32, kWavePairBuf = 256;
 constexpr uint32_t kPrimary = 0x80000000u;
 // counters[]: 0 visible, 1 culled, 4 draws, 5 dropped, 6 renderables; per tick parity q: 8+8q+{0 pairs, 1 big, 2 bin-full}
 constexpr uint32_t kCtrPar = 8, kCtrPairs = 0, kCtrBig = 1, kCtrBinFull = 2, kCtrBorderLost = 3, kCtrBigLocal = 4, kCtrSpill = 5;
-// counter set 2 (counters[24..31]) and shard counter set 2: pipelined tiles' snapshot of the last pair search
+// Tick "parity": which copy of the per-tick broadphase state a tick works on.  The in-order flows alternate between two
+// copies; pipelined tiles rotate through `depth` (2..kMaxParity) copies, so that the pair half of tick t may still run while
+// the fused kernels of ticks t+1 .. t+depth-1 refill the others.
+constexpr uint32_t kMaxParity = 4, kSnapSet = kMaxParity, kCounterWords = kCtrPar + 8u * (kMaxParity + 1u);
+// counter set kSnapSet and shard counter set kSnapSet: pipelined tiles' snapshot of the last pair search
 // (kCtrBig counts the big list: this tile's boxes, then -- after the border merge -- its neighbours' that reach it;
 //  kCtrBigLocal keeps this tile's own count; kCtrBorderLost: records or boxes a border message had no room for, or
 //  big boxes that reach beyond the eight neighbouring tiles -- pairs may be missing)

@@ -746,7 +746,7 @@ __device__ __forceinline__ void resetOtherParity(const DeviceState& d, const Tic
 
 // Pipelined tiles: queued on the pairs stream right behind the pair kernel of parity q.  Nobody else may clear this parity's
 // state -- the next fused kernel of the OTHER parity is already running, the next of THIS parity waits for this stream -- so
-// the results are copied to the snapshot slot the host reads (counter set 2, shard counter set 2) and counters, shard
+// the results are copied to the snapshot slot the host reads (counter set kSnapSet, shard counter set kSnapSet) and counters, shard
 // counters and big-box bits are cleared here.  (Doing it in the pair kernel's last workgroup needs a ticket per workgroup:
 // a thousand device-scope atomics on one word cost more than this launch.)
 __global__ __launch_bounds__(kTile) void k_snapshot_reset(const DeviceState d, uint32_t q, uint32_t words)
@@ -756,8 +756,8 @@ __global__ __launch_bounds__(kTile) void k_snapshot_reset(const DeviceState d, u
     uint32_t cv = 0, sv = 0;
     if (threadIdx.x < 8) cv = d.counters[ctr + threadIdx.x];
     if (threadIdx.x < kPairShards) sv = d.pairShardCount[(q * kPairShards + threadIdx.x) * kShardStride];
-    if (threadIdx.x < 8) { d.counters[kCtrPar + 16u + threadIdx.x] = cv; d.counters[ctr + threadIdx.x] = 0u; }
-    if (threadIdx.x < kPairShards) { d.pairShardCount[(2u * kPairShards + threadIdx.x) * kShardStride] = sv; d.pairShardCount[(q * kPairShards + threadIdx.x) * kShardStride] = 0u; }
+    if (threadIdx.x < 8) { d.counters[kCtrPar + 8u * kSnapSet + threadIdx.x] = cv; d.counters[ctr + threadIdx.x] = 0u; }
+    if (threadIdx.x < kPairShards) { d.pairShardCount[(kSnapSet * kPairShards + threadIdx.x) * kShardStride] = sv; d.pairShardCount[(q * kPairShards + threadIdx.x) * kShardStride] = 0u; }
   }
   for (uint32_t w = blockIdx.x * kTile + threadIdx.x; w < words; w += gridDim.x * kTile) d.bigBits[q][w] = 0u;
 }

@@ -324,7 +324,8 @@ class WorldTick:
         self._ok(self.lib.scTickCommDestroy(self.ctx), "scTickCommDestroy")
 
     def set_pipelined(self, on):
-        self._ok(self.lib.scTickSetPipelined(self.ctx, 1 if on else 0), "scTickSetPipelined")
+        """False / 0 = off, True / 1 = on (default depth 3), 2..4 = on with that many copies of the per-tick broadphase state"""
+        self._ok(self.lib.scTickSetPipelined(self.ctx, int(on)), "scTickSetPipelined")
 
     def tile_step(self, flags):
         """One whole step of a tile: tick + pack, RCCL exchange, merge + pair search -- one call, nothing waits on the host."""

@@ -74,6 +74,8 @@ class BorderBuffers:
     batched isend/irecv group costs about 25 us per operation, 200 us for eight neighbours, four ticks' worth.
     send[d] / recv[d] are views of those tensors per direction (what the single-GPU tile tests copy between contexts)."""
 
+    PIPE_DEPTH = 3          # copies a pipelined tile rotates through (scTickSetPipelined's default)
+
     def __init__(self, tick, rank, grid, device, world_size=None, pipelined=False):
         import torch
         self.rank, self.grid = rank, grid
@@ -91,9 +93,9 @@ class BorderBuffers:
         for r in range(ranks):
             offset[r] = at
             at += self.splits[r]
-        # pipelined tiles keep one set per tick parity: tick t+1 packs its messages while tick t's are still in flight
+        # pipelined tiles keep one set per tick parity (t mod depth): later ticks pack their messages while tick t's are still in flight
         self.sets = []
-        for q in range(2 if pipelined else 1):
+        for q in range(self.PIPE_DEPTH if pipelined else 1):
             send_all = torch.zeros(total, dtype=torch.int32, device=device)
             recv_all = torch.zeros(total, dtype=torch.int32, device=device)
             send = {d: send_all[offset[r]:offset[r] + words[d]] for d, r in nb.items()}

@@ -65,7 +65,7 @@ def test_rccl_loopback_equals_device_copy_loopback(pipelined):
     for step in range(6):
         a.tile_step(flags)
         b.run(flags | capi.SPLIT_PAIRS)
-        q = (step & 1) if pipelined else 0
+        q = (step % len(bufs.sets)) if pipelined else 0
         send, recv = bufs.sets[q][2], bufs.sets[q][3]
         if pipelined:
             with torch.cuda.stream(s2):                     # ordered behind the pack by the library's event

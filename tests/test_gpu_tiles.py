@@ -258,7 +258,7 @@ def test_pipelined_tiles_overlap_pair_search_with_the_next_tick(oracle, grid):
         t.nudge_roots_x(0.7)
     steps = 6
     for step in range(steps):
-        q = step & 1
+        q = step % len(bufs[0].sets)
         for t in ticks:
             t.run(flags)                                               # tick stream: fused kernel, end-of-tick kernel, pack
         for r, b in enumerate(bufs):                                   # the "network", on the receivers' pairs streams

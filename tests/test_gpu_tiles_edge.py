@@ -124,7 +124,7 @@ def test_switching_between_in_order_and_pipelined_flows(oracle):
             for t in ticks:
                 t.nudge_roots_x(0.3)
                 t.run(SPLIT)
-            network(bufs, grid, parity=step & 1)
+            network(bufs, grid, parity=step % len(bufs[0].sets))
             for t in ticks:
                 t.run_pairs()
         ow.transform_system()

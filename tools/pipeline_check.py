@@ -21,6 +21,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=400)
 ap.add_argument("--workload", default="config3")
 ap.add_argument("--graph", type=int, default=0)
+ap.add_argument("--row", type=int, default=0, help="1: centre tile of a 3x1 world (two neighbours, 4 operations per group) instead of 3x3 (eight, 16)")
+ap.add_argument("--only", type=int, default=-1, help="run one flow only: 0 in order, 2..4 pipelined with that depth")
 args = ap.parse_args()
 
 S = 256
@@ -31,11 +33,17 @@ if args.workload == "config3dyn":
     w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
 out = {"world": f"{w.n} entities, centre tile of a 3x3 grid, loop-back RCCL (8 sends + 8 receives per step)"}
 flags = capi.FULL | capi.PRODUCE_NEXT
-for pipelined in (False, True):
+for pipelined in (0, 2, 3, 4):
+    if args.only >= 0 and pipelined != args.only:
+        continue
     t = WorldTick.from_world(w, broadphase=True)
     t.set_view_proj(camera_view_proj(w.camera))
-    t.set_tile(4, 0xFF); t.set_tile_grid(1, 1, 3, 3)
-    t.comm_init(capi.comm_unique_id(), 1, 0, peers=[0] * 8)
+    if args.row:
+        t.set_tile(1, 0b00011000); t.set_tile_grid(1, 0, 3, 1)
+        t.comm_init(capi.comm_unique_id(), 1, 0, peers=[-1, -1, -1, 0, 0, -1, -1, -1])
+    else:
+        t.set_tile(4, 0xFF); t.set_tile_grid(1, 1, 3, 3)
+        t.comm_init(capi.comm_unique_id(), 1, 0, peers=[0] * 8)
     t.set_pipelined(pipelined)
     t.set_frame_producer(1, 0.01); t.nudge_roots_x(0.01)
     if args.graph:
@@ -49,7 +57,7 @@ for pipelined in (False, True):
     issued = time.perf_counter() - t0
     t.sync()
     total = time.perf_counter() - t0
-    key = "pipelined" if pipelined else "in_order"
+    key = f"pipelined_depth{pipelined}" if pipelined else "in_order"
     out[key + "_us_per_step"] = round(total / args.steps * 1e6, 2)
     out[key + "_host_issue_us"] = round(issued / args.steps * 1e6, 2)
     # host issue alone, with the device idle between steps (the queue never fills up: what the call itself costs)
