@@ -238,7 +238,9 @@ int scTickSetStream(ScTickContext* ctx, void* hip_stream, int external);
  * SynthWorld's movers are that model reduced to straight segments inside the agent's sector:
  *   kind 1 (vehicle): pos += vel*dt, wrapping inside [lo, hi) on x and z
  *   kind 2 (ped):     pos += vel*dt, reflecting at lo / hi (the velocity component flips)
- * Only localPos.x / .z change; the moved entities are marked dirty, exactly as setLocalPosition does. */
+ * Only localPos.x / .z change; the moved entities are marked dirty, exactly as setLocalPosition does.
+ * These two kinds are SynthWorld's stand-ins (peds have no reference counterpart); the engine's own mover, the on-rails
+ * traffic agent, is below ("on-rails traffic") and advances in the same call. */
 int scTickUploadMovers(ScTickContext* ctx, uint32_t first, uint32_t count, const uint8_t* kind,
                        const float* vel_xz2, const float* lo_xz2, const float* hi_xz2);
 int scTickAdvanceMovers(ScTickContext* ctx, float dt);
@@ -247,6 +249,57 @@ int scTickReadMoverVelocities(ScTickContext* ctx, uint32_t first, uint32_t count
  * tick) is one stream sequence and, in graph mode, one captured hipGraph.  kind 0 = none,
  * 1 = scTickNudgeRootsX(param), 2 = scTickAdvanceMovers(param). */
 int scTickSetFrameProducer(ScTickContext* ctx, uint32_t kind, float param);
+
+/* ---- on-rails traffic: the engine's own upstream mover ----
+ * TrafficAISystem moves every agent of the OnRails tier along the lane graph each fixed step and writes its Transform
+ * (src/engine/traffic/sc_traffic_ai.cpp:264-299 preamble, :434-460 on-rails branch): targetSpeed is smoothed towards the
+ * lane's speed limit (smoothExp, :58-62, response 2.5), the agent advances targetSpeed * dt along its lane
+ * (TrafficLaneGraph::advanceAlongLane, src/engine/traffic/sc_traffic_lanes.cpp:291-352, crossing into the best-aligned
+ * connected segment, :137-156, parking on a dead end), localPos.x/z follow the lane, localRot = (0, atan2(dir.x, dir.z), 0),
+ * dirty = true.  Without a PhysicsWorld there is no obstacle ray (obstacleBrake = 0), as in the reference when
+ * TrafficAIState::physics is null.  The Physics / Kinematic tiers are Bullet's (absent): agents in those modes are left
+ * alone, their transforms arrive through the upload calls like any physics-synced body's.
+ * The lane graph is handed over flat: per segment the start node's position, the direction, length, end node, active flag
+ * and the speed limit of its start node (laneSpeedLimit, sc_traffic_lanes.cpp:392-400); per node its position and the
+ * segments that start there (LaneNode::connections, CSR).  sin / cos of each segment's yaw are taken here with the host
+ * libm, so an agent's world matrix equals the host's bit for bit: the device never evaluates a trigonometric function.
+ * scTickUploadTrafficAgents gives entities a TrafficAgent + TrafficVehicle (sc_traffic_common.h:26-44): lane id
+ * (0xFFFFFFFF = none: the spawner always assigns one, sc_traffic_spawner.cpp:315-318), laneS, targetSpeed, mode 0 Physics /
+ * 1 Kinematic / 2 OnRails, lookAheadDist (NULL = 12).  Agents then move with scTickAdvanceMovers(dt) or as the frame
+ * producer kind 2, next to SynthWorld's straight-line movers. */
+typedef struct ScTickLaneGraph
+{
+  uint32_t segments, nodes, connections;
+  const float* seg_start3;          /* [segments][3] m_nodes[startNode].pos */
+  const float* seg_dir3;            /* [segments][3] LaneSegment::dir (unit) */
+  const float* seg_length;          /* [segments] */
+  const uint8_t* seg_active;        /* [segments], NULL = all active */
+  const uint32_t* seg_end_node;     /* [segments] */
+  const float* seg_speed_limit;     /* [segments] m_nodes[startNode].speedLimit */
+  const float* node_pos3;           /* [nodes][3] */
+  const uint32_t* node_conn_offset; /* [nodes + 1] */
+  const uint32_t* node_conn;        /* [connections] segment ids, in LaneNode::connections order */
+} ScTickLaneGraph;
+int scTickSetLaneGraph(ScTickContext* ctx, const ScTickLaneGraph* graph);
+/* TrafficLaneGraph::removeSector / re-activation (sc_traffic_lanes.cpp:164-171, :227-237) */
+int scTickSetLaneActive(ScTickContext* ctx, const uint32_t* segment_ids, uint32_t count, int active);
+int scTickUploadTrafficAgents(ScTickContext* ctx, uint32_t first, uint32_t count, const uint8_t* is_agent, const uint32_t* lane_id,
+                              const float* lane_s, const float* target_speed, const uint8_t* mode, const float* look_ahead_dist);
+int scTickReadTrafficAgents(ScTickContext* ctx, uint32_t first, uint32_t count, uint32_t* lane_id, float* lane_s,
+                            float* target_speed, uint8_t* mode);
+/* TrafficDebugState::speedMultiplier (sc_traffic_ai.cpp:297-298); 1 by default */
+int scTickSetTrafficSpeedMultiplier(ScTickContext* ctx, float multiplier);
+/* TrafficLODSystem's tier selection (src/engine/traffic/sc_traffic_lod.cpp:269-274 threshold repair, :303-307 xz distance to
+ * the player, :323-353 hysteresis, :355-417 the physics / kinematic caps -- candidates sorted by distance, descending, equal
+ * distances in pool order, everything past the cap demoted): every agent's TrafficVehicle::mode becomes its desired tier.
+ * The total cap and the despawn behind it (:419-465) are streaming and stay with the caller. */
+typedef struct ScTickTierParams     /* TrafficDebugState, sc_traffic_common.h:67-75 */
+{
+  float tier_a_enter, tier_a_exit, tier_b_enter, tier_b_exit;   /* 50 / 70 / 110 / 150 m */
+  uint32_t max_physics, max_kinematic;                          /* 24 / 64; 0 = no cap */
+} ScTickTierParams;
+typedef struct ScTickTierCounts { uint32_t physics, kinematic, on_rails, total; } ScTickTierCounts;   /* tierPhysics / tierKinematic / tierOnRails / totalVehicles */
+int scTickSelectTrafficTiers(ScTickContext* ctx, const float player_pos[3], const ScTickTierParams* params, ScTickTierCounts* out);
 
 /* The renderer's draw order (VkRenderer::recordCommandBuffer, src/engine/src/sc_vk.cpp:1842-1864): draws whose
  * mesh handle is >= mesh_count or whose material handle has no Material are skipped, the rest sorted by

@@ -78,6 +78,8 @@ def lib():
     L.orc_transform_count.restype = C.c_uint32
     L.orc_transform_dense_entities.argtypes = [vp]
     L.orc_transform_dense_entities.restype = U32P
+    L.orc_transform_dense_data.argtypes = [vp]
+    L.orc_transform_dense_data.restype = vp
     L.orc_world_build.argtypes = [vp, C.c_uint32, F32P, F32P, F32P, I32P, U8P, U32P, U32P, U8P, F32P, F32P]
     L.orc_set_local_positions.argtypes = [vp, C.c_uint32, U32P, F32P]
     L.orc_nudge_roots_x.argtypes = [vp, C.c_float]
@@ -112,6 +114,17 @@ def lib():
     L.orc_is_occupied.argtypes = [vp, U8P, F32P, C.c_float]
     L.orc_is_occupied.restype = C.c_int
     L.orc_raycast_boxes.argtypes = [C.c_uint32, F32P, F32P, U32P, U32P, C.c_uint32, F32P, F32P, F32P, U32P, C.c_void_p]
+    L.orc_lanes_new.restype = vp
+    L.orc_lanes_free.argtypes = [vp]
+    L.orc_lanes_build_sector.argtypes = [vp, C.c_int32, C.c_int32, C.c_float, U32P]
+    L.orc_lanes_set_active.argtypes = [vp, C.c_uint32, C.c_int]
+    for name in ("orc_lanes_segment_count", "orc_lanes_node_count", "orc_lanes_connection_count"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = C.c_uint32
+    L.orc_lanes_export.argtypes = [vp, F32P, F32P, F32P, U8P, U32P, F32P, F32P, U32P, U32P]
+    L.orc_lanes_advance.argtypes = [vp, U32P, F32P, C.c_float, F32P, F32P]
+    L.orc_traffic_ai_onrails.argtypes = [vp, vp, U8P, U32P, F32P, F32P, U8P, F32P, C.c_float, C.c_float]
+    L.orc_traffic_lod_tiers.argtypes = [vp, U8P, U8P, F32P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, U8P, U32P]
     _LIB = L
     return L
 
@@ -205,6 +218,55 @@ def broadphase_grid(mn, mx, group, mask, cell):
     if cnt:
         lib().orc_broadphase_grid(n, _f(mn), _f(mx), _u(g), _u(m), float(cell), _u(out), cnt)
     return out
+
+
+# ---- lane graph + traffic (the step before the path) -------------------------------------------
+class OracleLanes:
+    """The oracle's TrafficLaneGraph restatement (oracle/sc_oracle_traffic.c)."""
+
+    def __init__(self):
+        self.L = lib()
+        self.g = self.L.orc_lanes_new()
+
+    def close(self):
+        if self.g:
+            self.L.orc_lanes_free(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build_sectors(self, cx, cz, sector_size=64.0):
+        """buildProceduralForSector for every sector, in this order; returns (sectors, 4) segment ids"""
+        out = np.zeros((len(cx), 4), np.uint32)
+        row = np.zeros(4, np.uint32)
+        for k in range(len(cx)):
+            self.L.orc_lanes_build_sector(self.g, int(cx[k]), int(cz[k]), float(sector_size), _u(row))
+            out[k] = row
+        return out
+
+    def set_active(self, seg, active):
+        self.L.orc_lanes_set_active(self.g, int(seg), 1 if active else 0)
+
+    def export(self):
+        from types import SimpleNamespace
+        S, N, Cn = (int(self.L.orc_lanes_segment_count(self.g)), int(self.L.orc_lanes_node_count(self.g)), int(self.L.orc_lanes_connection_count(self.g)))
+        a = SimpleNamespace(seg_start=np.zeros((S, 3), np.float32), seg_dir=np.zeros((S, 3), np.float32), seg_length=np.zeros(S, np.float32),
+                            seg_active=np.zeros(S, np.uint8), seg_end_node=np.zeros(S, np.uint32), seg_speed_limit=np.zeros(S, np.float32),
+                            node_pos=np.zeros((N, 3), np.float32), node_conn_offset=np.zeros(N + 1, np.uint32), node_conn=np.zeros(max(Cn, 1), np.uint32))
+        self.L.orc_lanes_export(self.g, _f(a.seg_start), _f(a.seg_dir), _f(a.seg_length), a.seg_active.ctypes.data_as(U8P), _u(a.seg_end_node),
+                                _f(a.seg_speed_limit), _f(a.node_pos), _u(a.node_conn_offset), _u(a.node_conn))
+        a.node_conn = a.node_conn[:Cn]
+        return a
+
+    def advance(self, lane, s, distance):
+        ln, ss = C.c_uint32(int(lane)), C.c_float(float(s))
+        pos, dr = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        ok = self.L.orc_lanes_advance(self.g, C.byref(ln), C.byref(ss), float(distance), _f(pos), _f(dr))
+        return bool(ok), ln.value, np.float32(ss.value), pos, dr
 
 
 # ---- world wrapper ---------------------------------------------------------------------------
@@ -327,6 +389,33 @@ class OracleWorld:
         assert vel.dtype == np.float32 and vel.flags.c_contiguous
         lo, hi = _c32(lo), _c32(hi)
         self.L.orc_advance_movers(self.w, k.ctypes.data_as(U8P), _f(vel), _f(lo), _f(hi), float(dt))
+
+    def traffic_ai_onrails(self, lanes, is_agent, lane_id, lane_s, target_speed, mode, look_ahead, dt, speed_multiplier=1.0):
+        """lane_id (uint32), lane_s, target_speed (float32) are updated in place"""
+        ia, md = np.ascontiguousarray(is_agent, np.uint8), np.ascontiguousarray(mode, np.uint8)
+        la = _c32(look_ahead)
+        assert lane_id.dtype == np.uint32 and lane_s.dtype == np.float32 and target_speed.dtype == np.float32
+        self.L.orc_traffic_ai_onrails(self.w, lanes.g, ia.ctypes.data_as(U8P), _u(lane_id), _f(lane_s), _f(target_speed),
+                                      md.ctypes.data_as(U8P), _f(la), float(speed_multiplier), float(dt))
+
+    def traffic_lod_tiers(self, is_agent, mode, player_pos, a_enter=50.0, a_exit=70.0, b_enter=110.0, b_exit=150.0, max_physics=24, max_kinematic=64):
+        ia, md = np.ascontiguousarray(is_agent, np.uint8), np.ascontiguousarray(mode, np.uint8)
+        pp = _c32(player_pos)
+        out = md.copy()
+        counts = np.zeros(3, np.uint32)
+        self.L.orc_traffic_lod_tiers(self.w, ia.ctypes.data_as(U8P), md.ctypes.data_as(U8P), _f(pp), float(a_enter), float(a_exit),
+                                     float(b_enter), float(b_exit), int(max_physics), int(max_kinematic), out.ctypes.data_as(U8P), _u(counts))
+        return out, tuple(int(x) for x in counts)
+
+    def local_rotations(self):
+        n = self.count()
+        v = np.ctypeslib.as_array(C.cast(self.L.orc_transform_dense_data(self.w), C.POINTER(C.c_uint8)), shape=(n, 128))
+        return v[:, 16:28].copy().view(np.float32).reshape(n, 3)
+
+    def local_positions(self):
+        n = self.count()
+        v = np.ctypeslib.as_array(C.cast(self.L.orc_transform_dense_data(self.w), C.POINTER(C.c_uint8)), shape=(n, 128))
+        return v[:, 4:16].copy().view(np.float32).reshape(n, 3)
 
     # systems
     def transform_system(self):

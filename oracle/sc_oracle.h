@@ -182,6 +182,27 @@ int orc_is_occupied(OrcWorld* w, const uint8_t* isAgent, const float pos[3], flo
  *      sc_traffic_ai.cpp:434-460): dense-order arrays; vel is updated in place for reflecting peds ---- */
 void orc_advance_movers(OrcWorld* w, const uint8_t* kind, float* vel_xz2, const float* lo_xz2, const float* hi_xz2, float dt);
 
+/* ---- the step before the path, sc_oracle_traffic.c: lane graph, on-rails traffic advance, tier selection.
+ *      PARITY UNPINNED (no reference test or fixture; the sources need Vulkan headers to compile). ---- */
+typedef struct OrcLaneGraph OrcLaneGraph;
+OrcLaneGraph* orc_lanes_new(void);
+void     orc_lanes_free(OrcLaneGraph* g);
+void     orc_lanes_build_sector(OrcLaneGraph* g, int32_t cx, int32_t cz, float sectorSize, uint32_t outSegs[4]);  /* sc_traffic_lanes.cpp:158-225 */
+void     orc_lanes_set_active(OrcLaneGraph* g, uint32_t seg, int active);                                        /* :227-237 */
+uint32_t orc_lanes_segment_count(const OrcLaneGraph* g);
+uint32_t orc_lanes_node_count(const OrcLaneGraph* g);
+uint32_t orc_lanes_connection_count(const OrcLaneGraph* g);
+void     orc_lanes_export(const OrcLaneGraph* g, float* segStart3, float* segDir3, float* segLength, uint8_t* segActive,
+                          uint32_t* segEndNode, float* segSpeedLimit, float* nodePos3, uint32_t* nodeConnOffset, uint32_t* nodeConn);
+int      orc_lanes_advance(const OrcLaneGraph* g, uint32_t* laneId, float* s, float distance, float outPos[3], float outDir[3]); /* :291-352 */
+/* dense-order arrays; laneId / laneS / targetSpeed are updated in place (sc_traffic_ai.cpp:264-299, :434-460) */
+void     orc_traffic_ai_onrails(OrcWorld* w, const OrcLaneGraph* g, const uint8_t* isAgent, uint32_t* laneId, float* laneS,
+                                float* targetSpeed, const uint8_t* mode, const float* lookAheadDist, float speedMultiplier, float dt);
+/* mode / desired: 0 Physics, 1 Kinematic, 2 OnRails (sc_traffic_common.h:11-16); counts[3] after the caps (sc_traffic_lod.cpp:323-417) */
+void     orc_traffic_lod_tiers(OrcWorld* w, const uint8_t* isAgent, const uint8_t* mode, const float playerPos[3],
+                               float tierAEnter, float tierAExit, float tierBEnter, float tierBExit,
+                               uint32_t maxPhysics, uint32_t maxKinematic, uint8_t* desiredOut, uint32_t counts[3]);
+
 /* ---- whole-tick convenience for the cpu_baseline leg: Transform + Camera + Culling ---- */
 void orc_tick(OrcWorld* w, OrcCameraState* cam, OrcCullingState* cull);
 

@@ -48,6 +48,21 @@ class RayHit(C.Structure):
                 ("normal", C.c_float * 3), ("layer", C.c_uint32), ("pad", C.c_uint32 * 2)]
 
 
+class LaneGraph(C.Structure):
+    _fields_ = [("segments", C.c_uint32), ("nodes", C.c_uint32), ("connections", C.c_uint32),
+                ("seg_start3", F32P), ("seg_dir3", F32P), ("seg_length", F32P), ("seg_active", U8P), ("seg_end_node", U32P),
+                ("seg_speed_limit", F32P), ("node_pos3", F32P), ("node_conn_offset", U32P), ("node_conn", U32P)]
+
+
+class TierParams(C.Structure):
+    _fields_ = [("tier_a_enter", C.c_float), ("tier_a_exit", C.c_float), ("tier_b_enter", C.c_float), ("tier_b_exit", C.c_float),
+                ("max_physics", C.c_uint32), ("max_kinematic", C.c_uint32)]
+
+
+class TierCounts(C.Structure):
+    _fields_ = [("physics", C.c_uint32), ("kinematic", C.c_uint32), ("on_rails", C.c_uint32), ("total", C.c_uint32)]
+
+
 class SectorInfo(C.Structure):
     _fields_ = [("version", C.c_uint32), ("sector_x", C.c_int32), ("sector_z", C.c_int32), ("instances", C.c_uint32),
                 ("lanes", C.c_uint32), ("lane_points", C.c_uint32), ("spawners", C.c_uint32), ("colliders", C.c_uint32),
@@ -100,6 +115,12 @@ SYMBOLS = {
     "scTickAdvanceMovers": (C.c_int, [_CTX, C.c_float]),
     "scTickReadMoverVelocities": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
     "scTickSetFrameProducer": (C.c_int, [_CTX, C.c_uint32, C.c_float]),
+    "scTickSetLaneGraph": (C.c_int, [_CTX, C.POINTER(LaneGraph)]),
+    "scTickSetLaneActive": (C.c_int, [_CTX, U32P, C.c_uint32, C.c_int]),
+    "scTickUploadTrafficAgents": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P, U32P, F32P, F32P, U8P, F32P]),
+    "scTickReadTrafficAgents": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U32P, F32P, F32P, U8P]),
+    "scTickSetTrafficSpeedMultiplier": (C.c_int, [_CTX, C.c_float]),
+    "scTickSelectTrafficTiers": (C.c_int, [_CTX, F32P, C.POINTER(TierParams), C.POINTER(TierCounts)]),
     "scTickSetViewProj": (C.c_int, [_CTX, F32P]),
     "scTickSetFrustumPlanes": (C.c_int, [_CTX, F32P, C.c_int]),
     "scTickGetFrustumPlanes": (C.c_int, [_CTX, F32P, C.POINTER(C.c_int)]),

@@ -92,6 +92,9 @@ struct ScTickContext
   uint32_t rank = 0, neighbourMask = 0;
   uint32_t tileX = 0, tileZ = 0, tilesX = 0, tilesZ = 0;
   uint32_t producerKind = 0; float producerParam = 0.0f;      // part of the frame when set (scTickSetFrameProducer)
+  float trafficMult = 1.0f;                                   // TrafficDebugState::speedMultiplier (sc_traffic_common.h:63)
+  void* laneAllocs[6] = {};                                   // device copies of the lane graph (scTickSetLaneGraph)
+  uint2* dTierPatch = nullptr;                                // tier selection: the few modes the caps changed
   bool pairsPending = false;
   TickParams pendingParams{};
   hipStream_t ownStream = nullptr;
@@ -399,6 +402,8 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.bigClearWords = ((c->pairsStream ? c->n : c->prevBroadphaseN) + 31u) >> 5;      // pipelined: a pair kernel clears its own parity
   if (c->pairsStream && (flags & SC_TICK_BROADPHASE)) p.flags |= kFlagDeferredReset;
   if (flags & SC_TICK_PRODUCE_NEXT) { p.producerKind = c->producerKind; p.producerParam = c->producerParam; }
+  p.trafficSmooth = 1.0f - std::exp(-2.5f * c->producerParam);       // smoothExp(current, target, 2.5f, dt), sc_traffic_ai.cpp:58-62, :437
+  p.trafficMult = c->trafficMult;
   p.bigCap = c->cap + 8u * kBorderBigCap;
   p.pairRunLog2 = pairRunLog2(p.binSX * p.binSZ);
   p.tileX = c->tileX; p.tileZ = c->tileZ; p.tilesX = c->tilesX; p.tilesZ = c->tilesZ;
@@ -424,7 +429,7 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
   if (c->producerKind && !(flags & SC_TICK_PRODUCE_NEXT)) {
     Scoped s(c, SC_TICK_K_NUDGE);
     if (c->producerKind == 1) launchNudgeRootsX(ds, c->n, c->producerParam, c->stream);
-    else launchAdvanceMovers(ds, c->n, c->producerParam, c->stream);
+    else launchAdvanceMovers(ds, c->n, c->producerParam, p.trafficSmooth, p.trafficMult, c->stream);
   }
   if (flags & (SC_TICK_XFORM | SC_TICK_CULL | SC_TICK_BROADPHASE)) {
     // the dominant kernel is timed by its own begin / end timestamps (the figure the roofline uses)
@@ -627,7 +632,8 @@ int scTickUploadLocals(ScTickContext* c, uint32_t first, uint32_t count, const f
     const uint8_t triv = (uint8_t)(((s[0][i] == 0.0f && s[1][i] == 1.0f) ? 4u : 0u) | ((s[2][i] == 0.0f && s[3][i] == 1.0f) ? 8u : 0u) |
                                    ((s[4][i] == 0.0f && s[5][i] == 1.0f) ? 16u : 0u));
     uint8_t& f = c->hFlags[first + i];
-    if ((f & 28u) != triv) { f = (uint8_t)((f & ~28u) | triv); c->linksStale = true; }
+    const uint8_t want = (f & 32u) ? 0u : triv;       // traffic agents: the device rewrites their yaw, every axis stays streamed
+    if ((f & 28u) != want) { f = (uint8_t)((f & ~28u) | want); c->linksStale = true; }
   }
   DeviceState& d = c->d;
   float* dst[6] = { d.rsx, d.rcx, d.rsy, d.rcy, d.rsz, d.rcz };
@@ -745,6 +751,7 @@ int scTickAppendEntities(ScTickContext* c, uint32_t count, const float* pos3, co
       scTickUploadRenderMeshes(c, first, count, nullptr, mesh ? mesh : zeros.data(), material ? material : zeros.data()) &&
       scTickUploadLayers(c, first, count, group ? group : all.data(), mask ? mask : all.data());
   if (!ok) { c->n = first; c->linksStale = true; return 0; }
+  for (uint32_t i = first; i < first + count; ++i) c->hFlags[i] &= (uint8_t)~32u;
   if (c->d.moverKind) {       // an appended entity is no mover until scTickUploadMovers says so
     const hipError_t e = hipMemsetAsync(c->d.moverKind + first, 0, (size_t)count * 4u, c->stream);
     if (e != hipSuccess) return fail(c, "hipMemsetAsync", e);
@@ -1274,7 +1281,7 @@ int scTickAdvanceMovers(ScTickContext* c, float dt)
   if (!bind(c) || !flushLinks(c)) return 0;
   if (!c->d.moverKind) return fail(c, "no movers uploaded");
   Scoped s(c, SC_TICK_K_NUDGE);
-  launchAdvanceMovers(c->d, c->n, dt, c->stream);
+  launchAdvanceMovers(c->d, c->n, dt, 1.0f - std::exp(-2.5f * dt), c->trafficMult, c->stream);
   return 1;
 }
 
@@ -1583,6 +1590,172 @@ int scTickSetGraphMode(ScTickContext* c, int enable)
 }
 
 void* scTickGetStream(ScTickContext* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---- on-rails traffic: lane graph, agents, tier selection ----------------------------------------------
+int scTickSetLaneGraph(ScTickContext* c, const ScTickLaneGraph* g)
+{
+  if (!c || !g) return c ? fail(c, "null argument") : 0;
+  if (g->segments && (!g->seg_start3 || !g->seg_dir3 || !g->seg_length || !g->seg_end_node || !g->seg_speed_limit)) return fail(c, "null segment array");
+  if (g->nodes && (!g->node_pos3 || !g->node_conn_offset)) return fail(c, "null node array");
+  if (g->connections && !g->node_conn) return fail(c, "null connection array");
+  for (uint32_t i = 0; i < g->segments; ++i) if (g->seg_end_node[i] >= g->nodes) return fail(c, "segment end node out of range");
+  for (uint32_t i = 0; i < g->nodes; ++i) if (g->node_conn_offset[i] > g->node_conn_offset[i + 1]) return fail(c, "node connection offsets must ascend");
+  if (g->nodes && g->node_conn_offset[g->nodes] != g->connections) return fail(c, "node_conn_offset[nodes] != connections");
+  if (!bind(c) || !sync(c)) return 0;
+  for (void*& p : c->laneAllocs) { dfree(c, p); p = nullptr; }
+  std::vector<float4> A(g->segments), B(g->segments), P(g->nodes);
+  std::vector<uint4> C(g->segments);
+  for (uint32_t i = 0; i < g->segments; ++i) {
+    const float* st = g->seg_start3 + 3 * (size_t)i; const float* dr = g->seg_dir3 + 3 * (size_t)i;
+    A[i] = make_float4(st[0], st[1], st[2], g->seg_length[i]);
+    B[i] = make_float4(dr[0], dr[1], dr[2], g->seg_speed_limit[i]);
+    // yawFromDir (sc_traffic_ai.cpp:72-75) and then the sin / cos mat4_rotation_xyz takes of it (sc_math.cpp:102-107), host libm
+    const float yaw = std::atan2(dr[0], dr[2]);
+    const float sy = std::sin(yaw), cy = std::cos(yaw);
+    uint32_t sb, cb; std::memcpy(&sb, &sy, 4); std::memcpy(&cb, &cy, 4);
+    C[i] = make_uint4(g->seg_end_node[i], (!g->seg_active || g->seg_active[i]) ? 1u : 0u, sb, cb);
+  }
+  for (uint32_t i = 0; i < g->nodes; ++i) P[i] = make_float4(g->node_pos3[3 * (size_t)i], g->node_pos3[3 * (size_t)i + 1], g->node_pos3[3 * (size_t)i + 2], 0.0f);
+  float4 *dA = nullptr, *dB = nullptr, *dP = nullptr; uint4* dC = nullptr; uint32_t *dOff = nullptr, *dConn = nullptr;
+  if (!dalloc(c, dA, g->segments, false) || !dalloc(c, dB, g->segments, false) || !dalloc(c, dC, g->segments, false) ||
+      !dalloc(c, dP, g->nodes, false) || !dalloc(c, dOff, (size_t)g->nodes + 1u) || !dalloc(c, dConn, g->connections, false)) return 0;
+  c->laneAllocs[0] = dA; c->laneAllocs[1] = dB; c->laneAllocs[2] = dC; c->laneAllocs[3] = dP; c->laneAllocs[4] = dOff; c->laneAllocs[5] = dConn;
+  bool ok = true;
+  if (g->segments) ok = h2d(c, dA, A.data(), A.size() * 16u) && h2d(c, dB, B.data(), B.size() * 16u) && h2d(c, dC, C.data(), C.size() * 16u);
+  if (ok && g->nodes) ok = h2d(c, dP, P.data(), P.size() * 16u) && h2d(c, dOff, g->node_conn_offset, ((size_t)g->nodes + 1u) * 4u);
+  if (ok && g->connections) ok = h2d(c, dConn, g->node_conn, (size_t)g->connections * 4u);
+  if (!ok || !sync(c)) return 0;
+  LaneGraphDev& L = c->d.lanes;
+  L.segA = dA; L.segB = dB; L.segC = dC; L.nodePos = dP; L.nodeConnOff = dOff; L.nodeConn = dConn; L.segments = g->segments; L.nodes = g->nodes;
+  c->topoEpoch++;                       // captured graphs hold the old table pointers
+  return 1;
+}
+
+int scTickSetLaneActive(ScTickContext* c, const uint32_t* segIds, uint32_t count, int active)
+{
+  if (!c || (!segIds && count)) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !sync(c)) return 0;
+  for (uint32_t k = 0; k < count; ++k) {
+    if (segIds[k] >= c->d.lanes.segments) return fail(c, "segment id out of range");
+    const uint32_t v = active ? 1u : 0u;
+    if (!h2d(c, reinterpret_cast<uint32_t*>(const_cast<uint4*>(c->d.lanes.segC) + segIds[k]) + 1, &v, 4u)) return 0;
+    if (!sync(c)) return 0;           // `v` dies with the iteration
+  }
+  return 1;
+}
+
+int scTickSetTrafficSpeedMultiplier(ScTickContext* c, float multiplier)
+{
+  if (!c) return 0;
+  if (!bind(c) || !sync(c)) return 0;
+  dropGraph(c);
+  c->trafficMult = multiplier;
+  return 1;
+}
+
+int scTickUploadTrafficAgents(ScTickContext* c, uint32_t first, uint32_t count, const uint8_t* isAgent, const uint32_t* laneId,
+                              const float* laneS, const float* targetSpeed, const uint8_t* mode, const float* lookAhead)
+{
+  if (!c || !isAgent || !laneId || !laneS || !targetSpeed || !mode) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  DeviceState& d = c->d;
+  const size_t N = c->cap;
+  if (!d.moverKind && (!dalloc(c, d.moverKind, N) || !dalloc(c, d.mvx, N) || !dalloc(c, d.mvz, N) || !dalloc(c, d.mlox, N) ||
+                       !dalloc(c, d.mloz, N) || !dalloc(c, d.mhix, N) || !dalloc(c, d.mhiz, N))) return 0;
+  if (!d.aLane && (!dalloc(c, d.aLane, N) || !dalloc(c, d.aS, N) || !dalloc(c, d.aSpeed, N) || !dalloc(c, d.aMode, N) || !dalloc(c, d.aLook, N) ||
+                   !dalloc(c, d.aDesired, N) || !dalloc(c, d.tierCounts, 4) || !dalloc(c, d.tierNear, kTierNearCap, false) || !dalloc(c, c->dTierPatch, kTierNearCap, false))) return 0;
+  if (!count) return 1;
+  if (!sync(c)) return 0;
+  std::vector<uint32_t> kind(count), md(count);
+  std::vector<float> look(count);
+  if (!d2h(c, kind.data(), d.moverKind + first, (size_t)count * 4u) || !sync(c)) return 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    if (mode[i] > 2u) return fail(c, "mode must be 0 (Physics), 1 (Kinematic) or 2 (OnRails)");
+    if (isAgent[i]) kind[i] = kMoverTraffic; else if (kind[i] == kMoverTraffic) kind[i] = 0u;
+    md[i] = mode[i];
+    look[i] = lookAhead ? lookAhead[i] : 12.0f;              // TrafficAgent::lookAheadDist, sc_traffic_common.h:32
+    uint8_t& f = c->hFlags[first + i];
+    const uint8_t nf = isAgent[i] ? (uint8_t)((f | 32u) & ~28u) : (uint8_t)(f & ~32u);
+    if (nf != f) { f = nf; c->linksStale = true; }            // an agent's rotation axes are always streamed (the device rewrites its yaw)
+  }
+  const bool ok = h2d(c, d.moverKind + first, kind.data(), (size_t)count * 4u) && h2d(c, d.aLane + first, laneId, (size_t)count * 4u) &&
+                  h2d(c, d.aS + first, laneS, (size_t)count * 4u) && h2d(c, d.aSpeed + first, targetSpeed, (size_t)count * 4u) &&
+                  h2d(c, d.aMode + first, md.data(), (size_t)count * 4u) && h2d(c, d.aLook + first, look.data(), (size_t)count * 4u);
+  return ok && sync(c) ? 1 : 0;
+}
+
+int scTickReadTrafficAgents(ScTickContext* c, uint32_t first, uint32_t count, uint32_t* laneId, float* laneS, float* targetSpeed, uint8_t* mode)
+{
+  if (!c) return 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!c->d.aLane) return fail(c, "no traffic agents uploaded");
+  if (!count) return 1;
+  std::vector<uint32_t> md(count);
+  bool ok = true;
+  if (laneId) ok = ok && d2h(c, laneId, c->d.aLane + first, (size_t)count * 4u);
+  if (laneS) ok = ok && d2h(c, laneS, c->d.aS + first, (size_t)count * 4u);
+  if (targetSpeed) ok = ok && d2h(c, targetSpeed, c->d.aSpeed + first, (size_t)count * 4u);
+  if (mode) ok = ok && d2h(c, md.data(), c->d.aMode + first, (size_t)count * 4u);
+  if (!ok || !sync(c)) return 0;
+  if (mode) for (uint32_t i = 0; i < count; ++i) mode[i] = (uint8_t)md[i];
+  return 1;
+}
+
+int scTickSelectTrafficTiers(ScTickContext* c, const float playerPos[3], const ScTickTierParams* tp, ScTickTierCounts* out)
+{
+  if (!c || !playerPos || !tp) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !flushLinks(c)) return 0;
+  if (!c->d.aLane) return fail(c, "no traffic agents uploaded");
+  TierParams k;
+  k.px = playerPos[0]; k.pz = playerPos[2];
+  k.aEnter = tp->tier_a_enter; k.aExit = tp->tier_a_exit; k.bEnter = tp->tier_b_enter; k.bExit = tp->tier_b_exit;
+  if (k.aExit < k.aEnter + 1.0f) k.aExit = k.aEnter + 1.0f;           // sc_traffic_lod.cpp:269-274
+  if (k.bEnter < k.aExit + 1.0f) k.bEnter = k.aExit + 1.0f;
+  if (k.bExit < k.bEnter + 1.0f) k.bExit = k.bEnter + 1.0f;
+  HIP_OK(c, hipMemsetAsync(c->d.tierCounts, 0, 4 * sizeof(uint32_t), c->stream));
+  launchTrafficTiers(c->d, c->n, k, c->stream);
+  uint32_t cnt[4] = {};
+  if (!d2h(c, cnt, c->d.tierCounts, sizeof cnt) || !sync(c)) return 0;
+  if (cnt[3] > kTierNearCap) return fail(c, "more than 65536 agents want the Physics or Kinematic tier");
+  std::vector<uint2> nearList(cnt[3]);
+  if (cnt[3] && (!d2h(c, nearList.data(), c->d.tierNear, (size_t)cnt[3] * 8u) || !sync(c))) return 0;
+  // the order ForEach would visit them in (Transform-pool dense order): the list arrives in atomic order
+  std::sort(nearList.begin(), nearList.end(), [](const uint2& a, const uint2& b) { return a.x < b.x; });
+  uint32_t physicsCount = cnt[0], kinematicCount = cnt[1], onRailsCount = cnt[2];
+  std::vector<uint8_t> des(nearList.size());
+  std::vector<float> dist(nearList.size());
+  for (size_t q = 0; q < nearList.size(); ++q) {
+    const uint32_t bits = nearList[q].y & 0x7FFFFFFFu;
+    std::memcpy(&dist[q], &bits, 4);
+    des[q] = (uint8_t)((nearList[q].y >> 31) ? kTierKinematic : kTierPhysics);
+  }
+  // the caps, sc_traffic_lod.cpp:355-417: candidates sorted by distance, descending (std::sort there; stable here, so equal
+  // distances keep their pool order), everything past the cap is demoted
+  std::vector<uint2> patches;
+  auto byDistDesc = [&](uint32_t a, uint32_t b) { return dist[a] > dist[b]; };
+  if (tp->max_physics > 0 && physicsCount > tp->max_physics) {
+    std::vector<uint32_t> phys;
+    for (uint32_t q = 0; q < des.size(); ++q) if (des[q] == kTierPhysics) phys.push_back(q);
+    std::stable_sort(phys.begin(), phys.end(), byDistDesc);
+    for (size_t a = tp->max_physics; a < phys.size(); ++a) {
+      if (tp->max_kinematic == 0 || kinematicCount < tp->max_kinematic) { des[phys[a]] = (uint8_t)kTierKinematic; kinematicCount++; }
+      else { des[phys[a]] = (uint8_t)kTierOnRails; onRailsCount++; }
+      physicsCount--;
+    }
+  }
+  if (tp->max_kinematic > 0 && kinematicCount > tp->max_kinematic) {
+    std::vector<uint32_t> kin;
+    for (uint32_t q = 0; q < des.size(); ++q) if (des[q] == kTierKinematic) kin.push_back(q);
+    std::stable_sort(kin.begin(), kin.end(), byDistDesc);
+    for (size_t a = tp->max_kinematic; a < kin.size(); ++a) { des[kin[a]] = (uint8_t)kTierOnRails; kinematicCount--; onRailsCount++; }
+  }
+  for (uint32_t q = 0; q < des.size(); ++q) patches.push_back(make_uint2(nearList[q].x, des[q]));
+  if (!patches.empty() && !h2d(c, c->dTierPatch, patches.data(), patches.size() * 8u)) return 0;
+  launchApplyTiers(c->d, c->n, c->dTierPatch, (uint32_t)patches.size(), c->stream);
+  if (!sync(c)) return 0;
+  if (out) { out->physics = physicsCount; out->kinematic = kinematicCount; out->on_rails = onRailsCount; out->total = physicsCount + kinematicCount + onRailsCount; }
+  return 1;
+}
 
 // ---- the border exchange, owned by the library -------------------------------------------------------------------
 static const RcclApi* needRccl(ScTickContext* c)

@@ -39,6 +39,25 @@ enum Stream : uint32_t {
   kBMINX, kBMINY, kBMINZ, kBMAXX, kBMAXY, kBMAXZ, kLINK, kLAYERS, kMESH, kMATERIAL, kStreamCount
 };
 
+// Lane graph of the traffic system (TrafficLaneGraph, src/engine/traffic/sc_traffic_lanes.h:13-30) as the on-rails advance
+// reads it: per segment its start node's position and length, its direction and speed limit (laneSpeedLimit = the start
+// node's, sc_traffic_lanes.cpp:392-400), its end node, the active flag, and sin / cos of yaw = atan2(dir.x, dir.z) taken with
+// the HOST libm when the graph is set -- an on-rails agent's rotation only ever takes these per-segment values
+// (sc_traffic_ai.cpp:455), so the device never evaluates a trigonometric function and stays bit-equal to the host.
+struct LaneGraphDev {
+  const float4* segA;           // start.xyz, length
+  const float4* segB;           // dir.xyz, speed limit
+  const uint4*  segC;           // end node, active, bits of sin(yaw), bits of cos(yaw)
+  const float4* nodePos;        // xyz
+  const uint32_t* nodeConnOff;  // [nodes + 1] offsets into nodeConn (LaneNode::connections)
+  const uint32_t* nodeConn;     // segment ids
+  uint32_t segments, nodes;
+};
+constexpr uint32_t kInvalidLane = 0xFFFFFFFFu;               // kInvalidLaneId, sc_traffic_common.h:9
+constexpr uint32_t kTierPhysics = 0, kTierKinematic = 1, kTierOnRails = 2;   // TrafficSimMode, sc_traffic_common.h:11-16
+constexpr uint32_t kMoverTraffic = 3;                        // moverKind of a traffic agent (1 / 2: SynthWorld's straight-line movers)
+constexpr uint32_t kTierNearCap = 1u << 16;                  // agents whose desired tier is not OnRails, per selection
+
 // Device SoA state of one context.  All arrays are sized to `cap` (padded to kTile).
 struct DeviceState {
   const char* fslab;        // kStreamCount streams x cap x 4 B
@@ -81,6 +100,11 @@ struct DeviceState {
   uint32_t* pairShardCount;    // [kMaxParity parities + snapshot][kPairShards] counters, one per 128-byte line (kShardStride words apart)
   // upstream movers (allocated on first scTickUploadMovers)
   uint32_t* moverKind; float *mvx, *mvz, *mlox, *mloz, *mhix, *mhiz;
+  // traffic agents (TrafficAgent + TrafficVehicle, sc_traffic_common.h:26-44; allocated on first scTickUploadTrafficAgents)
+  LaneGraphDev lanes;
+  uint32_t* aLane; float* aS; float* aSpeed; uint32_t* aMode; float* aLook; uint32_t* aDesired;
+  uint32_t* tierCounts;        // [0..2] desired tiers, [3] entries in tierNear
+  uint2* tierNear;             // (dense index, bits of the distance) of agents whose desired tier is Physics or Kinematic
   // multi-GPU border exchange: one message per neighbour direction (caller-owned device buffers)
   uint32_t* borderSend[8];
   uint32_t* borderRecv[8];
@@ -130,6 +154,7 @@ struct TickParams {
   uint32_t chain;           // min(deepest hierarchy level, kMaxChain): selects the fused kernel's specialisation
   uint32_t tileX, tileZ, tilesX, tilesZ;   // this tile's place in the grid of equal tiles (tilesX == 0: unknown, no big-box exchange)
   uint32_t producerKind; float producerParam;   // with SC_TICK_PRODUCE_NEXT: the frame producer fused into the end-of-tick kernel
+  float trafficSmooth, trafficMult;             // movers: 1 - exp(-2.5 dt) (smoothExp, sc_traffic_ai.cpp:58-62; host libm) and dbg->speedMultiplier
   uint32_t bigCap;          // entries the big list can hold (capacity + room for the neighbours' boxes): every index into it is held below this
   uint32_t bigClearWords;   // words of the other parity's bigBits the previous broadphase tick may have set (its entity count / 32)
   uint32_t pairRunLog2;     // pair role: a wave takes its sectors in runs of 2^pairRunLog2 consecutive ones (pairRunLog2())
@@ -187,7 +212,10 @@ void launchCompactPack(const DeviceState& d, const TickParams& p, uint32_t grid,
 void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchBorderMerge(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s);
-void launchAdvanceMovers(const DeviceState& d, uint32_t n, float dt, hipStream_t s);
+void launchAdvanceMovers(const DeviceState& d, uint32_t n, float dt, float trafficSmooth, float trafficMult, hipStream_t s);
+struct TierParams { float px, pz, aEnter, aExit, bEnter, bExit; };
+void launchTrafficTiers(const DeviceState& d, uint32_t n, const TierParams& tp, hipStream_t s);
+void launchApplyTiers(const DeviceState& d, uint32_t n, const uint2* patches, uint32_t patchCount, hipStream_t s);
 void launchDenseAabbs(const DeviceState& d, uint32_t n, hipStream_t s);
 void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, hipStream_t s);
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);

@@ -539,11 +539,89 @@ __device__ __forceinline__ void markDirtyWave(const DeviceState& d, uint32_t i, 
 }
 // Upstream movers (include/sc_tick.h "upstream movers"): straight-line advance inside the agent's
 // sector, vehicles wrap, peds reflect.  pos + vel*dt is two roundings (no FMA), as the oracle's.
-__device__ __forceinline__ bool moverPosition(const DeviceState& d, uint32_t i, uint32_t n, float dt)
+// ---- on-rails traffic (the step before the path) -------------------------------------------------------
+// advanceAlongLane, src/engine/traffic/sc_traffic_lanes.cpp:291-352, with chooseNextSegment :137-156 inside: walk `distance`
+// along the lane graph from (lane, s), at most eight segments; a dead end parks the agent on the end node.
+struct LaneStep { bool ok; uint32_t lane; float s; float pos[3]; float dir[3]; };
+__device__ __forceinline__ LaneStep advanceAlongLane(const LaneGraphDev& g, uint32_t lane, float s, float distance)
+{
+  LaneStep r; r.ok = false; r.lane = lane; r.s = s;
+  r.pos[0] = r.pos[1] = r.pos[2] = 0.0f; r.dir[0] = r.dir[1] = r.dir[2] = 0.0f;
+  if (lane == kInvalidLane || lane >= g.segments) return r;
+  float remaining = distance; uint32_t current = lane; float currentS = s;
+  for (uint32_t guard = 0; guard < 8u; ++guard) {
+    const float4 A = g.segA[current], B = g.segB[current]; const uint4 C = g.segC[current];
+    if (!C.y) return r;                                     // !seg.active
+    const float len = A.w;
+    if (len <= 1e-5f) return r;
+    const float available = len - currentS;
+    if (remaining <= available) {
+      currentS += remaining;
+      r.pos[0] = A.x + B.x * currentS; r.pos[1] = A.y + B.y * currentS; r.pos[2] = A.z + B.z * currentS;
+      r.dir[0] = B.x; r.dir[1] = B.y; r.dir[2] = B.z;
+      r.lane = current; r.s = currentS; r.ok = true;
+      return r;
+    }
+    remaining -= available; currentS = 0.0f;
+    // chooseNextSegment: the active connection of the end node whose direction agrees best (dot > -1)
+    uint32_t best = kInvalidLane; float bestDot = -1.0f;
+    const uint32_t c0 = g.nodeConnOff[C.x], c1 = g.nodeConnOff[C.x + 1u];
+    for (uint32_t k = c0; k < c1; ++k) {
+      const uint32_t segId = g.nodeConn[k];
+      if (segId >= g.segments) continue;
+      if (!g.segC[segId].y) continue;
+      const float4 D = g.segB[segId];
+      const float dot = B.x * D.x + B.y * D.y + B.z * D.z;
+      if (dot > bestDot) { bestDot = dot; best = segId; }
+    }
+    if (best == kInvalidLane) {
+      const float4 E = g.nodePos[C.x];
+      r.pos[0] = E.x; r.pos[1] = E.y; r.pos[2] = E.z; r.dir[0] = B.x; r.dir[1] = B.y; r.dir[2] = B.z;
+      r.lane = current; r.s = len; r.ok = true;
+      return r;
+    }
+    current = best;
+  }
+  return r;
+}
+
+// TrafficAISystem for one agent of the OnRails tier, without a PhysicsWorld (no obstacle ray: obstacleBrake = 0):
+// the per-agent preamble src/engine/traffic/sc_traffic_ai.cpp:264-299 (valid active lane, look-ahead point, the 1e-4 early
+// out, desired speed) and the on-rails branch :434-460.  Returns true when the transform was written (Transform::dirty).
+// `smooth` = 1 - exp(-2.5 dt) from the host (smoothExp :58-62); the yaw's sin / cos come from the segment table.
+__device__ __forceinline__ bool trafficAgentStep(const DeviceState& d, uint32_t i, float dt, float smooth, float mult)
+{
+  if (d.aMode[i] != kTierOnRails) return false;               // Physics / Kinematic tiers: moved by the physics sync, not here
+  const LaneGraphDev& g = d.lanes;
+  const uint32_t lane = d.aLane[i];
+  if (lane == kInvalidLane || lane >= g.segments) return false;
+  if (!g.segC[lane].y) return false;
+  const float s0 = d.aS[i];
+  const LaneStep look = advanceAlongLane(g, lane, s0, d.aLook[i]);   // getLookAheadPoint, sc_traffic_lanes.cpp:281-289
+  if (!look.ok) return false;
+  const float tx = look.pos[0] - d.px[i], tz = look.pos[2] - d.pz[i];
+  if (sqrtf(tx * tx + 0.0f * 0.0f + tz * tz) < 1e-4f) return false;
+  float desiredSpeed = g.segB[lane].w * mult;
+  desiredSpeed = (0.0f < desiredSpeed) ? desiredSpeed : 0.0f;         // std::max(0.0f, desiredSpeed)
+  const float desired = desiredSpeed * (1.0f - 0.0f);
+  const float cur = d.aSpeed[i];
+  const float speed = cur + (desired - cur) * smooth;
+  d.aSpeed[i] = speed;
+  const LaneStep st = advanceAlongLane(g, lane, s0, speed * dt);
+  if (!st.ok) return false;
+  d.aLane[i] = st.lane; d.aS[i] = st.s;
+  d.px[i] = st.pos[0]; d.pz[i] = st.pos[2];                    // localPos.y keeps its value (:447)
+  const uint4 C = g.segC[st.lane];
+  d.rsx[i] = 0.0f; d.rcx[i] = 1.0f; d.rsy[i] = __uint_as_float(C.z); d.rcy[i] = __uint_as_float(C.w); d.rsz[i] = 0.0f; d.rcz[i] = 1.0f;
+  return true;
+}
+
+__device__ __forceinline__ bool moverPosition(const DeviceState& d, uint32_t i, uint32_t n, float dt, float smooth, float mult)
 {
   const bool in = i < n;
   // everything is requested at once (one round trip); non-movers just drop what they fetched
   const uint32_t kind = in ? d.moverKind[i] : 0u;
+  if (kind == kMoverTraffic) return trafficAgentStep(d, i, dt, smooth, mult);
   float vx = 0, vz = 0, lox = 0, loz = 0, hix = 0, hiz = 0, x = 0, z = 0;
   if (in) { vx = d.mvx[i]; vz = d.mvz[i]; lox = d.mlox[i]; loz = d.mloz[i]; hix = d.mhix[i]; hiz = d.mhiz[i]; x = d.px[i]; z = d.pz[i]; }
   if (kind) {
@@ -562,7 +640,7 @@ __device__ __forceinline__ bool moverPosition(const DeviceState& d, uint32_t i, 
 }
 __device__ __forceinline__ bool producePosition(const DeviceState& d, const TickParams& p, uint32_t i)
 {
-  return p.producerKind == 1u ? nudgePosition(d, i, p.n, p.producerParam) : moverPosition(d, i, p.n, p.producerParam);
+  return p.producerKind == 1u ? nudgePosition(d, i, p.n, p.producerParam) : moverPosition(d, i, p.n, p.producerParam, p.trafficSmooth, p.trafficMult);
 }
 
 __device__ __forceinline__ uint32_t blockSum(uint32_t v, uint32_t* scratch)
@@ -1337,10 +1415,52 @@ __global__ __launch_bounds__(kTile) void k_dense_aabbs(const DeviceState d, uint
   d.aabbMax[i] = make_float4(mx[0], mx[1], mx[2], 0.0f);
 }
 
-__global__ __launch_bounds__(kTile) void k_advance_movers(const DeviceState d, uint32_t n, float dt)
+__global__ __launch_bounds__(kTile) void k_advance_movers(const DeviceState d, uint32_t n, float dt, float smooth, float mult)
 {
   const uint32_t i = blockIdx.x * kTile + threadIdx.x;
-  markDirtyWave(d, i, n, moverPosition(d, i, n, dt));
+  markDirtyWave(d, i, n, moverPosition(d, i, n, dt, smooth, mult));
+}
+
+// TrafficLODSystem's tier selection, per vehicle (src/engine/traffic/sc_traffic_lod.cpp:303-307 distance to the player in
+// the xz plane, :323-353 the hysteresis between the tiers): writes the desired tier, counts the tiers, and lists the few
+// agents that want the Physics or Kinematic tier (the host applies the caps :355-417 to that list).
+__global__ __launch_bounds__(kTile) void k_traffic_tiers(const DeviceState d, uint32_t n, const TierParams tp)
+{
+  const uint32_t i = blockIdx.x * kTile + threadIdx.x;
+  const bool agent = i < n && d.moverKind[i] == kMoverTraffic;
+  uint32_t want = kTierOnRails; float dist = 0.0f;
+  if (agent) {
+    const float dx = d.px[i] - tp.px, dz = d.pz[i] - tp.pz;
+    dist = sqrtf(dx * dx + dz * dz);
+    const uint32_t cur = d.aMode[i];
+    if (cur == kTierPhysics) want = (dist > tp.aExit) ? ((dist < tp.bEnter) ? kTierKinematic : kTierOnRails) : kTierPhysics;
+    else if (cur == kTierKinematic) want = (dist < tp.aEnter) ? kTierPhysics : ((dist > tp.bExit) ? kTierOnRails : kTierKinematic);
+    else want = (dist < tp.aEnter) ? kTierPhysics : ((dist < tp.bEnter) ? kTierKinematic : kTierOnRails);
+    d.aDesired[i] = want;
+  }
+  const unsigned long long mp = __ballot(agent && want == kTierPhysics), mk = __ballot(agent && want == kTierKinematic), mr = __ballot(agent && want == kTierOnRails);
+  if ((threadIdx.x & 63u) == 0u) {
+    if (mp) atomicAdd(&d.tierCounts[0], (uint32_t)__popcll(mp));
+    if (mk) atomicAdd(&d.tierCounts[1], (uint32_t)__popcll(mk));
+    if (mr) atomicAdd(&d.tierCounts[2], (uint32_t)__popcll(mr));
+  }
+  if (agent && want != kTierOnRails) {
+    const uint32_t slot = atomicAdd(&d.tierCounts[3], 1u);
+    // (a distance is never negative: its sign bit carries which of the two tiers is wanted)
+    if (slot < kTierNearCap) d.tierNear[slot] = make_uint2(i, __float_as_uint(dist) | (want == kTierKinematic ? 0x80000000u : 0u));
+  }
+}
+
+// TrafficVehicle::mode = the desired tier (applyMode, sc_traffic_lod.cpp:486-487), then the handful the caps changed
+__global__ __launch_bounds__(kTile) void k_apply_tiers(const DeviceState d, uint32_t n)
+{
+  const uint32_t i = blockIdx.x * kTile + threadIdx.x;
+  if (i < n && d.moverKind[i] == kMoverTraffic) d.aMode[i] = d.aDesired[i];
+}
+__global__ __launch_bounds__(kTile) void k_patch_tiers(const DeviceState d, const uint2* __restrict__ patches, uint32_t count)
+{
+  const uint32_t t = blockIdx.x * kTile + threadIdx.x;
+  if (t < count) d.aMode[patches[t].x] = patches[t].y;
 }
 
 __global__ __launch_bounds__(kTile) void k_set_dirty_range(const DeviceState d, uint32_t first, uint32_t count)
@@ -1373,7 +1493,7 @@ __global__ __launch_bounds__(kTile) void k_gather_rows(const DeviceState d, cons
 // Swap-remove relocations (ComponentPool::remove, sc_ecs.h:240-262, applied to every per-entity array at
 // once): entity src[k] moves to slot dst[k].  The host guarantees every src lies at or beyond the new
 // entity count and every dst below it, so no slot is both read and written.  One thread per (move, array).
-constexpr uint32_t kMoveSlots = 40;     // 22 streams, 3 matrix rows, the dirty bit, 7 mover arrays (+ idle)
+constexpr uint32_t kMoveSlots = 40;     // 22 streams, 3 matrix rows, the dirty bit, 7 mover arrays, 5 traffic-agent arrays (+ idle)
 __global__ __launch_bounds__(kTile) void k_move_entities(const DeviceState d, const uint32_t* __restrict__ src,
                                                          const uint32_t* __restrict__ dst, uint32_t moves)
 {
@@ -1396,6 +1516,10 @@ __global__ __launch_bounds__(kTile) void k_move_entities(const DeviceState d, co
                             reinterpret_cast<uint32_t*>(d.mlox), reinterpret_cast<uint32_t*>(d.mloz),
                             reinterpret_cast<uint32_t*>(d.mhix), reinterpret_cast<uint32_t*>(d.mhiz) };
     uint32_t* a = arrays[slot - kStreamCount - 4u];
+    a[to] = a[from];
+  } else if (d.aLane && slot >= kStreamCount + 11u && slot < kStreamCount + 16u) {
+    uint32_t* arrays[5] = { d.aLane, reinterpret_cast<uint32_t*>(d.aS), reinterpret_cast<uint32_t*>(d.aSpeed), d.aMode, reinterpret_cast<uint32_t*>(d.aLook) };
+    uint32_t* a = arrays[slot - kStreamCount - 11u];
     a[to] = a[from];
   }
 }
@@ -1545,10 +1669,21 @@ void launchDenseAabbs(const DeviceState& d, uint32_t n, hipStream_t s)
   if (!n) return;
   hipLaunchKernelGGL(k_dense_aabbs, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n);
 }
-void launchAdvanceMovers(const DeviceState& d, uint32_t n, float dt, hipStream_t s)
+void launchAdvanceMovers(const DeviceState& d, uint32_t n, float dt, float trafficSmooth, float trafficMult, hipStream_t s)
 {
   if (!n || !d.moverKind) return;
-  hipLaunchKernelGGL(k_advance_movers, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, dt);
+  hipLaunchKernelGGL(k_advance_movers, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, dt, trafficSmooth, trafficMult);
+}
+void launchTrafficTiers(const DeviceState& d, uint32_t n, const TierParams& tp, hipStream_t s)
+{
+  if (!n || !d.moverKind || !d.aMode) return;
+  hipLaunchKernelGGL(k_traffic_tiers, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, tp);
+}
+void launchApplyTiers(const DeviceState& d, uint32_t n, const uint2* patches, uint32_t patchCount, hipStream_t s)
+{
+  if (!n || !d.moverKind || !d.aMode) return;
+  hipLaunchKernelGGL(k_apply_tiers, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n);
+  if (patchCount) hipLaunchKernelGGL(k_patch_tiers, dim3((patchCount + kTile - 1) / kTile), dim3(kTile), 0, s, d, patches, patchCount);
 }
 void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, hipStream_t s)
 {

@@ -92,6 +92,13 @@ class SynthWorld:
     mover_vel: np.ndarray = None
     mover_lo: np.ndarray = None
     mover_hi: np.ndarray = None
+    # on-rails traffic agents (laned config 5): TrafficAgent + TrafficVehicle per entity and the lane graph they follow
+    is_agent: np.ndarray = None
+    agent_lane: np.ndarray = None
+    agent_s: np.ndarray = None
+    agent_speed: np.ndarray = None
+    agent_mode: np.ndarray = None
+    lane_graph: object = None
 
     @property
     def n(self):
@@ -202,10 +209,15 @@ LANE_OFFSET = 1.75                       # src/engine/traffic/sc_traffic_lanes.c
 PED_SCALE, PED_Y, PED_SPEED = (0.5, 1.8, 0.5), 0.9, 1.4
 
 
-def generate_config5(sectors_x, sectors_z, origin=(0, 0), seed=SEED, tiles=(1, 1)):
+def generate_config5(sectors_x, sectors_z, origin=(0, 0), seed=SEED, tiles=(1, 1), laned=False):
     """SynthWorld v1 config 5: per sector ground + 15 props (static, hierarchy as config 3)
     + 12 vehicles on the sector's four lanes + 4 peds = 32 entities; vehicles and peds are dynamic
-    (group 1 / mask all) roots that the mover kernel advances every tick."""
+    (group 1 / mask all) roots that the mover kernel advances every tick.
+
+    laned=False: vehicles are straight-line movers that wrap inside their sector (the round-1 stand-in).
+    laned=True: vehicles are the engine's own on-rails traffic agents (TrafficAgent on a lane of the procedural lane
+    graph, spawned as sc_traffic_spawner.cpp:267-318 does: pos = lane start + dir * laneS, targetSpeed 0, tier OnRails);
+    they follow their lane across sectors and park at the world's edge.  Peds keep the reflecting stand-in."""
     base = generate(sectors_x, sectors_z, 15, hierarchy=True, origin=origin, seed=seed, tiles=tiles)
     S = base.n // 16
     per_old, extra = 16, VEHICLES_PER_SECTOR + PEDS_PER_SECTOR
@@ -230,6 +242,14 @@ def generate_config5(sectors_x, sectors_z, origin=(0, 0), seed=SEED, tiles=(1, 1
     kind = np.zeros((S, per), np.uint8)
     vel = np.zeros((S, per, 2), np.float32)
     pad = np.float32(2.0)
+    graph = None
+    is_agent = agent_lane = agent_s = None
+    if laned:
+        from . import lanes as lanes_mod
+        graph = lanes_mod.build_procedural(cx, cz, float(size))
+        is_agent = np.zeros((S, per), np.uint8)
+        agent_lane = np.full((S, per), lanes_mod.INVALID_LANE, np.uint32)
+        agent_s = np.zeros((S, per), np.float32)
     lanes = [((1, 0), None, -LANE_OFFSET), ((-1, 0), None, LANE_OFFSET), ((0, 1), LANE_OFFSET, None), ((0, -1), -LANE_OFFSET, None)]
     for v in range(VEHICLES_PER_SECTOR):
         k = per_old + v
@@ -244,6 +264,15 @@ def generate_config5(sectors_x, sectors_z, origin=(0, 0), seed=SEED, tiles=(1, 1
         pos[:, k, 1] = np.float32(VEHICLE_Y)
         rot[:, k, 1] = np.float32(np.arctan2(np.float32(dx), np.float32(dz)))      # yaw = atan2(dir.x, dir.z), sc_traffic_ai.cpp:72-75
         scl[:, k] = np.float32(VEHICLE_SCALE)
+        if laned:
+            seg = graph.sector_segments[:, v % 4]
+            s_along = lerp(pad, size - pad, along)
+            p0 = (graph.seg_start[seg] + graph.seg_dir[seg] * s_along[:, None]).astype(np.float32)       # sc_traffic_spawner.cpp:272-274
+            pos[:, k, 0], pos[:, k, 2] = p0[:, 0], p0[:, 2]
+            is_agent[:, k] = 1
+            agent_lane[:, k] = seg
+            agent_s[:, k] = s_along
+            continue
         kind[:, k] = 1
         vel[:, k, 0], vel[:, k, 1] = np.float32(VEHICLE_SPEED * dx), np.float32(VEHICLE_SPEED * dz)
     for q in range(PEDS_PER_SECTOR):
@@ -272,6 +301,13 @@ def generate_config5(sectors_x, sectors_z, origin=(0, 0), seed=SEED, tiles=(1, 1
         sector_of=np.repeat(np.stack([cx, cz], axis=1), per, axis=0).astype(np.int32),
         origin=tuple(origin), sectors=(sectors_x, sectors_z),
         mover_kind=kind.reshape(N), mover_vel=vel.reshape(N, 2), mover_lo=lo, mover_hi=(lo + size).astype(np.float32))
+    if laned:
+        w.is_agent = is_agent.reshape(N)
+        w.agent_lane = agent_lane.reshape(N)
+        w.agent_s = agent_s.reshape(N)
+        w.agent_speed = np.zeros(N, np.float32)                                  # sc_traffic_spawner.cpp:318
+        w.agent_mode = np.full(N, 2, np.uint8)                                   # TrafficSimMode::OnRails, sc_traffic_common.h:42
+        w.lane_graph = graph
     w.camera = default_camera(w.world_side)
     return w
 

@@ -121,6 +121,9 @@ class WorldTick:
         self.set_topology(w.parent)
         if getattr(w, "mover_kind", None) is not None:
             self.upload_movers(0, w.mover_kind, w.mover_vel, w.mover_lo, w.mover_hi)
+        if getattr(w, "is_agent", None) is not None:
+            self.set_lane_graph(w.lane_graph)
+            self.upload_traffic_agents(0, w.is_agent, w.agent_lane, w.agent_s, w.agent_speed, w.agent_mode)
 
     def set_count(self, n):
         self._ok(self.lib.scTickSetEntityCount(self.ctx, n), "scTickSetEntityCount")
@@ -274,6 +277,49 @@ class WorldTick:
 
     def advance_movers(self, dt):
         self._ok(self.lib.scTickAdvanceMovers(self.ctx, float(dt)), "scTickAdvanceMovers")
+
+    # ---- on-rails traffic ----
+    def set_lane_graph(self, g):
+        """g: lanes.LaneGraph (or anything with the same arrays)"""
+        a = {k: np.ascontiguousarray(getattr(g, k), dt) for k, dt in (
+            ("seg_start", np.float32), ("seg_dir", np.float32), ("seg_length", np.float32), ("seg_active", np.uint8),
+            ("seg_end_node", np.uint32), ("seg_speed_limit", np.float32), ("node_pos", np.float32),
+            ("node_conn_offset", np.uint32), ("node_conn", np.uint32))}
+        lg = capi.LaneGraph()
+        lg.segments, lg.nodes, lg.connections = len(a["seg_length"]), len(a["node_pos"]), len(a["node_conn"])
+        lg.seg_start3, lg.seg_dir3, lg.seg_length = _f(a["seg_start"]), _f(a["seg_dir"]), _f(a["seg_length"])
+        lg.seg_active = a["seg_active"].ctypes.data_as(capi.U8P)
+        lg.seg_end_node, lg.seg_speed_limit = _u(a["seg_end_node"]), _f(a["seg_speed_limit"])
+        lg.node_pos3, lg.node_conn_offset, lg.node_conn = _f(a["node_pos"]), _u(a["node_conn_offset"]), _u(a["node_conn"])
+        self._ok(self.lib.scTickSetLaneGraph(self.ctx, C.byref(lg)), "scTickSetLaneGraph")
+
+    def set_lane_active(self, segment_ids, active):
+        ids = np.ascontiguousarray(segment_ids, np.uint32)
+        self._ok(self.lib.scTickSetLaneActive(self.ctx, _u(ids), len(ids), 1 if active else 0), "scTickSetLaneActive")
+
+    def upload_traffic_agents(self, first, is_agent, lane_id, lane_s, target_speed, mode, look_ahead=None):
+        ia, md = np.ascontiguousarray(is_agent, np.uint8), np.ascontiguousarray(mode, np.uint8)
+        ln, ls, sp = np.ascontiguousarray(lane_id, np.uint32), _c32(lane_s), _c32(target_speed)
+        la = None if look_ahead is None else _c32(look_ahead)
+        self._ok(self.lib.scTickUploadTrafficAgents(self.ctx, first, len(ia), ia.ctypes.data_as(capi.U8P), _u(ln), _f(ls), _f(sp),
+                                                    md.ctypes.data_as(capi.U8P), None if la is None else _f(la)), "scTickUploadTrafficAgents")
+
+    def traffic_agents(self):
+        """(lane_id, lane_s, target_speed, mode) of every entity (meaningful where the entity is an agent)"""
+        ln, ls, sp, md = np.zeros(self.n, np.uint32), np.zeros(self.n, np.float32), np.zeros(self.n, np.float32), np.zeros(self.n, np.uint8)
+        self._ok(self.lib.scTickReadTrafficAgents(self.ctx, 0, self.n, _u(ln), _f(ls), _f(sp), md.ctypes.data_as(capi.U8P)), "scTickReadTrafficAgents")
+        return ln, ls, sp, md
+
+    def set_traffic_speed_multiplier(self, m):
+        self._ok(self.lib.scTickSetTrafficSpeedMultiplier(self.ctx, float(m)), "scTickSetTrafficSpeedMultiplier")
+
+    def select_traffic_tiers(self, player_pos, a_enter=50.0, a_exit=70.0, b_enter=110.0, b_exit=150.0, max_physics=24, max_kinematic=64):
+        """TrafficLODSystem's tier selection; returns (physics, kinematic, on_rails) counts after the caps"""
+        pp = _c32(player_pos)
+        tp = capi.TierParams(a_enter, a_exit, b_enter, b_exit, max_physics, max_kinematic)
+        out = capi.TierCounts()
+        self._ok(self.lib.scTickSelectTrafficTiers(self.ctx, _f(pp), C.byref(tp), C.byref(out)), "scTickSelectTrafficTiers")
+        return out.physics, out.kinematic, out.on_rails
 
     def set_frame_producer(self, kind, param=0.0):
         """0 none, 1 nudge roots by `param`, 2 advance movers by dt=`param`: run() then is the whole frame"""

@@ -1,0 +1,166 @@
+"""The engine's own upstream mover on the device: on-rails traffic agents following the lane graph
+(sc_traffic_ai.cpp:434-460, sc_traffic_lanes.cpp:291-352) and TrafficLODSystem's tier selection (sc_traffic_lod.cpp:323-417),
+against the oracle's restatement on a laned config-5 world.  Lane state and positions are compared as bit patterns, world
+matrices with IEEE equality (an agent's yaw only takes per-segment values whose sin / cos come from the host libm, so the
+device matches without a trigonometric function of its own), visible lists element for element."""
+import numpy as np
+import pytest
+
+from sc_gameengine_amd import capi, lanes, synth_world as sw
+from sc_gameengine_amd.tick import WorldTick, camera_view_proj
+from tests import worlds
+
+pytestmark = pytest.mark.gpu
+DT = 1.0 / 60.0
+
+
+def laned_world(sx=24, sz=16, seed=3):
+    w = sw.generate_config5(sx, sz, laned=True)
+    rng = np.random.default_rng(seed)
+    agents = np.flatnonzero(w.is_agent)
+    # a few agents close to the end of their lane at the world's edge (they park on the dead end within the run), a few
+    # already rolling, a few in the Physics / Kinematic tiers (not moved here)
+    g = w.lane_graph
+    pick = rng.choice(agents, 200, replace=False)
+    w.agent_s[pick] = (g.seg_length[w.agent_lane[pick]] - rng.uniform(0.05, 3.0, 200)).astype(np.float32)
+    p0 = (g.seg_start[w.agent_lane[pick]] + g.seg_dir[w.agent_lane[pick]] * w.agent_s[pick][:, None]).astype(np.float32)
+    w.pos[pick, 0], w.pos[pick, 2] = p0[:, 0], p0[:, 2]
+    fast = rng.choice(agents, 300, replace=False)
+    w.agent_speed[fast] = rng.uniform(3.0, 20.0, 300).astype(np.float32)
+    other = rng.choice(agents, 100, replace=False)
+    w.agent_mode[other] = rng.integers(0, 2, 100).astype(np.uint8)
+    return w
+
+
+def oracle_side(oracle, w):
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    ol = oracle.OracleLanes()
+    ol.build_sectors(w.sector_of[::32, 0], w.sector_of[::32, 1])
+    state = dict(lane=w.agent_lane.copy(), s=w.agent_s.copy(), speed=w.agent_speed.copy(), mode=w.agent_mode.copy(),
+                 look=np.full(w.n, 12.0, np.float32), vel=w.mover_vel.copy())
+    return ow, ol, state
+
+
+def oracle_advance(ow, ol, w, st, dt, mult=1.0):
+    ow.traffic_ai_onrails(ol, w.is_agent, st["lane"], st["s"], st["speed"], st["mode"], st["look"], dt, mult)
+    ow.advance_movers(w.mover_kind, st["vel"], w.mover_lo, w.mover_hi, dt)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def assert_agents_equal(t, w, st, ow):
+    ln, ls, sp, md = t.traffic_agents()
+    a = w.is_agent.astype(bool)
+    assert np.array_equal(ln[a], st["lane"][a])
+    assert np.array_equal(bits(ls[a]), bits(st["s"][a])) and np.array_equal(bits(sp[a]), bits(st["speed"][a]))
+    assert np.array_equal(md[a], st["mode"][a])
+    assert np.array_equal(bits(t.positions()), bits(ow.local_positions()[:w.n]))
+
+
+def test_on_rails_agents_follow_their_lanes_60_ticks(oracle):
+    w = laned_world()
+    ow, ol, st = oracle_side(oracle, w)
+    vp = camera_view_proj(w.camera)
+    t = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 19)
+    t.set_view_proj(vp)
+    start = w.pos.copy()
+    for k in range(60):
+        oracle_advance(ow, ol, w, st, DT)
+        t.advance_movers(DT)
+        ow.transform_system(); ow.culling_system(view_proj=vp)
+        t.run(capi.FULL)
+        if k % 6 == 5 or k < 3:
+            assert_agents_equal(t, w, st, ow)
+            assert np.array_equal(t.world_matrices(), ow.world_matrices()[:w.n]), f"tick {k}: world matrices differ"
+            assert np.array_equal(t.visible(), ow.visible()), f"tick {k}: visible list differs"
+            assert not t.dirty().any()
+    a = w.is_agent.astype(bool) & (st["mode"] == 2)
+    moved = np.abs(ow.local_positions()[:w.n] - start).max(axis=1)
+    assert (moved[a] > 0).mean() > 0.95 and moved[a].max() > 6.0          # speeds approach 12 m/s: ~7 m in a second
+    assert (moved[w.is_agent.astype(bool) & (st["mode"] != 2)] == 0).all()  # Physics / Kinematic agents are not the mover's
+    g = w.lane_graph
+    crossed = (st["lane"][a] != w.agent_lane[a]).sum()
+    parked = (st["s"][a] == g.seg_length[st["lane"][a]]).sum()
+    assert crossed > 100 and parked > 5                                    # lanes were crossed and dead ends reached
+    # yaw only takes the segments' values
+    yaw = ow.local_rotations()[:w.n][a, 1]
+    allowed = np.float32([0.0, np.arctan2(np.float32(1), np.float32(0)), np.arctan2(np.float32(-1), np.float32(0)), np.arctan2(np.float32(0), np.float32(-1))])
+    assert np.isin(yaw, allowed).all() and len(np.unique(yaw)) == 4
+    t.close(); ow.close(); ol.close()
+
+
+def test_traffic_as_fused_frame_producer_and_graph_replay(oracle):
+    w = laned_world(16, 16, seed=5)
+    ow, ol, st = oracle_side(oracle, w)
+    vp = camera_view_proj(w.camera)
+    for graph in (False, True):
+        ow2, ol2, st2 = oracle_side(oracle, w)
+        t = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 19)
+        t.set_view_proj(vp)
+        t.set_frame_producer(2, DT)
+        t.set_graph_mode(graph)
+        t.advance_movers(DT)                                 # the first frame's producer, explicitly
+        for k in range(12):
+            oracle_advance(ow2, ol2, w, st2, DT)
+            ow2.transform_system(); ow2.culling_system(view_proj=vp)
+            t.run(capi.FULL | capi.PRODUCE_NEXT)             # tick, then the NEXT frame's producer inside the end-of-tick kernel
+            assert np.array_equal(t.world_matrices(), ow2.world_matrices()[:w.n]), f"graph={graph} tick {k}"
+            assert np.array_equal(t.visible(), ow2.visible())
+        oracle_advance(ow2, ol2, w, st2, DT)                 # the device is one producer step ahead
+        assert_agents_equal(t, w, st2, ow2)
+        t.close(); ow2.close(); ol2.close()
+    ow.close(); ol.close()
+
+
+def test_inactive_lanes_speed_multiplier_and_invalid_lane(oracle):
+    w = laned_world(12, 12, seed=7)
+    agents = np.flatnonzero(w.is_agent)
+    w.agent_lane[agents[:20]] = lanes.INVALID_LANE           # getLane() == nullptr: the agent is skipped
+    ow, ol, st = oracle_side(oracle, w)
+    t = WorldTick.from_world(w, broadphase=False)
+    off = np.arange(40, 120, dtype=np.uint32)                # removeSector: these segments go inactive
+    for s in off:
+        ol.set_active(int(s), False)
+    t.set_lane_active(off, False)
+    t.set_traffic_speed_multiplier(1.7)
+    for k in range(30):
+        oracle_advance(ow, ol, w, st, DT, mult=1.7)
+        t.advance_movers(DT)
+        if k == 14:                                          # ... and back (buildProceduralForSector re-activates, :164-171)
+            for s in off[:40]:
+                ol.set_active(int(s), True)
+            t.set_lane_active(off[:40], True)
+    ow.transform_system()
+    t.run(capi.XFORM)
+    assert_agents_equal(t, w, st, ow)
+    assert np.array_equal(t.world_matrices(), ow.world_matrices()[:w.n])
+    a = w.is_agent.astype(bool)
+    assert st["speed"][a].max() > 12.0                       # the multiplier raised the target speed above the limit
+    t.close(); ow.close(); ol.close()
+
+
+def test_tier_selection_hysteresis_and_caps(oracle):
+    w = laned_world(16, 16, seed=9)
+    ow, ol, st = oracle_side(oracle, w)
+    t = WorldTick.from_world(w, broadphase=False)
+    a = w.is_agent.astype(bool)
+    player = np.float32([500.0, 0.0, 510.0])
+    for rnd, (caps, pl) in enumerate([((24, 64), player), ((24, 64), player + np.float32([30, 0, 10])), ((0, 0), player), ((5, 0), player), ((3, 7), player - np.float32([80, 0, 40]))]):
+        want, counts = ow.traffic_lod_tiers(w.is_agent, st["mode"], pl, max_physics=caps[0], max_kinematic=caps[1])
+        got_counts = t.select_traffic_tiers(pl, max_physics=caps[0], max_kinematic=caps[1])
+        st["mode"][a] = want[a]                              # applyMode: the desired tier becomes the vehicle's mode
+        md = t.traffic_agents()[3]
+        assert np.array_equal(md[a], want[a]), f"round {rnd}"
+        assert got_counts == counts and sum(counts) == int(a.sum())
+        assert counts[0] > 0 and counts[1] > 0 and counts[2] > 0
+        if caps[0]:
+            assert counts[0] <= caps[0]
+        if caps[1]:
+            assert counts[1] <= caps[1]
+        # agents promoted out of the OnRails tier stop being moved by the mover; the rest go on
+        oracle_advance(ow, ol, w, st, DT)
+        t.advance_movers(DT)
+        assert_agents_equal(t, w, st, ow)
+    t.close(); ow.close(); ol.close()
