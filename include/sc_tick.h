@@ -89,11 +89,12 @@ typedef struct ScTickCounts    /* CullingStats (sc_world_partition.h:334-339) + 
   uint32_t draws_dropped;
   uint32_t max_depth;          /* deepest hierarchy level after scTickSetTopology */
   uint32_t unreachable;        /* entities in or below a parent cycle (never updated, sc_ecs.cpp:173-210) */
-  uint32_t bin_overflow;       /* broadphase boxes that found a sector bin full (they take the big list) */
-  uint32_t big_boxes;          /* boxes in the big list: larger than 2x2 sectors, outside the tile rectangle, or bin full */
+  uint32_t bin_overflow;       /* bin records that found their sector's bin (64 records) full: they sit in the sector overflow list */
+  uint32_t big_boxes;          /* boxes in the big list: larger than 2x2 sectors or outside the tile rectangle */
   uint32_t draws_sorted;       /* with SC_TICK_SORT_DRAWS: draws left after the renderer's mesh / material handle checks */
-  uint32_t border_lost;        /* tiled world: border messages that ran out of room + big boxes reaching beyond the eight
-                                  neighbouring tiles; non-zero means pairs across tile borders may be missing */
+  uint32_t border_lost;        /* records the fixed capacities could not carry: border messages that ran out of room, a ring sector
+                                  with more than 64 boxes, big boxes reaching beyond the eight neighbouring tiles, a sector with more
+                                  than 64 + 1024 boxes; non-zero means pairs may be missing */
   uint32_t relinks;            /* whole-world hierarchy re-links (O(entities) on the host) this context has done so far */
 } ScTickCounts;
 
@@ -176,8 +177,8 @@ int scTickNudgeRootsX(ScTickContext* ctx, float dx);
  * (1,0) (-1,1) (0,1) (1,1).  Pair ids are rank << 24 | dense index. */
 int scTickSetTile(ScTickContext* ctx, uint32_t rank, uint32_t neighbour_mask);
 /* This tile's place (tile_x, tile_z) in the grid of tiles_x x tiles_z equal tiles; sets the neighbour mask from it.
- * With the grid known the border messages also carry the big boxes (wider than 2x2 sectors, outside the tile's
- * rectangle, or pushed out of a full bin) that reach a neighbour's region, so pairs with them are found across tile
+ * With the grid known the border messages also carry the big boxes (wider than 2x2 sectors or outside the tile's
+ * rectangle) that reach a neighbour's region, so pairs with them are found across tile
  * borders too: a tile reports a box-vs-big pair when it owns the sector of the box's primary copy, and a big-vs-big
  * pair when it owns the sector holding the low corner of the intersection (sectors outside the world belong to the
  * nearest tile).  A big box may reach its own tile and the eight around it; one that reaches further, or a message

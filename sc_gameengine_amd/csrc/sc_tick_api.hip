@@ -88,7 +88,6 @@ struct ScTickContext
   uint2* dPairsOut = nullptr;          // gathered (contiguous) pair list for read-back
   uint32_t* dPairTotal = nullptr;      // [0] pairs found, [1] truncated flag
   uint32_t parity = 0, lastParity = 0;
-  uint32_t prevBroadphaseN = 0;        // entity count of the previous broadphase tick: bounds the bigBits words it may have set
   uint32_t rank = 0, neighbourMask = 0;
   uint32_t tileX = 0, tileZ = 0, tilesX = 0, tilesZ = 0;
   uint32_t producerKind = 0; float producerParam = 0.0f;      // part of the frame when set (scTickSetFrameProducer)
@@ -102,7 +101,8 @@ struct ScTickContext
   // kernel of tick t+1; everything the two halves share is double-buffered by tick parity (set 0 lives in `d`)
   hipStream_t pairsStream = nullptr;
   struct AltSet { uint32_t* binCount = nullptr; uint32_t* binLayers = nullptr; float4* bins = nullptr; float4* bigList = nullptr;
-                  float4* spill = nullptr; uint32_t* spillSector = nullptr; uint32_t* borderSend[8] = {}; uint32_t* borderRecv[8] = {}; };
+                  float4* spill = nullptr; uint32_t* spillSector = nullptr; uint32_t* ovfLo = nullptr; uint32_t* ovfHi = nullptr;
+                  uint32_t* borderSend[8] = {}; uint32_t* borderRecv[8] = {}; };
   AltSet alt[kMaxParity - 1];          // parity q > 0 works on alt[q - 1]
   uint32_t pipeDepth = 3;              // copies a pipelined tile rotates through (scTickSetPipelined)
   hipEvent_t packed[kMaxParity] = {}, pairsDone[kMaxParity] = {};
@@ -210,7 +210,7 @@ DeviceState stateFor(const ScTickContext* c, uint32_t q)
   if (c->pairsStream && q >= 1u && q < kMaxParity) {
     const ScTickContext::AltSet& a = c->alt[q - 1u];
     s.binCount = a.binCount; s.binLayers = a.binLayers; s.bins = a.bins; s.bigList = a.bigList;
-    s.spill = a.spill; s.spillSector = a.spillSector;
+    s.spill = a.spill; s.spillSector = a.spillSector; s.ovfLo = a.ovfLo; s.ovfHi = a.ovfHi;
     for (int k = 0; k < 8; ++k) { s.borderSend[k] = a.borderSend[k]; s.borderRecv[k] = a.borderRecv[k]; }
   }
   return s;
@@ -399,7 +399,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.neighbourMask = c->neighbourMask;
   p.variant = c->variant;
   p.chain = std::min(c->maxDepth, kMaxChain);
-  p.bigClearWords = ((c->pairsStream ? c->n : c->prevBroadphaseN) + 31u) >> 5;      // pipelined: a pair kernel clears its own parity
+  p.ovfCap = c->cap;
   if (c->pairsStream && (flags & SC_TICK_BROADPHASE)) p.flags |= kFlagDeferredReset;
   if (flags & SC_TICK_PRODUCE_NEXT) { p.producerKind = c->producerKind; p.producerParam = c->producerParam; }
   p.trafficSmooth = 1.0f - std::exp(-2.5f * c->producerParam);       // smoothExp(current, target, 2.5f, dt), sc_traffic_ai.cpp:58-62, :437
@@ -561,11 +561,12 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
   if (ok && c->sectors) {
     if ((uint64_t)desc->tile_sectors_x * desc->tile_sectors_z > (1u << 24)) ok = fail(c, "tile rectangle too large");
     ok = ok && dalloc(c, d.binCount, c->sectors) && dalloc(c, d.binLayers, c->sectors) && dalloc(c, d.bins, (size_t)c->sectors * kBinCap * 2u, false)
-            && dalloc(c, d.bigList, (N + 8u * kBorderBigCap) * 2u, false) && dalloc(c, d.spill, 2u * kSpillCap, false) && dalloc(c, d.spillSector, kSpillCap)
-            && dalloc(c, d.bigBits[0], N / 32) && dalloc(c, d.bigBits[1], N / 32)
+            && dalloc(c, d.bigList, (N + 8u * kBorderBigCap) * 2u, false) && dalloc(c, d.spill, 2u * N, false) && dalloc(c, d.spillSector, N)
+            && dalloc(c, d.ovfIdx, (size_t)kOvfWaves * kOvfPerSector, false) && dalloc(c, d.ovfLo, c->sectors, false) && dalloc(c, d.ovfHi, c->sectors)
             && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, (kMaxParity + 1u) * kPairShards * kShardStride)
             && dalloc(c, c->dPairsOut, c->maxPairs, false) && dalloc(c, c->dPairTotal, 4);
   }
+  if (ok && c->sectors) { e = hipMemset(d.ovfLo, 0xFF, (size_t)c->sectors * sizeof(uint32_t)); if (e != hipSuccess) ok = fail(c, "hipMemset", e); }
   if (ok) { void* p = nullptr; e = hipMalloc(&p, N * sizeof(ScTickDrawItem)); if (e != hipSuccess) ok = fail(c, "hipMalloc draws", e); else { c->allocs.push_back(p); c->dDraws = p; } }
   if (ok) {
     // Transform{}: worldMatrix = identity, scale = 1, cos = 1 (sc_ecs.h:63-71)
@@ -1087,7 +1088,6 @@ int scTickRun(ScTickContext* c, uint32_t flags)
     enqueueStages(c, p, grid, true);
   }
   if (flags & SC_TICK_BROADPHASE) {
-    c->prevBroadphaseN = c->n;
     if (flags & SC_TICK_SPLIT_PAIRS) { c->pairsPending = true; c->pendingParams = p; }
     else { c->lastParity = c->parity; c->parity ^= 1u; }           // (in-order flows alternate between two copies)
   }
@@ -1109,7 +1109,7 @@ int scTickRunPairs(ScTickContext* c)
   if (c->pendingParams.flags & SC_TICK_RAYS) launchRayQueries(ds, c->pendingParams, c->rays, ps);   // sees the neighbours' border boxes too
   if (c->pairsStream) {
     launchPairs(ds, c->pendingParams, ps);
-    launchSnapshotReset(ds, q, c->pendingParams.bigClearWords, ps);
+    launchSnapshotReset(ds, q, ps);
     HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
     c->pairsInFlight[q] = true;
   } else {
@@ -1184,18 +1184,20 @@ int scTickSetPairsStream(ScTickContext* c, void* stream)
   // here (synchronised above): start both parities from a clean slate.
   auto resetBroadphaseState = [&]() -> bool {
     if (!c->sectors) return true;
-    const size_t N = c->cap;
     hipError_t e = hipMemsetAsync(c->d.counters + kCtrPar, 0, (kCounterWords - kCtrPar) * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d.pairShardCount, 0, (kMaxParity + 1u) * kPairShards * kShardStride * sizeof(uint32_t), c->stream);
-    for (uint32_t q = 0; q < kMaxParity && e == hipSuccess; ++q) if (c->d.bigBits[q]) e = hipMemsetAsync(c->d.bigBits[q], 0, N / 32 * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d.binCount, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d.binLayers, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d.ovfLo, 0xFF, (size_t)c->sectors * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d.ovfHi, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
     for (auto& a : c->alt) {
       if (e == hipSuccess && a.binCount) e = hipMemsetAsync(a.binCount, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
       if (e == hipSuccess && a.binLayers) e = hipMemsetAsync(a.binLayers, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
+      if (e == hipSuccess && a.ovfLo) e = hipMemsetAsync(a.ovfLo, 0xFF, (size_t)c->sectors * sizeof(uint32_t), c->stream);
+      if (e == hipSuccess && a.ovfHi) e = hipMemsetAsync(a.ovfHi, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream);
     }
     if (e != hipSuccess) return fail(c, "hipMemsetAsync (broadphase state)", e);
-    c->parity = 0; c->lastParity = 0; c->prevBroadphaseN = 0;
+    c->parity = 0; c->lastParity = 0;
     return sync(c);
   };
   if (!stream) {
@@ -1209,8 +1211,7 @@ int scTickSetPairsStream(ScTickContext* c, void* stream)
     const size_t N = c->cap;
     if (!a.bins && (!dalloc(c, a.binCount, c->sectors) || !dalloc(c, a.binLayers, c->sectors) ||
         !dalloc(c, a.bins, (size_t)c->sectors * kBinCap * 2u, false) || !dalloc(c, a.bigList, (N + 8u * kBorderBigCap) * 2u, false) ||
-        !dalloc(c, a.spill, 2u * kSpillCap, false) || !dalloc(c, a.spillSector, kSpillCap))) return 0;
-    if (!c->d.bigBits[q] && !dalloc(c, c->d.bigBits[q], N / 32)) return 0;
+        !dalloc(c, a.spill, 2u * N, false) || !dalloc(c, a.spillSector, N) || !dalloc(c, a.ovfLo, c->sectors, false) || !dalloc(c, a.ovfHi, c->sectors))) return 0;
     if (q > 1u && !a.borderSend[0] && !a.borderRecv[0])      // (buffers bound without a parity serve every copy)
       for (int k = 0; k < 8; ++k) { a.borderSend[k] = c->alt[0].borderSend[k]; a.borderRecv[k] = c->alt[0].borderRecv[k]; }
   }
@@ -1330,7 +1331,7 @@ int scTickGetCounts(ScTickContext* c, ScTickCounts* out)
     out->pairs = tot[0];
     out->pairs_truncated = tot[1];
   }
-  out->bin_overflow = bp[kCtrBinFull];
+  out->bin_overflow = bp[kCtrSpill];                 // length of the sector overflow list (own boxes + border records that landed in a full bin)
   out->big_boxes = (c->lastFlags & SC_TICK_SPLIT_PAIRS) ? bp[kCtrBigLocal] : bp[kCtrBig];
   out->border_lost = bp[kCtrBorderLost];
   out->draws_emitted = k[4];

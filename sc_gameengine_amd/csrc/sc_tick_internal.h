@@ -93,9 +93,13 @@ struct DeviceState {
   uint32_t* binLayers;         // OR of the records' (group | mask << 16) per bin: lets the pair kernel skip a bin unread
   float4* bins;                // [sector][kBinCap][2]: (min.xyz, layers) (max.xyz, id | primary<<31)
   float4* bigList;             // [cap][2] boxes that cannot be binned (too large, outside the rect, bin full)
-  float4* spill;               // [kSpillCap][2] border records whose landing bin was full ...
-  uint32_t* spillSector;       // ... and the sector each was meant for
-  uint32_t* bigBits[4];        // per-entity "is in the big list" bit, one buffer per tick parity (kMaxParity)
+  float4* spill;               // [ovfCap][2] sector OVERFLOW list: records that found their sector bin full -- this tile's own
+                               // (fused kernel) and the neighbours' border records (merge) alike ...
+  uint32_t* spillSector;       // ... and the sector each belongs to: the wave that searches that sector gathers them back
+  uint32_t* ovfLo;             // per sector: lowest overflow-list index tagged with it (0xFFFFFFFF: none) ...
+  uint32_t* ovfHi;             // ... and one past the highest: the slice a sector's wave has to sweep (entities of a sector sit
+                               // together in pool order, so its overflow records sit together in the list)
+  uint32_t* ovfIdx;            // [pair-role waves][kOvfPerSector] scratch: overflow-list indices of the sector a wave is working on
   uint2* pairs;                // (a, b) ids, a < b; id = rank << 24 | dense index; kPairShards segments of shardCap
   uint32_t* pairShardCount;    // [kMaxParity parities + snapshot][kPairShards] counters, one per 128-byte line (kShardStride words apart)
   // upstream movers (allocated on first scTickUploadMovers)
@@ -115,8 +119,8 @@ struct DeviceState {
 // boxes (8 words each).  L = sectors on that ring side.
 constexpr uint32_t kBorderHeader = 2;
 constexpr uint32_t kBorderRecsPerBin = 16;    // capacity = L * kBorderRecsPerBin records per message, at least one full bin
-constexpr uint32_t kSpillCap = 4096;          // received records that found their landing bin full (kept per sector, see pairsBody)
-constexpr uint32_t kSpillPerSector = 64;      // == kBinCap: the spilled records of a sector reuse the bin's LDS tile
+constexpr uint32_t kOvfPerSector = 1024;      // overflow records one sector can hold besides its bin (what lies beyond is counted, never silent)
+constexpr uint32_t kOvfWaves = 2048u * 4u;    // pair-role waves that can own an ovfIdx scratch row (the launcher's workgroup cap x 4)
 constexpr uint32_t kBorderBigCap = 128;       // big boxes (wider than 2x2 sectors, outside the rectangle, bin full) per message
 constexpr uint32_t kBorderBigWords = 2u + kBorderBigCap * 8u;
 constexpr float kBigReach = 2.0f;             // sectors around a tile's owned region within which it must know a big box
@@ -146,7 +150,7 @@ struct TickParams {
   // broadphase grid: sectors [binOx, binOx+binSX) x [binOz, binOz+binSZ), keyed like worldToSector
   float binOx, binOz, invSector;
   uint32_t binSX, binSZ;
-  uint32_t parity;          // tick parity: selects the counter set and bigBits buffer
+  uint32_t parity;          // tick parity: selects the counter set (and, through the context, the bins / lists)
   uint32_t maxPairs;
   uint32_t rankBits;        // rank << 24, OR-ed into every box id
   uint32_t neighbourMask;   // bit d set: a neighbour tile exists in direction d (its ring side is foreign)
@@ -156,7 +160,7 @@ struct TickParams {
   uint32_t producerKind; float producerParam;   // with SC_TICK_PRODUCE_NEXT: the frame producer fused into the end-of-tick kernel
   float trafficSmooth, trafficMult;             // movers: 1 - exp(-2.5 dt) (smoothExp, sc_traffic_ai.cpp:58-62; host libm) and dbg->speedMultiplier
   uint32_t bigCap;          // entries the big list can hold (capacity + room for the neighbours' boxes): every index into it is held below this
-  uint32_t bigClearWords;   // words of the other parity's bigBits the previous broadphase tick may have set (its entity count / 32)
+  uint32_t ovfCap;          // entries the sector overflow list can hold
   uint32_t pairRunLog2;     // pair role: a wave takes its sectors in runs of 2^pairRunLog2 consecutive ones (pairRunLog2())
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d
@@ -221,7 +225,7 @@ void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, h
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);
 void launchMoveEntities(const DeviceState& d, const uint32_t* src, const uint32_t* dst, uint32_t moves, hipStream_t s);
 void launchSetFrustum(const DeviceState& d, const Frustum6& fr, hipStream_t s);
-void launchSnapshotReset(const DeviceState& d, uint32_t q, uint32_t words, hipStream_t s);
+void launchSnapshotReset(const DeviceState& d, uint32_t q, hipStream_t s);
 void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s);
 void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s);
 void launchEmitDraws(const DeviceState& d, uint32_t budget, void* items, hipStream_t s);

@@ -193,8 +193,10 @@ __device__ __forceinline__ void worldAabb(const Aff& M, const BoundsCE& b, float
 // [floor(min*inv), floor(max*inv)] touches (worldToSector arithmetic, sc_world_partition.cpp:268-275)
 // when that is at most 2x2 sectors inside the grid rectangle; a pair is later reported only from
 // the sector holding the low corner of the two boxes' intersection, so every bin is self-contained:
-// no halo, no duplicate.  Anything else (larger, outside the rectangle, bin full) goes to the
-// "big" list, which the pair kernel tests against everything.
+// no halo, no duplicate.  A box that finds a sector's bin full goes to the sector OVERFLOW list, tagged with
+// that sector (the wave that searches the sector gathers its overflow back and treats it like the bin's
+// records); a box larger than 2x2 sectors or outside the rectangle goes to the "big" list, which the pair
+// kernel tests against everything.
 // ------------------------------------------------------------------------------------------
 struct BinPlan { bool collide, big; float x0, z0; uint32_t nx, nz; };
 
@@ -224,8 +226,8 @@ __device__ __forceinline__ void appendBig(const DeviceState& d, const TickParams
 
 // One insertion round for the whole wave (must be called by all 64 lanes).  Consecutive lanes that
 // target the same sector form a run; the run's first lane reserves the slots with ONE atomic.
-__device__ __forceinline__ void binInsertWave(const DeviceState& d, bool want, uint32_t sector,
-                                              const float4& rmin, const float4& rmax, bool& binFull)
+__device__ __forceinline__ void binInsertWave(const DeviceState& d, const TickParams& p, bool want, uint32_t sector,
+                                              const float4& rmin, const float4& rmax)
 {
   const unsigned long long act = __ballot(want);
   if (!act) return;
@@ -253,16 +255,27 @@ __device__ __forceinline__ void binInsertWave(const DeviceState& d, bool want, u
   uint32_t base = 0;
   if (head) { base = atomicAdd(&d.binCount[sector], runEnd - lane); atomicOr(&d.binLayers[sector], lay); }
   base = __shfl(base, myHead, 64);
-  if (want) {
-    const uint32_t slot = base + (lane - myHead);
-    if (slot < kBinCap) {
-      float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
-#ifdef SC_NT_BINS
-      storeStream16(r, rmin); storeStream16(r + 1, rmax);
-#else
-      r[0] = rmin; r[1] = rmax;
-#endif
-    } else binFull = true;
+  const uint32_t slot = base + (lane - myHead);
+  if (want && slot < kBinCap) {
+    float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
+    r[0] = rmin; r[1] = rmax;
+  }
+  // bin full: the record joins the sector overflow list (one reservation per wave)
+  const bool over = want && slot >= kBinCap;
+  const unsigned long long mo = __ballot(over);
+  if (mo) {
+    const uint32_t ctr = kCtrPar + 8u * p.parity;
+    const uint32_t first = (uint32_t)__ffsll((long long)mo) - 1u;
+    uint32_t at = 0;
+    if (lane == first) at = atomicAdd(&d.counters[ctr + kCtrSpill], (uint32_t)__popcll(mo));     // (every wave of the chip meets on this word: one atomic, not two)
+    at = __shfl(at, (int)first, 64) + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
+    if (over && at < p.ovfCap) {
+      d.spill[2u * (size_t)at] = rmin; d.spill[2u * (size_t)at + 1u] = rmax; d.spillSector[at] = sector;
+      // the overflowing lanes of a run are its tail and their list indices ascend with the lane: the first one lowers the
+      // sector's slice bound, the last one raises it (two atomics per run, not per record)
+      if (slot == kBinCap || lane == myHead) atomicMin(&d.ovfLo[sector], at);
+      if (lane + 1u == runEnd) atomicMax(&d.ovfHi[sector], at + 1u);
+    }
   }
 }
 
@@ -280,7 +293,6 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
     rmax = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i | p.rankBits));
   }
   const bool binned = plan.collide && !plan.big;
-  bool binFull = false;
   const uint32_t sx = (uint32_t)plan.x0, sz = (uint32_t)plan.z0;
 #pragma unroll
   for (uint32_t k = 0; k < 4; ++k) {
@@ -288,15 +300,9 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
     const bool want = binned && dx < plan.nx && dz < plan.nz;
     float4 rm = rmax;
     if (k == 0) rm.w = __uint_as_float(i | p.rankBits | kPrimary);   // exactly one primary copy per box
-    binInsertWave(d, want, (sz + dz) * p.binSX + (sx + dx), rmin, rm, binFull);
+    binInsertWave(d, p, want, (sz + dz) * p.binSX + (sx + dx), rmin, rm);
   }
   if (plan.collide && plan.big) appendBig(d, p, rmin, rmax);
-  if (binFull) {
-    // partially binned: flag it so the pair kernel ignores its copies, and hand it to the big list once
-    const uint32_t bit = 1u << (i & 31u);
-    const uint32_t old = atomicOr(&d.bigBits[p.parity][i >> 5], bit);
-    if (!(old & bit)) { appendBig(d, p, rmin, rmax); atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBinFull], 1u); }
-  }
 }
 
 // Same for a single lane (level kernels: entities of one level are scattered, no runs to aggregate).
@@ -309,7 +315,6 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
   float4 rmax = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i | p.rankBits));
   if (!plan.collide) return;
   if (plan.big) { appendBig(d, p, rmin, rmax); return; }
-  bool binFull = false;
   const uint32_t sx = (uint32_t)plan.x0, sz = (uint32_t)plan.z0;
   for (uint32_t k = 0; k < 4; ++k) {
     const uint32_t dx = k & 1u, dz = k >> 1;
@@ -317,16 +322,18 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
     const uint32_t sector = (sz + dz) * p.binSX + (sx + dx);
     const uint32_t slot = atomicAdd(&d.binCount[sector], 1u);
     atomicOr(&d.binLayers[sector], __float_as_uint(rmin.w));
+    float4 rm = rmax; if (k == 0) rm.w = __uint_as_float(i | p.rankBits | kPrimary);
     if (slot < kBinCap) {
       float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
-      float4 rm = rmax; if (k == 0) rm.w = __uint_as_float(i | p.rankBits | kPrimary);
       r[0] = rmin; r[1] = rm;
-    } else binFull = true;
-  }
-  if (binFull) {
-    const uint32_t bit = 1u << (i & 31u);
-    const uint32_t old = atomicOr(&d.bigBits[p.parity][i >> 5], bit);
-    if (!(old & bit)) { appendBig(d, p, rmin, rmax); atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBinFull], 1u); }
+    } else {
+      const uint32_t ctr = kCtrPar + 8u * p.parity;
+      const uint32_t at = atomicAdd(&d.counters[ctr + kCtrSpill], 1u);
+      if (at < p.ovfCap) {
+        d.spill[2u * (size_t)at] = rmin; d.spill[2u * (size_t)at + 1u] = rm; d.spillSector[at] = sector;
+        atomicMin(&d.ovfLo[sector], at); atomicMax(&d.ovfHi[sector], at + 1u);
+      }
+    }
   }
 }
 
@@ -812,22 +819,20 @@ __device__ __forceinline__ void sinkPush(const DeviceState& d, const TickParams&
   if (k.count > kWavePairBuf - 64u) sinkFlush(d, p, k);        // keep room for a full wave of hits
 }
 
-// The state of the OTHER tick parity -- counter set, pair shard counters, big-box bits -- back to zero.
+// The state of the OTHER tick parity -- counter set, pair shard counters -- back to zero.
 __device__ __forceinline__ void resetOtherParity(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks)
 {
   if (bid == 0 && threadIdx.x < 8) d.counters[kCtrPar + 8u * (p.parity ^ 1u) + threadIdx.x] = 0u;
   if (bid == 0 && threadIdx.x < kPairShards) d.pairShardCount[((p.parity ^ 1u) * kPairShards + threadIdx.x) * kShardStride] = 0u;
-  const uint32_t words = p.bigClearWords;      // what the previous tick (other parity) can have set: its entity count, not this one's
-  uint32_t* nextBits = d.bigBits[p.parity ^ 1u];
-  for (uint32_t w = bid * kTile + threadIdx.x; w < words; w += nblocks * kTile) nextBits[w] = 0u;
+  (void)nblocks;
 }
 
 // Pipelined tiles: queued on the pairs stream right behind the pair kernel of parity q.  Nobody else may clear this parity's
 // state -- the next fused kernel of the OTHER parity is already running, the next of THIS parity waits for this stream -- so
-// the results are copied to the snapshot slot the host reads (counter set kSnapSet, shard counter set kSnapSet) and counters, shard
-// counters and big-box bits are cleared here.  (Doing it in the pair kernel's last workgroup needs a ticket per workgroup:
+// the results are copied to the snapshot slot the host reads (counter set kSnapSet, shard counter set kSnapSet) and counters and
+// shard counters are cleared here.  (Doing it in the pair kernel's last workgroup needs a ticket per workgroup:
 // a thousand device-scope atomics on one word cost more than this launch.)
-__global__ __launch_bounds__(kTile) void k_snapshot_reset(const DeviceState d, uint32_t q, uint32_t words)
+__global__ __launch_bounds__(kTile) void k_snapshot_reset(const DeviceState d, uint32_t q)
 {
   const uint32_t ctr = kCtrPar + 8u * q;
   if (blockIdx.x == 0) {
@@ -837,7 +842,6 @@ __global__ __launch_bounds__(kTile) void k_snapshot_reset(const DeviceState d, u
     if (threadIdx.x < 8) { d.counters[kCtrPar + 8u * kSnapSet + threadIdx.x] = cv; d.counters[ctr + threadIdx.x] = 0u; }
     if (threadIdx.x < kPairShards) { d.pairShardCount[(kSnapSet * kPairShards + threadIdx.x) * kShardStride] = sv; d.pairShardCount[(q * kPairShards + threadIdx.x) * kShardStride] = 0u; }
   }
-  for (uint32_t w = blockIdx.x * kTile + threadIdx.x; w < words; w += gridDim.x * kTile) d.bigBits[q][w] = 0u;
 }
 
 // Does this tile own sector (gx, gz) of its bin grid (coordinates may lie outside the grid)?  A sector belongs to
@@ -875,8 +879,8 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   const uint32_t sectors = p.binSX * p.binSZ;
   const uint32_t ctr = kCtrPar + 8u * p.parity;
   const uint32_t nbig = min(d.counters[ctr + kCtrBig], p.bigCap);      // (bounded whatever the counter holds)
-  const uint32_t nspill = min(d.counters[ctr + kCtrSpill], kSpillCap);
-  const uint32_t* bigBits = d.bigBits[p.parity];
+  const uint32_t novf = min(d.counters[ctr + kCtrSpill], p.ovfCap);     // sector overflow list: own boxes and neighbours' border records
+  uint32_t* ovfIdx = d.ovfIdx + (size_t)(waveGlobal < kOvfWaves ? waveGlobal : kOvfWaves - 1u) * kOvfPerSector;   // (the launcher keeps waves below kOvfWaves)
   float4* T = tile[wave];
   PairSink sink = { pairBuf[wave], 0u, bid % kPairShards };
 
@@ -884,8 +888,8 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   for (uint32_t i = 1u + threadIdx.x / 64u * 16u; i < kBinCap && i < 17u + threadIdx.x / 64u * 16u; ++i)
     for (uint32_t j = lane; j < i; j += 64u) pairTab[i * (i - 1u) / 2u + j] = (uint16_t)(i << 8 | j);
 
-  // next tick's counter set and big bits start clean (pipelined tiles do this in the end-of-tick kernel instead:
-  // there the next tick's fused kernel may already be filling them while this pair search runs)
+  // next tick's counter set starts clean (pipelined tiles do this in a small kernel behind the pair kernel instead:
+  // there the next tick's fused kernel may already be filling it while this pair search runs)
   if (!(p.flags & kFlagDeferredReset)) resetOtherParity(d, p, bid, nblocks);
   __syncthreads();
 
@@ -906,16 +910,20 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       if (myCount) {
         d.binCount[mySector] = 0u; d.binLayers[mySector] = 0u;
         // no record of this bin can pass the group/mask filter against another one: nothing to read
-        if (nbig == 0u && ((lay & 0xFFFFu) & (lay >> 16)) == 0u) myCount = 0u;
+        if (nbig == 0u && ((lay & 0xFFFFu) & (lay >> 16)) == 0u) {
+          if (myCount > kBinCap) { d.ovfLo[mySector] = 0xFFFFFFFFu; d.ovfHi[mySector] = 0u; }     // (its overflow slice goes unread too)
+          myCount = 0u;
+        }
       }
     }
+    const uint32_t myTrue = myCount;                   // records the sector holds, bin and overflow list together
     if (myCount > kBinCap) myCount = kBinCap;
     const unsigned long long work = __ballot(myCount != 0u);
     if (!work) continue;
 
     // software pipeline: records of the next non-empty sector are in flight while this one is tested
     int it = __ffsll((long long)work) - 1;
-    uint32_t n = __shfl(myCount, it, 64);
+    uint32_t n = __shfl(myCount, it, 64), nTrue = __shfl(myTrue, it, 64);
     float4 rmin = make_float4(0, 0, 0, 0), rmax = make_float4(0, 0, 0, 0);
     uint32_t s = __shfl(mySector, it, 64);            // (cross-lane reads stay outside divergent code: every lane takes part)
     if (lane < n) {
@@ -925,12 +933,12 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     unsigned long long rest = work & ~(1ull << it);
     while (it >= 0) {
       const int itNext = rest ? __ffsll((long long)rest) - 1 : -1;
-      uint32_t nNext = 0;
+      uint32_t nNext = 0, nTrueNext = 0;
       float4 nmin = make_float4(0, 0, 0, 0), nmax = make_float4(0, 0, 0, 0);
       uint32_t sNext = 0;
       if (itNext >= 0) {
         rest &= ~(1ull << itNext);
-        nNext = __shfl(myCount, itNext, 64);
+        nNext = __shfl(myCount, itNext, 64); nTrueNext = __shfl(myTrue, itNext, 64);
         sNext = __shfl(mySector, itNext, 64);
         if (lane < nNext) {
           const float4* r = d.bins + 2u * ((size_t)sNext * kBinCap + lane);
@@ -939,17 +947,15 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       }
 
       bool valid = lane < n;
-      if (valid && nbig) {                                   // partially binned boxes live in the big list
-        const uint32_t id = __float_as_uint(rmax.w) & ~kPrimary;
-        if ((id & ~kParentMask) == p.rankBits && ((bigBits[(id & kParentMask) >> 5] >> (id & 31u)) & 1u)) valid = false;
-      }
       // a ring sector on a side where a neighbour tile exists belongs to that neighbour: it reports the
       // pairs whose low corner lies there (it received these boxes through the border exchange)
+      bool ours = true;
       {
         const uint32_t gx = s % p.binSX, gz = s / p.binSX;
         const int dx = gx == 0 ? -1 : (gx == p.binSX - 1u ? 1 : 0), dz = gz == 0 ? -1 : (gz == p.binSZ - 1u ? 1 : 0);
-        if ((dx != 0 && hasNb(p, dx, 0)) || (dz != 0 && hasNb(p, 0, dz))) valid = false;   // nearest tile is not this one
+        if ((dx != 0 && hasNb(p, dx, 0)) || (dz != 0 && hasNb(p, 0, dz))) ours = false;    // nearest tile is not this one
       }
+      valid = valid && ours;
       // Filter first (integer, cheap): like btDbvtBroadphase, which keeps static bodies in a separate set
       // and never tests fixed-vs-fixed, a record that cannot pass (a.group & b.mask) && (b.group & a.mask)
       // against ANY other record of this bin is dropped before the box tests, and a bin without a single
@@ -1036,51 +1042,84 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
           sinkPush(d, p, sink, hit, myId, __float_as_uint(gmax.w));
         }
       }
-      // Border records that found this (core-edge) bin full on arrival: they belong to this sector as much as the
-      // records in it, so each meets the bin's records and the other spilled records of the sector under the same
-      // rule (low corner of the intersection in this sector), and -- if it is its box's primary copy -- the big boxes.
-      if (nspill) {
-        const uint32_t gx = s % p.binSX, gz = s / p.binSX;
-        if (gx == 1u || gz == 1u || gx == p.binSX - 2u || gz == p.binSZ - 2u) {
-          float4* X = T;          // the bin's LDS tile is free again here (its records are in registers); kSpillPerSector == kBinCap
-          uint32_t m = 0;
-          for (uint32_t e0 = 0; e0 < nspill; e0 += 64u) {
-            const uint32_t e = e0 + lane;
-            const bool match = e < nspill && d.spillSector[e] == s;
+      // Sector overflow: records that found this sector's bin full -- this tile's own boxes and border records that
+      // arrived from a neighbour alike -- sit in the overflow list, tagged with the sector.  They belong to the sector as much
+      // as the records in the bin: each meets the bin's records and the sector's other overflow records under the same rule
+      // (low corner of the intersection in this sector), and -- if it is its box's primary copy -- the big boxes.
+      // The wave gathers the list indices of its sector in one sweep (scratch row in global memory), then walks them in
+      // tiles of 64: tile k in registers (one record per lane) against the bin and against tiles 0..k staged in LDS.
+      // Cost: one sweep of the list per overflowing sector + (records of the sector)^2 / 64 tests.
+      if (nTrue > kBinCap && novf) {
+        // the slice of the list that holds this sector's records; the wave that consumes a sector resets its slice
+        uint32_t eLo = d.ovfLo[s], eHi = d.ovfHi[s];
+        if (lane == 0) { d.ovfLo[s] = 0xFFFFFFFFu; d.ovfHi[s] = 0u; }
+        if (eHi > novf) eHi = novf;
+        if (!ours) eLo = eHi;                                     // a neighbour's ring sector: its pairs are the neighbour's
+        uint32_t m = 0;
+        for (uint32_t e0 = eLo; e0 < eHi; e0 += 256u) {           // four tags per lane in flight: the sweep is latency-bound
+          uint32_t tag[4];
+#pragma unroll
+          for (uint32_t u = 0; u < 4u; ++u) { const uint32_t e = e0 + u * 64u + lane; tag[u] = e < eHi ? d.spillSector[e] : 0xFFFFFFFFu; }
+#pragma unroll
+          for (uint32_t u = 0; u < 4u; ++u) {
+            const bool match = tag[u] == s;
             const unsigned long long mm = __ballot(match);
             if (match) {
               const uint32_t at = m + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-              if (at < kSpillPerSector) { X[2u * at] = d.spill[2u * e]; X[2u * at + 1u] = d.spill[2u * e + 1u]; }
+              if (at < kOvfPerSector) ovfIdx[at] = e0 + u * 64u + lane;
             }
             m += (uint32_t)__popcll(mm);
           }
-          if (m > kSpillPerSector) { if (lane == 0) atomicAdd(&d.counters[ctr + kCtrBorderLost], m - kSpillPerSector); m = kSpillPerSector; }
+        }
+        if (m > kOvfPerSector) { if (lane == 0) atomicAdd(&d.counters[ctr + kCtrBorderLost], m - kOvfPerSector); m = kOvfPerSector; }
+        __threadfence_block();                                  // the index row was written by other lanes of this wave
+        const uint32_t tiles = (m + 63u) / 64u;
+        for (uint32_t k = 0; k < tiles; ++k) {
+          const uint32_t q = k * 64u + lane;
+          const bool has = q < m;
+          float4 xmin = make_float4(0, 0, 0, 0), xmax = make_float4(0, 0, 0, 0);
+          if (has) { const uint32_t e = ovfIdx[q]; xmin = d.spill[2u * (size_t)e]; xmax = d.spill[2u * (size_t)e + 1u]; }
+          // against the bin's records (still in registers: stage them)
           __builtin_amdgcn_wave_barrier();
-          for (uint32_t k = 0; k < m; ++k) {
-            const float4 xmin = X[2u * k], xmax = X[2u * k + 1u];
+          T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
+          __builtin_amdgcn_wave_barrier();
+          for (uint32_t j = 0; j < n; ++j) {
+            // most boxes of a sector do not touch: the interval test alone decides, the rest only runs when some lane passes it
+            const float4 tmin = T[2u * j], tmax = T[2u * j + 1u];
+            if (!__ballot(has && boxesOverlap(xmin, xmax, tmin, tmax))) continue;
             uint32_t ia = 0, ib = 0;
-            bool hit = valid && pairHit(p, xmin, xmax, rmin, rmax, secX, secZ, ia, ib);            // against the bin's records
+            const bool hit = has && pairHit(p, xmin, xmax, tmin, tmax, secX, secZ, ia, ib);
             sinkPush(d, p, sink, hit, ia, ib);
-            hit = lane < k && pairHit(p, xmin, xmax, X[2u * lane], X[2u * lane + 1u], secX, secZ, ia, ib);   // against earlier spilled ones
-            sinkPush(d, p, sink, hit, ia, ib);
-            if (__float_as_uint(xmax.w) & kPrimary) {
-              const uint32_t xid = __float_as_uint(xmax.w) & ~kPrimary;
-              for (uint32_t b0 = 0; b0 < nbig; b0 += 64u) {
-                const uint32_t b = b0 + lane;
-                bool bh = false; uint32_t bid2 = 0;
-                if (b < nbig) {
-                  const float4 gmin = d.bigList[2u * (size_t)b], gmax = d.bigList[2u * (size_t)b + 1u];
-                  bid2 = __float_as_uint(gmax.w);
-                  bh = boxesOverlap(xmin, xmax, gmin, gmax) && filterPass(__float_as_uint(xmin.w), __float_as_uint(gmin.w));
-                }
-                sinkPush(d, p, sink, bh, xid, bid2);
-              }
+          }
+          // against the overflow tiles before this one, and against this one's earlier lanes
+          for (uint32_t jt = 0; jt <= k; ++jt) {
+            __builtin_amdgcn_wave_barrier();
+            if (jt == k) { T[2u * lane] = xmin; T[2u * lane + 1u] = xmax; }
+            else { const uint32_t e = ovfIdx[jt * 64u + lane]; T[2u * lane] = d.spill[2u * (size_t)e]; T[2u * lane + 1u] = d.spill[2u * (size_t)e + 1u]; }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t cnt = (m - jt * 64u) < 64u ? (m - jt * 64u) : 64u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+              const float4 tmin = T[2u * i], tmax = T[2u * i + 1u];
+              const bool cand = has && (jt < k || i < lane);
+              if (!__ballot(cand && boxesOverlap(xmin, xmax, tmin, tmax))) continue;
+              uint32_t ia = 0, ib = 0;
+              const bool hit = cand && pairHit(p, xmin, xmax, tmin, tmax, secX, secZ, ia, ib);
+              sinkPush(d, p, sink, hit, ia, ib);
+            }
+          }
+          if (nbig) {
+            const bool mine = has && (__float_as_uint(xmax.w) & kPrimary);
+            const uint32_t xid = __float_as_uint(xmax.w) & ~kPrimary;
+            for (uint32_t b2 = 0; b2 < nbig; ++b2) {
+              const float4 gmin = d.bigList[2u * (size_t)b2], gmax = d.bigList[2u * (size_t)b2 + 1u];
+              const bool hit = mine && boxesOverlap(xmin, xmax, gmin, gmax) && filterPass(__float_as_uint(xmin.w), __float_as_uint(gmin.w));
+              sinkPush(d, p, sink, hit, xid, __float_as_uint(gmax.w));
             }
           }
         }
       }
       __builtin_amdgcn_wave_barrier();
-      it = itNext; n = nNext; s = sNext; rmin = nmin; rmax = nmax;
+      it = itNext; n = nNext; nTrue = nTrueNext; s = sNext; rmin = nmin; rmax = nmax;
     }
   }
 
@@ -1213,28 +1252,23 @@ __device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickP
   uint32_t* msg = d.borderSend[dir];
   const uint32_t cap = borderRecCap(L);
   float4* records = reinterpret_cast<float4*>(msg + kBorderHeader + L);
-  const bool anyBig = d.counters[kCtrPar + 8u * p.parity + kCtrBig] != 0u;      // else no box was pushed out of a bin: no lookups
   // 2 * kTile ring bins at a time (one pass for a 256-sector side): a thread takes two neighbouring bins, finds their
   // offsets (parallel scan, carry across chunks) and copies their records.  Ring bins are sparse, and 512 bins in flight
   // hide the latency that a wave-per-bin walk would serialise (measured: 59 us against 14).
   auto copyBin = [&](uint32_t cell, uint32_t off, uint32_t take) {
     const float4* src = d.bins + 2u * ((size_t)cell * kBinCap);
     float4* dst = records + 2u * (size_t)off;
-    for (uint32_t r = 0; r < take; ++r) {
-      float4 lo = src[2u * r]; const float4 hi = src[2u * r + 1u];
-      // a box that found some bin full travels in the big section instead: its copies must not take part
-      // over there either (a zero layer word fails every group/mask filter)
-      const uint32_t id = __float_as_uint(hi.w) & ~kPrimary;
-      if (anyBig && (id & ~kParentMask) == p.rankBits && ((d.bigBits[p.parity][(id & kParentMask) >> 5] >> (id & 31u)) & 1u)) lo.w = 0.0f;
-      dst[2u * r] = lo; dst[2u * r + 1u] = hi;
-    }
+    for (uint32_t r = 0; r < take; ++r) { dst[2u * r] = src[2u * r]; dst[2u * r + 1u] = src[2u * r + 1u]; }
   };
   uint32_t carry = 0;
   for (uint32_t base = 0; base < L; base += 2u * kTile) {
     const uint32_t l0 = base + 2u * threadIdx.x, l1 = l0 + 1u;
     uint32_t c0 = 0, c1 = 0, cell0 = 0, cell1 = 0;
-    if (l0 < L) { bool send = false; cell0 = ringCell(p, dx, dz, l0, &send); if (send) { c0 = d.binCount[cell0]; if (c0 > kBinCap) c0 = kBinCap; } }
-    if (l1 < L) { bool send = false; cell1 = ringCell(p, dx, dz, l1, &send); if (send) { c1 = d.binCount[cell1]; if (c1 > kBinCap) c1 = kBinCap; } }
+    // (a ring sector carries at most one bin's worth of boxes across the border: what overflowed there is counted as lost)
+    uint32_t over = 0;
+    if (l0 < L) { bool send = false; cell0 = ringCell(p, dx, dz, l0, &send); if (send) { c0 = d.binCount[cell0]; if (c0 > kBinCap) { over += c0 - kBinCap; c0 = kBinCap; } } }
+    if (l1 < L) { bool send = false; cell1 = ringCell(p, dx, dz, l1, &send); if (send) { c1 = d.binCount[cell1]; if (c1 > kBinCap) { over += c1 - kBinCap; c1 = kBinCap; } } }
+    if (over) atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBorderLost], over);
     uint32_t total;
     const uint32_t off0 = blockScanExclusive(c0 + c1, carry, sWave, &total), off1 = off0 + c0;
     const uint32_t take0 = (off0 + c0 <= cap) ? c0 : (off0 < cap ? cap - off0 : 0u);
@@ -1332,10 +1366,12 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
         float4* dst = d.bins + 2u * ((size_t)sector * kBinCap + slot0 + r);
         dst[0] = lo; dst[1] = hi;
       } else {
-        // the landing bin is full: keep the record on the side, tagged with its sector; the pair search adds it back
+        // the landing bin is full: the record joins the sector overflow list; the pair search gathers it back
         const uint32_t q = atomicAdd(&d.counters[ctr + kCtrSpill], 1u);
-        if (q < kSpillCap) { d.spill[2u * q] = lo; d.spill[2u * q + 1u] = hi; d.spillSector[q] = sector; }
-        else atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);
+        if (q < p.ovfCap) {
+          d.spill[2u * (size_t)q] = lo; d.spill[2u * (size_t)q + 1u] = hi; d.spillSector[q] = sector;
+          atomicMin(&d.ovfLo[sector], q); atomicMax(&d.ovfHi[sector], q + 1u);
+        } else atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);
       }
     }
     if (lay) atomicOr(&d.binLayers[sector], lay);
@@ -1620,7 +1656,7 @@ static uint32_t pairGridFor(const TickParams& p)
 {
   const uint32_t sectors = p.binSX * p.binSZ;
   const uint32_t runs = (sectors + (1u << p.pairRunLog2) - 1u) >> p.pairRunLog2;
-  const uint32_t capWaves = ((p.variant >> 8) ? (p.variant >> 8) : 2048u) * (kTile / 64u);
+  const uint32_t capWaves = std::min(((p.variant >> 8) ? (p.variant >> 8) : 2048u) * (kTile / 64u), kOvfWaves);
   const uint32_t rounds = (runs + capWaves - 1u) / capWaves;
   const uint32_t waves = (runs + rounds - 1u) / rounds;
   return std::max(1u, (waves + kTile / 64u - 1u) / (kTile / 64u));
@@ -1706,10 +1742,9 @@ void launchSetFrustum(const DeviceState& d, const Frustum6& fr, hipStream_t s)
 {
   hipLaunchKernelGGL(k_set_frustum, dim3(1), dim3(64), 0, s, const_cast<float*>(d.frustum), fr);
 }
-void launchSnapshotReset(const DeviceState& d, uint32_t q, uint32_t words, hipStream_t s)
+void launchSnapshotReset(const DeviceState& d, uint32_t q, hipStream_t s)
 {
-  const uint32_t blocks = std::max(1u, std::min((words + kTile - 1) / kTile, 32u));
-  hipLaunchKernelGGL(k_snapshot_reset, dim3(blocks), dim3(kTile), 0, s, d, q, words);
+  hipLaunchKernelGGL(k_snapshot_reset, dim3(1), dim3(kTile), 0, s, d, q);
 }
 void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s)
 {

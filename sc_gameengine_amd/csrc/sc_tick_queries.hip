@@ -103,10 +103,10 @@ __global__ __launch_bounds__(kTile) void k_ray_queries(const DeviceState d, cons
   }
   const uint32_t nbig = min(d.counters[kCtrPar + 8u * p.parity + kCtrBig], p.bigCap);
   for (uint32_t b = lane; b < nbig; b += 64u) consider(d.bigList[2u * (size_t)b], d.bigList[2u * (size_t)b + 1u]);
-  // tiled world: a neighbour's border record that found its landing bin full lives only in the spill list
-  // (k_border_merge); it is this tile's to answer for like the records in the bin.  Duplicates of a box that is also
-  // binned elsewhere are harmless: the same box gives the same distance and the id breaks the tie.
-  const uint32_t nspill = min(d.counters[kCtrPar + 8u * p.parity + kCtrSpill], kSpillCap);
+  // records that found their sector's bin full -- this tile's own boxes and a neighbour's border records (k_border_merge)
+  // -- live only in the sector overflow list; they are this tile's to answer for like the records in the bins.  Duplicates
+  // of a box that is also binned elsewhere are harmless: the same box gives the same distance and the id breaks the tie.
+  const uint32_t nspill = min(d.counters[kCtrPar + 8u * p.parity + kCtrSpill], p.ovfCap);
   for (uint32_t e = lane; e < nspill; e += 64u) consider(d.spill[2u * (size_t)e], d.spill[2u * (size_t)e + 1u]);
 
   // closest hit of the wave: distances are >= 0, so their bit patterns order like the values
