@@ -338,6 +338,39 @@ def main():
     t.set_profiling(0)
     counts = t.counts()
 
+    # End to end, as the engine would run it in resident mode: every frame also emits the draw items (the sandbox's budget,
+    # 6000: src/sandbox/src/main.cpp:96) and reads back counts + visible list + draw items -- staged by a small kernel, ONE
+    # device-to-host copy per frame on a copy stream under the next tick -- and the host consumes frame t-1 while tick t runs.
+    end_to_end = None
+    if world_size == 1 and not args.graph:
+        t.set_draw_budget(6000)
+        t.set_frame_readback(8192, 6000)
+        e2e_flags = flags | capi.DRAWS
+        check = 0
+
+        def e2e_step(k):
+            nonlocal check
+            ticks_done[0] += 1
+            t.run(e2e_flags)
+            if k:
+                fr, vis, draws = t.acquire_frame(frames_back=1, copy=False)
+                check += int(vis[-1]) + int(fr.draws_in_buffer) if fr.visible_in_buffer else 0     # the host really touches the frame
+        for k in range(args.warmup):
+            e2e_step(k)
+        fence()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            e2e_step(k + 1)
+        fr, vis, draws = t.acquire_frame(frames_back=0, copy=False)
+        e2e_elapsed = time.perf_counter() - t0
+        fence()
+        end_to_end = {"ms_per_step": e2e_elapsed / args.steps * 1e3,
+                      "added_us_per_step": (e2e_elapsed - elapsed) / args.steps * 1e6,
+                      "visible_read_back": int(fr.visible_in_buffer), "draws_read_back": int(fr.draws_in_buffer),
+                      "bytes_per_frame": 64 + 8192 * 4 + 6000 * 80,
+                      "what": "tick + k_emit_draws (budget 6000) + staging kernel + one pinned D2H per frame on a copy stream; the host takes frame t-1 while tick t runs"}
+        t.set_frame_readback(0, 0)
+
     if world_size > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=ctl_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -413,6 +446,7 @@ def main():
                 "rehearsal_same_device": bool(args.same_device),
             },
             "parity_in_run": parity,
+            "end_to_end": end_to_end,
             "roofline": {
                 "bound": "hbm", "kernel": "k_xform_cull",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

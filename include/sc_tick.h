@@ -326,6 +326,30 @@ int scTickReadWorldAabbs(ScTickContext* ctx, uint32_t first, uint32_t count, flo
 int scTickReadPairs(ScTickContext* ctx, uint32_t* pairs2, uint32_t capacity, uint32_t* count);
 int scTickReadDraws(ScTickContext* ctx, ScTickDrawItem* items, uint32_t capacity, uint32_t* count);
 
+/* ---- per-frame read-back, overlapped with the next tick ----
+ * In resident mode the engine still needs, every frame, what the renderer consumes: the visible list
+ * (CullingState::visible, sc_world_partition.h:341-351), the draw items (RenderFrameData::draws, sc_ecs.h:167-173) and
+ * the stats.  scTickSetFrameReadback(max_visible, max_draws) makes every scTickRun end with a small staging kernel (the
+ * frame's counts, the first max_visible visible indices, the first max_draws draw items when SC_TICK_DRAWS ran, in ONE
+ * device block) and ONE device-to-host copy of that block into pinned host memory, on a copy stream of the library's own:
+ * the copy of frame t runs under the kernels of tick t+1.  Blocks and host buffers are double-buffered.
+ * scTickAcquireFrame(frames_back) waits for the copy of ONE frame -- 0: the most recently queued, 1: the one before, which
+ * is how a host overlaps: queue tick t+1, then take frame t -- and for nothing queued after it, and hands out pointers into
+ * the pinned buffer; they stay valid until the second scTickRun after the one that produced the frame.
+ * (0, 0) switches it off.  Not combinable with graph replay. */
+typedef struct ScTickFrame
+{
+  uint64_t tick;                   /* index of the scTickRun that produced it (counted from the first one after switching on) */
+  uint32_t renderables_total, visible, culled;      /* CullingStats */
+  uint32_t draws_emitted, draws_dropped, draws_sorted;
+  uint32_t visible_in_buffer;      /* min(visible, max_visible) */
+  uint32_t draws_in_buffer;        /* min(draws, max_draws); 0 when the run had no SC_TICK_DRAWS */
+  const uint32_t* visible_indices;         /* pinned host memory */
+  const ScTickDrawItem* draws;             /* pinned host memory */
+} ScTickFrame;
+int scTickSetFrameReadback(ScTickContext* ctx, uint32_t max_visible, uint32_t max_draws);
+int scTickAcquireFrame(ScTickContext* ctx, uint32_t frames_back, ScTickFrame* out);
+
 /* ---- host-side helpers (no GPU work) ----
  * CameraSystem stays on the host (O(#cameras), sc_ecs.cpp:213-272).  These restate the four sc_math
  * functions it and the editor use (sc_math.h:31-58) with the reference's libm calls and operation

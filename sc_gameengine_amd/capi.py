@@ -48,6 +48,13 @@ class RayHit(C.Structure):
                 ("normal", C.c_float * 3), ("layer", C.c_uint32), ("pad", C.c_uint32 * 2)]
 
 
+class Frame(C.Structure):
+    _fields_ = [("tick", C.c_uint64), ("renderables_total", C.c_uint32), ("visible", C.c_uint32), ("culled", C.c_uint32),
+                ("draws_emitted", C.c_uint32), ("draws_dropped", C.c_uint32), ("draws_sorted", C.c_uint32),
+                ("visible_in_buffer", C.c_uint32), ("draws_in_buffer", C.c_uint32),
+                ("visible_indices", U32P), ("draws", C.POINTER(DrawItem))]
+
+
 class LaneGraph(C.Structure):
     _fields_ = [("segments", C.c_uint32), ("nodes", C.c_uint32), ("connections", C.c_uint32),
                 ("seg_start3", F32P), ("seg_dir3", F32P), ("seg_length", F32P), ("seg_active", U8P), ("seg_end_node", U32P),
@@ -115,6 +122,8 @@ SYMBOLS = {
     "scTickAdvanceMovers": (C.c_int, [_CTX, C.c_float]),
     "scTickReadMoverVelocities": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
     "scTickSetFrameProducer": (C.c_int, [_CTX, C.c_uint32, C.c_float]),
+    "scTickSetFrameReadback": (C.c_int, [_CTX, C.c_uint32, C.c_uint32]),
+    "scTickAcquireFrame": (C.c_int, [_CTX, C.c_uint32, C.POINTER(Frame)]),
     "scTickSetLaneGraph": (C.c_int, [_CTX, C.POINTER(LaneGraph)]),
     "scTickSetLaneActive": (C.c_int, [_CTX, U32P, C.c_uint32, C.c_int]),
     "scTickUploadTrafficAgents": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P, U32P, F32P, F32P, U8P, F32P]),

@@ -109,6 +109,13 @@ struct ScTickContext
   bool pairsInFlight[kMaxParity] = {};
   // library-owned exchange (scTickCommInit): one RCCL communicator per context, the border messages of both tick
   // parities in buffers of the library's own, the neighbour in direction d at rank peer[d]
+  // per-frame read-back (scTickSetFrameReadback): staged on the tick stream, copied on a stream of its own, double-buffered
+  struct FrameReadback {
+    uint32_t maxVisible = 0, maxDraws = 0; size_t bytes = 0;
+    uint32_t* dBlock[2] = {}; uint32_t* hBlock[2] = {};
+    hipStream_t copyStream = nullptr; hipEvent_t staged[2] = {}, copied[2] = {};
+    bool inFlight[2] = { false, false }; uint64_t frames = 0;
+  } rb;
   ncclComm_t comm = nullptr;
   uint32_t commSize = 0, commRank = 0;
   int32_t peer[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };
@@ -480,6 +487,22 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     if (flags & SC_TICK_SORT_DRAWS) launchSortedDraws(ds, c->sort, budget, (budget && budget < c->n) ? budget : c->n, c->dDraws, c->stream);
     else launchEmitDraws(ds, budget, c->dDraws, c->stream);
   }
+  if (c->rb.bytes) {
+    ScTickContext::FrameReadback& rb = c->rb;
+    const uint32_t f = (uint32_t)(rb.frames & 1u);
+    if (rb.inFlight[f]) {                 // the copy of two frames ago still reads this block? (asked first: a satisfied wait costs a bubble too)
+      if (hipEventQuery(rb.copied[f]) != hipSuccess) hipStreamWaitEvent(c->stream, rb.copied[f], 0);
+      (void)hipGetLastError();
+    }
+    const uint32_t drawMode = (flags & SC_TICK_DRAWS) ? ((flags & SC_TICK_SORT_DRAWS) ? 2u : 1u) : 0u;
+    launchStageFrame(ds, rb.dBlock[f], rb.maxVisible, rb.maxDraws, c->dDraws, drawMode, rb.frames, c->stream);
+    hipEventRecord(rb.staged[f], c->stream);
+    hipStreamWaitEvent(rb.copyStream, rb.staged[f], 0);
+    hipMemcpyAsync(rb.hBlock[f], rb.dBlock[f], rb.bytes, hipMemcpyDeviceToHost, rb.copyStream);
+    hipEventRecord(rb.copied[f], rb.copyStream);
+    rb.inFlight[f] = true;
+    rb.frames++;
+  }
   c->profiling = saved;
 }
 
@@ -594,6 +617,11 @@ void scTickDestroyContext(ScTickContext* c)
   for (auto& v : c->times) for (auto& p : v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : c->eventPool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (uint32_t k = 0; k < kMaxParity; ++k) { if (c->packed[k]) hipEventDestroy(c->packed[k]); if (c->pairsDone[k]) hipEventDestroy(c->pairsDone[k]); }
+  if (c->rb.copyStream) {
+    hipStreamSynchronize(c->rb.copyStream);
+    for (int k = 0; k < 2; ++k) { if (c->rb.hBlock[k]) hipHostFree(c->rb.hBlock[k]); if (c->rb.staged[k]) hipEventDestroy(c->rb.staged[k]); if (c->rb.copied[k]) hipEventDestroy(c->rb.copied[k]); }
+    hipStreamDestroy(c->rb.copyStream);
+  }
   if (c->pairsStream) hipStreamSynchronize(c->pairsStream);
   if (c->comm) { std::string why; if (const RcclApi* r = rccl(&why)) r->CommDestroy(c->comm); c->comm = nullptr; }
   for (void* p : c->allocs) hipFree(p);
@@ -1064,6 +1092,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   }
   if (c->pairsStream && (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS)) return fail(c, "a pairs stream is set: run the broadphase with SC_TICK_SPLIT_PAIRS + scTickRunPairs");
   if (c->pairsStream && c->graphMode) return fail(c, "graph replay and a pairs stream cannot be combined");
+  if (c->rb.bytes && c->graphMode) return fail(c, "graph replay and the frame read-back cannot be combined");
   if ((flags & SC_TICK_RAYS) && !(flags & SC_TICK_BROADPHASE)) return fail(c, "SC_TICK_RAYS needs SC_TICK_BROADPHASE in the same run (the queries read this tick's bins)");
   if ((flags & SC_TICK_SORT_DRAWS) && !c->sort.pipeline) return fail(c, "SC_TICK_SORT_DRAWS needs scTickSetDrawSortTable first");
   TickParams p; uint32_t grid;
@@ -1591,6 +1620,59 @@ int scTickSetGraphMode(ScTickContext* c, int enable)
 }
 
 void* scTickGetStream(ScTickContext* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---- per-frame read-back ---------------------------------------------------------------------------------------------
+int scTickSetFrameReadback(ScTickContext* c, uint32_t maxVisible, uint32_t maxDraws)
+{
+  if (!c) return 0;
+  if (!bind(c) || !sync(c)) return 0;
+  ScTickContext::FrameReadback& rb = c->rb;
+  if (rb.copyStream) HIP_OK(c, hipStreamSynchronize(rb.copyStream));
+  for (int k = 0; k < 2; ++k) { dfree(c, rb.dBlock[k]); rb.dBlock[k] = nullptr; if (rb.hBlock[k]) { hipHostFree(rb.hBlock[k]); rb.hBlock[k] = nullptr; } rb.inFlight[k] = false; }
+  rb.bytes = 0; rb.frames = 0; rb.maxVisible = rb.maxDraws = 0;
+  if (!maxVisible && !maxDraws) return 1;
+  if (maxVisible > c->cap || maxDraws > c->cap) return fail(c, "read-back sizes exceed the context's capacity");
+  maxVisible = (maxVisible + 3u) & ~3u;                        // keeps the draw items 16-byte aligned inside the block
+  const size_t bytes = (size_t)kFrameHeaderWords * 4u + (size_t)maxVisible * 4u + (size_t)maxDraws * sizeof(ScTickDrawItem);
+  if (!rb.copyStream) {
+    HIP_OK(c, hipStreamCreateWithFlags(&rb.copyStream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+      HIP_OK(c, hipEventCreateWithFlags(&rb.staged[k], hipEventDisableTiming));
+      HIP_OK(c, hipEventCreateWithFlags(&rb.copied[k], hipEventDisableTiming));
+    }
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (!dalloc(c, rb.dBlock[k], bytes / 4u)) return 0;
+    void* h = nullptr;
+    HIP_OK(c, hipHostMalloc(&h, bytes, hipHostMallocDefault));
+    std::memset(h, 0, bytes);
+    rb.hBlock[k] = static_cast<uint32_t*>(h);
+  }
+  rb.maxVisible = maxVisible; rb.maxDraws = maxDraws; rb.bytes = bytes;
+  dropGraph(c);
+  return 1;
+}
+
+int scTickAcquireFrame(ScTickContext* c, uint32_t framesBack, ScTickFrame* out)
+{
+  if (!c || !out) return c ? fail(c, "null argument") : 0;
+  ScTickContext::FrameReadback& rb = c->rb;
+  if (!rb.bytes) return fail(c, "scTickSetFrameReadback first");
+  if (framesBack > 1u) return fail(c, "frames_back must be 0 (the latest frame) or 1 (the one before): two frames are kept");
+  if (rb.frames <= framesBack) return fail(c, "that frame has not been produced yet");
+  if (!bind(c)) return 0;
+  const uint32_t f = (uint32_t)((rb.frames - 1u - framesBack) & 1u);
+  HIP_OK(c, hipEventSynchronize(rb.copied[f]));               // this frame's copy only: later work keeps running
+  const uint32_t* h = rb.hBlock[f];
+  std::memset(out, 0, sizeof *out);
+  out->tick = (uint64_t)h[6] | ((uint64_t)h[7] << 32);
+  out->visible = h[0]; out->culled = h[1]; out->renderables_total = h[2];
+  out->draws_emitted = h[3]; out->draws_dropped = h[4]; out->draws_sorted = h[5];
+  out->visible_in_buffer = h[8]; out->draws_in_buffer = h[9];
+  out->visible_indices = h + kFrameHeaderWords;
+  out->draws = reinterpret_cast<const ScTickDrawItem*>(h + kFrameHeaderWords + rb.maxVisible);
+  return 1;
+}
 
 // ---- on-rails traffic: lane graph, agents, tier selection ----------------------------------------------
 int scTickSetLaneGraph(ScTickContext* c, const ScTickLaneGraph* g)

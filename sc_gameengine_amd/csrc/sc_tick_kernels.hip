@@ -1589,9 +1589,36 @@ __global__ __launch_bounds__(kTile) void k_emit_draws(const DeviceState d, uint3
   }
 }
 
+// Frame read-back: the frame's counts, the head of the visible list and of the draw list, gathered into one block that a
+// single device-to-host copy then takes (the lists themselves are overwritten by the next tick).
+__global__ __launch_bounds__(kTile) void k_stage_frame(const DeviceState d, uint32_t* __restrict__ block, uint32_t maxVisible, uint32_t maxDraws,
+                                                       const uint4* __restrict__ items, uint32_t drawMode, uint32_t tickLo, uint32_t tickHi)
+{
+  const uint32_t visible = d.counters[0];
+  const uint32_t draws = drawMode == 2u ? d.counters[kCtrDrawsSorted] : (drawMode == 1u ? d.counters[4] : 0u);
+  const uint32_t nv = visible < maxVisible ? visible : maxVisible, nd = draws < maxDraws ? draws : maxDraws;
+  if (blockIdx.x == 0 && threadIdx.x < kFrameHeaderWords) {
+    const uint32_t h[kFrameHeaderWords] = { visible, d.counters[1], d.counters[6], drawMode ? d.counters[4] : 0u, drawMode ? d.counters[5] : 0u,
+                                            drawMode == 2u ? d.counters[kCtrDrawsSorted] : 0u, tickLo, tickHi, nv, nd, 0, 0, 0, 0, 0, 0 };
+    block[threadIdx.x] = h[threadIdx.x];
+  }
+  uint32_t* vis = block + kFrameHeaderWords;
+  for (uint32_t t = blockIdx.x * kTile + threadIdx.x; t < nv; t += gridDim.x * kTile) vis[t] = d.visibleIdx[t];
+  uint4* out = reinterpret_cast<uint4*>(block + kFrameHeaderWords + maxVisible);      // (maxVisible is a multiple of 4: 16-byte aligned)
+  for (uint32_t t = blockIdx.x * kTile + threadIdx.x; t < nd * 5u; t += gridDim.x * kTile) out[t] = items[t];
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+void launchStageFrame(const DeviceState& d, uint32_t* block, uint32_t maxVisible, uint32_t maxDraws, const void* items, uint32_t drawMode,
+                      uint64_t tick, hipStream_t s)
+{
+  const uint32_t work = std::max(maxVisible, maxDraws * 5u);
+  const uint32_t blocks = std::max(1u, std::min((work + kTile - 1) / kTile, 64u));
+  hipLaunchKernelGGL(k_stage_frame, dim3(blocks), dim3(kTile), 0, s, d, block, maxVisible, maxDraws, (const uint4*)items, drawMode,
+                     (uint32_t)tick, (uint32_t)(tick >> 32));
+}
 // evA / evB (both or neither): events that take the kernel's own begin / end timestamps (hipExtLaunchKernelGGL), so the
 // duration bench.py reports is the dispatch's, like the kernel trace's -- not the gap-inclusive span between two
 // hipEventRecord calls on the stream

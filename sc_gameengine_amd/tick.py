@@ -190,6 +190,10 @@ class WorldTick:
         self.set_view_proj(vp)
         return vp
 
+    def set_draw_budget(self, max_draws):
+        """WorldStreamingBudgets::maxDrawsBudget for the next SC_TICK_DRAWS (0 = unlimited)"""
+        self._ok(self.lib.scTickSetDrawBudget(self.ctx, int(max_draws)), "scTickSetDrawBudget")
+
     def set_freeze_culling(self, on):
         self._ok(self.lib.scTickSetFreezeCulling(self.ctx, 1 if on else 0), "scTickSetFreezeCulling")
 
@@ -398,6 +402,20 @@ class WorldTick:
         if cnt.value:
             self._ok(self.lib.scTickGetKernelTimes(self.ctx, kernel, _f(out), cnt.value, C.byref(cnt)), "scTickGetKernelTimes")
         return out
+
+    # ---- per-frame read-back, overlapped with the next tick ----
+    def set_frame_readback(self, max_visible, max_draws=0):
+        self._ok(self.lib.scTickSetFrameReadback(self.ctx, int(max_visible), int(max_draws)), "scTickSetFrameReadback")
+
+    def acquire_frame(self, frames_back=0, copy=True):
+        """Frame `frames_back` (0 latest, 1 the one before): (frame struct, visible indices, draw items as a (n, 80) byte array).
+        With copy=False the arrays are views of the pinned buffer (valid until the second run after this frame's)."""
+        fr = capi.Frame()
+        self._ok(self.lib.scTickAcquireFrame(self.ctx, int(frames_back), C.byref(fr)), "scTickAcquireFrame")
+        nv, nd = fr.visible_in_buffer, fr.draws_in_buffer
+        vis = np.ctypeslib.as_array(fr.visible_indices, shape=(nv,)) if nv else np.zeros(0, np.uint32)
+        draws = (np.ctypeslib.as_array(C.cast(fr.draws, capi.U8P), shape=(nd * 80,)).reshape(nd, 80) if nd else np.zeros((0, 80), np.uint8))
+        return fr, (vis.copy() if copy else vis), (draws.copy() if copy else draws)
 
     # ---- results ----
     def counts(self):
