@@ -64,6 +64,7 @@ struct ScTickContext
   // scratch device buffers for indexed read-back
   uint32_t* dIdx = nullptr; float* dRows = nullptr; uint32_t scratchCap = 0;
   void* dDraws = nullptr;
+  void* lastDraws = nullptr;           // where the last SC_TICK_DRAWS wrote its items (dDraws, or the frame read-back block)
   RayQueryState rays{};                // scTickSetRayQueries: device copies of the batch + the hit buffer
   uint32_t rayCap = 0;
   DrawSortState sort{};                // renderer draw order (scTickSetDrawSortTable); key/idx buffers allocated on first use
@@ -482,8 +483,12 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
       else { Scoped s(c, SC_TICK_K_PAIRS); launchPairs(ds, p, c->stream); }
     }
   }
-  if (flags & SC_TICK_DRAWS) {
-    const uint32_t budget = c->desc.max_draws_budget;
+  // with the frame read-back on and a plain draw list whose budget fits the block, emission and staging are one launch
+  const uint32_t drawBudget = c->desc.max_draws_budget;
+  const bool stagedEmit = c->rb.bytes && (flags & SC_TICK_DRAWS) && !(flags & SC_TICK_SORT_DRAWS) && drawBudget && drawBudget <= c->rb.maxDraws;
+  c->lastDraws = c->dDraws;
+  if ((flags & SC_TICK_DRAWS) && !stagedEmit) {
+    const uint32_t budget = drawBudget;
     if (flags & SC_TICK_SORT_DRAWS) launchSortedDraws(ds, c->sort, budget, (budget && budget < c->n) ? budget : c->n, c->dDraws, c->stream);
     else launchEmitDraws(ds, budget, c->dDraws, c->stream);
   }
@@ -495,7 +500,10 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
       (void)hipGetLastError();
     }
     const uint32_t drawMode = (flags & SC_TICK_DRAWS) ? ((flags & SC_TICK_SORT_DRAWS) ? 2u : 1u) : 0u;
-    launchStageFrame(ds, rb.dBlock[f], rb.maxVisible, rb.maxDraws, c->dDraws, drawMode, rb.frames, c->stream);
+    if (stagedEmit) {
+      launchEmitDrawsStaged(ds, drawBudget, rb.dBlock[f], rb.maxVisible, rb.frames, c->stream);
+      c->lastDraws = rb.dBlock[f] + kFrameHeaderWords + rb.maxVisible;       // what scTickReadDraws returns for this tick
+    } else launchStageFrame(ds, rb.dBlock[f], rb.maxVisible, rb.maxDraws, c->dDraws, drawMode, rb.frames, c->stream);
     hipEventRecord(rb.staged[f], c->stream);
     hipStreamWaitEvent(rb.copyStream, rb.staged[f], 0);
     hipMemcpyAsync(rb.hBlock[f], rb.dBlock[f], rb.bytes, hipMemcpyDeviceToHost, rb.copyStream);
@@ -1513,7 +1521,7 @@ int scTickReadDraws(ScTickContext* c, ScTickDrawItem* items, uint32_t cap, uint3
   const uint32_t have = (c->lastFlags & SC_TICK_SORT_DRAWS) ? k[kCtrDrawsSorted] : k[4];
   *count = have;
   const uint32_t take = std::min(have, cap);
-  if (take && items) { if (!d2h(c, items, c->dDraws, (size_t)take * sizeof(ScTickDrawItem)) || !sync(c)) return 0; }
+  if (take && items) { if (!d2h(c, items, c->lastDraws ? c->lastDraws : c->dDraws, (size_t)take * sizeof(ScTickDrawItem)) || !sync(c)) return 0; }
   return 1;
 }
 

@@ -1608,9 +1608,45 @@ __global__ __launch_bounds__(kTile) void k_stage_frame(const DeviceState d, uint
   for (uint32_t t = blockIdx.x * kTile + threadIdx.x; t < nd * 5u; t += gridDim.x * kTile) out[t] = items[t];
 }
 
+// Draw emission and frame staging in one launch (the common resident-mode frame: plain draw order, budget within the
+// block): the items are written straight into the read-back block, next to the header and the head of the visible list.
+__global__ __launch_bounds__(kTile) void k_emit_draws_staged(const DeviceState d, uint32_t budget, uint32_t* __restrict__ block, uint32_t maxVisible,
+                                                             uint32_t tickLo, uint32_t tickHi)
+{
+  const uint32_t visible = d.counters[0];
+  const uint32_t emitted = (budget > 0 && visible > budget) ? budget : visible;      // the host guarantees budget <= the block's draw capacity
+  const uint32_t nv = visible < maxVisible ? visible : maxVisible;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { d.counters[4] = emitted; d.counters[5] = visible - emitted; }
+  if (blockIdx.x == 0 && threadIdx.x < kFrameHeaderWords) {
+    const uint32_t h[kFrameHeaderWords] = { visible, d.counters[1], d.counters[6], emitted, visible - emitted, 0u, tickLo, tickHi, nv, emitted, 0, 0, 0, 0, 0, 0 };
+    block[threadIdx.x] = h[threadIdx.x];
+  }
+  uint32_t* vis = block + kFrameHeaderWords;
+  DrawItem80* items = reinterpret_cast<DrawItem80*>(block + kFrameHeaderWords + maxVisible);
+  for (uint32_t t = blockIdx.x * kTile + threadIdx.x; t < (emitted > nv ? emitted : nv); t += gridDim.x * kTile) {
+    const uint32_t j = d.visibleIdx[t];
+    if (t < nv) vis[t] = j;
+    if (t < emitted) {
+      const float4 a = ldRow(d, 0, j), b = ldRow(d, 1, j), c = ldRow(d, 2, j);
+      float4* o = reinterpret_cast<float4*>(&items[t]);
+      o[0] = make_float4(__uint_as_float(j), __uint_as_float(d.meshId[j]), __uint_as_float(d.materialId[j]), 0.0f);
+      o[1] = make_float4(a.x, b.x, c.x, 0.0f);
+      o[2] = make_float4(a.y, b.y, c.y, 0.0f);
+      o[3] = make_float4(a.z, b.z, c.z, 0.0f);
+      o[4] = make_float4(a.w, b.w, c.w, 1.0f);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+void launchEmitDrawsStaged(const DeviceState& d, uint32_t budget, uint32_t* block, uint32_t maxVisible, uint64_t tick, hipStream_t s)
+{
+  const uint32_t work = std::max(maxVisible, budget);
+  const uint32_t blocks = std::max(1u, std::min((work + kTile - 1) / kTile, 64u));
+  hipLaunchKernelGGL(k_emit_draws_staged, dim3(blocks), dim3(kTile), 0, s, d, budget, block, maxVisible, (uint32_t)tick, (uint32_t)(tick >> 32));
+}
 void launchStageFrame(const DeviceState& d, uint32_t* block, uint32_t maxVisible, uint32_t maxDraws, const void* items, uint32_t drawMode,
                       uint64_t tick, hipStream_t s)
 {
