@@ -193,7 +193,7 @@ class OracleLeg:
         med = float(np.median(times))
         n = self.world.n
         return {"value": n / med, "unit": "entities/s", "cores": workers + 1, "kind": "port",
-                "threading": "pthread range pool over groups of 128 (the reference's per-worker rings / stealing are not restated)" if workers else "single thread",
+                "threading": "JobSystem::Dispatch restated: per-worker 1024-slot rings, round-robin enqueue, inline when every ring is full, stealing workers, helping waiter (sc_jobs.cpp:247-372)" if workers else "no job system: groups run in order on the caller",
                 "sample": f"same world ({n} entities), {warm} warm-up + {ticks} timed ticks, "
                           f"{'all roots nudged' if self.vel is None else 'movers advanced'} each tick, "
                           f"median tick {med * 1e3:.1f} ms (xform+camera+cull), host cpus {hw}"}

@@ -90,6 +90,7 @@ def lib():
     L.orc_read_local_scales.argtypes = [vp, F32P]
     L.orc_jobs_init.argtypes = [C.c_uint32]
     L.orc_jobs_workers.restype = C.c_uint32
+    L.orc_jobs_ran_inline.restype = C.c_ulong
     L.orc_transform_system.argtypes = [vp]
     L.orc_camera_system.argtypes = [vp, C.POINTER(CameraState)]
     L.orc_frustum_from_viewproj.argtypes = [F32P, C.POINTER(Frustum)]

@@ -16,6 +16,7 @@
 #include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------------------------------
  * Math -- src/core/src/sc_math.cpp.  Column-major: element(row r, col c) = m[c*4 + r].
@@ -419,51 +420,111 @@ void orc_read_local_scales(OrcWorld* w, float* out)
 }
 
 /* ------------------------------------------------------------------------------------------
- * Job pool -- stand-in for JobSystem::Dispatch(count, groupSize, f) + Wait as CullingSystem
- * uses it (sc_jobs.h:70-134, sc_jobs.cpp:202-218): ceil(count/groupSize) groups handed to N
- * worker threads, the waiting caller executes groups too.  The reference's per-worker rings and
- * stealing are replaced by one shared atomic group cursor (same work split, less queue traffic).
+ * Job system as CullingSystem uses it -- JobSystem::Dispatch(count, groupSize, f) + Wait
+ * (src/core/include/sc_jobs.h:70-134, src/core/src/sc_jobs.cpp), restated:
+ *   - one bounded MPMC ring of kQueueSize = 1024 cells per worker, sequence-numbered cells
+ *     (sc_jobs.cpp:12-101);
+ *   - Dispatch cuts [0, count) into ceil(count / groupSize) jobs and enqueues them one by one
+ *     (sc_jobs.h:88-129); enqueue picks a ring round-robin (m_rr), falls back to the first ring
+ *     with room, and when every ring is full runs the job on the calling thread
+ *     (sc_jobs.cpp:247-288) -- with 8192 jobs at 1M entities and 1024 slots per worker that
+ *     overflow path is the common one on few workers;
+ *   - a worker pops its own ring, else steals from the others in index order, else sleeps until
+ *     jobs are queued (runOne :290-352, workerMain :354-372);
+ *   - Wait: the caller steals from any ring while the fence counts down, else naps 200 us on the
+ *     fence (:202-218).
+ * Not restated: the per-frame payload arena (2 MB; a job's payload is 24 bytes, so 87k jobs fit:
+ * never the limit below 11M candidates), the fence pool (one Dispatch is in flight at a time
+ * here), telemetry counters and scoped timers.
  * ---------------------------------------------------------------------------------------- */
 
 typedef void (*OrcRangeFn)(uint32_t start, uint32_t end, void* user);
 
-static struct {
-  pthread_t* threads; uint32_t workers; int running;
-  pthread_mutex_t mu; pthread_cond_t cvWork, cvDone;
-  uint64_t epoch;
-  OrcRangeFn fn; void* user; uint32_t count, groupSize, groupCount;
-  atomic_uint cursor; atomic_uint remaining;
-} gJobs = { .mu = PTHREAD_MUTEX_INITIALIZER, .cvWork = PTHREAD_COND_INITIALIZER, .cvDone = PTHREAD_COND_INITIALIZER };
+#define ORC_QUEUE_SIZE 1024u                       /* kQueueSize, sc_jobs.cpp:12 */
 
-static void jobs_drain(void)
+typedef struct { uint32_t start, end; OrcRangeFn fn; void* user; } OrcJobItem;
+typedef struct { atomic_uint seq; OrcJobItem job; } OrcCell;
+typedef struct { OrcCell* buffer; uint32_t mask; atomic_uint enqueuePos, dequeuePos; } OrcRing;
+
+static int ring_enqueue(OrcRing* q, const OrcJobItem* job)               /* :45-72 */
 {
+  OrcCell* cell;
+  uint32_t pos = atomic_load_explicit(&q->enqueuePos, memory_order_relaxed);
   for (;;) {
-    const uint32_t g = atomic_fetch_add(&gJobs.cursor, 1u);
-    if (g >= gJobs.groupCount) break;
-    const uint32_t s = g * gJobs.groupSize;
-    const uint32_t e = (s + gJobs.groupSize > gJobs.count) ? gJobs.count : s + gJobs.groupSize;
-    gJobs.fn(s, e, gJobs.user);
-    if (atomic_fetch_sub(&gJobs.remaining, 1u) == 1u) {
-      pthread_mutex_lock(&gJobs.mu);
-      pthread_cond_broadcast(&gJobs.cvDone);
-      pthread_mutex_unlock(&gJobs.mu);
-    }
+    cell = &q->buffer[pos & q->mask];
+    const uint32_t seq = atomic_load_explicit(&cell->seq, memory_order_acquire);
+    const int32_t diff = (int32_t)seq - (int32_t)pos;
+    if (diff == 0) { if (atomic_compare_exchange_weak_explicit(&q->enqueuePos, &pos, pos + 1u, memory_order_relaxed, memory_order_relaxed)) break; }
+    else if (diff < 0) return 0;                                          /* full */
+    else pos = atomic_load_explicit(&q->enqueuePos, memory_order_relaxed);
+  }
+  cell->job = *job;
+  atomic_store_explicit(&cell->seq, pos + 1u, memory_order_release);
+  return 1;
+}
+
+static int ring_dequeue(OrcRing* q, OrcJobItem* out)                      /* :74-100 */
+{
+  OrcCell* cell;
+  uint32_t pos = atomic_load_explicit(&q->dequeuePos, memory_order_relaxed);
+  for (;;) {
+    cell = &q->buffer[pos & q->mask];
+    const uint32_t seq = atomic_load_explicit(&cell->seq, memory_order_acquire);
+    const int32_t diff = (int32_t)seq - (int32_t)(pos + 1u);
+    if (diff == 0) { if (atomic_compare_exchange_weak_explicit(&q->dequeuePos, &pos, pos + 1u, memory_order_relaxed, memory_order_relaxed)) break; }
+    else if (diff < 0) return 0;                                          /* empty */
+    else pos = atomic_load_explicit(&q->dequeuePos, memory_order_relaxed);
+  }
+  *out = cell->job;
+  atomic_store_explicit(&cell->seq, pos + q->mask + 1u, memory_order_release);
+  return 1;
+}
+
+static struct {
+  pthread_t* threads; OrcRing* rings; uint32_t workers; atomic_int shutdown;
+  pthread_mutex_t wakeMu; pthread_cond_t wakeCv;                          /* m_wakeMutex / m_wakeCv */
+  atomic_uint rr; atomic_int jobsQueued;                                  /* m_rr, m_jobsQueued */
+  atomic_int fenceCount; pthread_mutex_t fenceMu; pthread_cond_t fenceCv; /* one JobFence (sc_jobs.h:34-40) */
+  atomic_ulong ranInline;                                                 /* jobs the dispatcher had to run itself (all rings full) */
+} gJobs = { .wakeMu = PTHREAD_MUTEX_INITIALIZER, .wakeCv = PTHREAD_COND_INITIALIZER,
+            .fenceMu = PTHREAD_MUTEX_INITIALIZER, .fenceCv = PTHREAD_COND_INITIALIZER };
+
+static void job_finish(const OrcJobItem* job)
+{
+  job->fn(job->start, job->end, job->user);
+  if (atomic_fetch_sub_explicit(&gJobs.fenceCount, 1, memory_order_acq_rel) - 1 == 0) {
+    pthread_mutex_lock(&gJobs.fenceMu);
+    pthread_cond_broadcast(&gJobs.fenceCv);
+    pthread_mutex_unlock(&gJobs.fenceMu);
   }
 }
 
-static void* jobs_worker(void* arg)
+static int jobs_run_one(uint32_t workerIndex)                             /* runOne, :290-352 */
 {
-  (void)arg;
-  uint64_t seen = 0;
-  pthread_mutex_lock(&gJobs.mu);
-  while (gJobs.running) {
-    if (gJobs.epoch == seen) { pthread_cond_wait(&gJobs.cvWork, &gJobs.mu); continue; }
-    seen = gJobs.epoch;
-    pthread_mutex_unlock(&gJobs.mu);
-    jobs_drain();
-    pthread_mutex_lock(&gJobs.mu);
+  if (gJobs.workers == 0) return 0;
+  OrcJobItem job; int found = 0;
+  if (workerIndex < gJobs.workers) {
+    found = ring_dequeue(&gJobs.rings[workerIndex], &job);
+    for (uint32_t i = 0; i < gJobs.workers && !found; ++i) { if (i != workerIndex) found = ring_dequeue(&gJobs.rings[i], &job); }   /* steal */
+  } else {
+    for (uint32_t i = 0; i < gJobs.workers && !found; ++i) found = ring_dequeue(&gJobs.rings[i], &job);                           /* main thread helps */
   }
-  pthread_mutex_unlock(&gJobs.mu);
+  if (!found) return 0;
+  atomic_fetch_sub_explicit(&gJobs.jobsQueued, 1, memory_order_relaxed);
+  job_finish(&job);
+  return 1;
+}
+
+static void* jobs_worker(void* arg)                                        /* workerMain, :354-372 */
+{
+  const uint32_t index = (uint32_t)(uintptr_t)arg;
+  while (!atomic_load_explicit(&gJobs.shutdown, memory_order_relaxed)) {
+    if (jobs_run_one(index)) continue;
+    pthread_mutex_lock(&gJobs.wakeMu);
+    while (!atomic_load_explicit(&gJobs.shutdown, memory_order_relaxed) && atomic_load_explicit(&gJobs.jobsQueued, memory_order_relaxed) <= 0)
+      pthread_cond_wait(&gJobs.wakeCv, &gJobs.wakeMu);
+    pthread_mutex_unlock(&gJobs.wakeMu);
+  }
   return NULL;
 }
 
@@ -472,50 +533,82 @@ int orc_jobs_init(uint32_t workers)
   orc_jobs_shutdown();
   if (workers == 0) return 1;
   gJobs.threads = calloc(workers, sizeof(pthread_t));
-  gJobs.running = 1; gJobs.epoch = 0; gJobs.groupCount = 0;
-  atomic_store(&gJobs.cursor, 0u); atomic_store(&gJobs.remaining, 0u);
+  gJobs.rings = calloc(workers, sizeof(OrcRing));
+  if (!gJobs.threads || !gJobs.rings) abort();
   for (uint32_t i = 0; i < workers; ++i) {
-    if (pthread_create(&gJobs.threads[i], NULL, jobs_worker, NULL) != 0) { gJobs.workers = i; orc_jobs_shutdown(); return 0; }
+    OrcRing* q = &gJobs.rings[i];
+    q->buffer = calloc(ORC_QUEUE_SIZE, sizeof(OrcCell));
+    if (!q->buffer) abort();
+    q->mask = ORC_QUEUE_SIZE - 1u;
+    for (uint32_t k = 0; k < ORC_QUEUE_SIZE; ++k) atomic_store_explicit(&q->buffer[k].seq, k, memory_order_relaxed);
+    atomic_store(&q->enqueuePos, 0u); atomic_store(&q->dequeuePos, 0u);
   }
+  atomic_store(&gJobs.shutdown, 0); atomic_store(&gJobs.rr, 0u); atomic_store(&gJobs.jobsQueued, 0); atomic_store(&gJobs.fenceCount, 0);
   gJobs.workers = workers;
+  for (uint32_t i = 0; i < workers; ++i) {
+    if (pthread_create(&gJobs.threads[i], NULL, jobs_worker, (void*)(uintptr_t)i) != 0) { gJobs.workers = i; orc_jobs_shutdown(); return 0; }
+  }
   return 1;
 }
 
 void orc_jobs_shutdown(void)
 {
   if (!gJobs.threads) { gJobs.workers = 0; return; }
-  pthread_mutex_lock(&gJobs.mu);
-  gJobs.running = 0;
-  pthread_cond_broadcast(&gJobs.cvWork);
-  pthread_mutex_unlock(&gJobs.mu);
+  atomic_store(&gJobs.shutdown, 1);
+  pthread_mutex_lock(&gJobs.wakeMu);
+  pthread_cond_broadcast(&gJobs.wakeCv);
+  pthread_mutex_unlock(&gJobs.wakeMu);
   for (uint32_t i = 0; i < gJobs.workers; ++i) pthread_join(gJobs.threads[i], NULL);
-  free(gJobs.threads); gJobs.threads = NULL; gJobs.workers = 0;
+  for (uint32_t i = 0; gJobs.rings && i < gJobs.workers; ++i) free(gJobs.rings[i].buffer);
+  free(gJobs.threads); free(gJobs.rings); gJobs.threads = NULL; gJobs.rings = NULL; gJobs.workers = 0;
 }
 
 uint32_t orc_jobs_workers(void) { return gJobs.workers; }
+unsigned long orc_jobs_ran_inline(void) { return atomic_load(&gJobs.ranInline); }
+
+static void jobs_enqueue(const OrcJobItem* job)                            /* enqueue, :247-288 */
+{
+  const uint32_t idx = atomic_fetch_add_explicit(&gJobs.rr, 1u, memory_order_relaxed) % gJobs.workers;
+  int placed = ring_enqueue(&gJobs.rings[idx], job);
+  for (uint32_t i = 0; i < gJobs.workers && !placed; ++i) placed = ring_enqueue(&gJobs.rings[i], job);   /* full: linear search */
+  if (placed) {
+    atomic_fetch_add_explicit(&gJobs.jobsQueued, 1, memory_order_relaxed);
+    pthread_mutex_lock(&gJobs.wakeMu);                 /* (notify_one under the mutex: no lost wake-up against the predicate above) */
+    pthread_cond_signal(&gJobs.wakeCv);
+    pthread_mutex_unlock(&gJobs.wakeMu);
+    return;
+  }
+  atomic_fetch_add(&gJobs.ranInline, 1ul);
+  job_finish(job);                                     /* every ring full: the caller runs it, nothing is lost */
+}
 
 static void jobs_dispatch_wait(uint32_t count, uint32_t groupSize, OrcRangeFn fn, void* user)
 {
   if (count == 0 || groupSize == 0) return;
   const uint32_t groups = (count + groupSize - 1u) / groupSize;
-  if (gJobs.workers == 0) {
+  if (gJobs.workers == 0) {                            /* no job system: the ranges run in order on the caller */
     for (uint32_t g = 0; g < groups; ++g) {
       const uint32_t s = g * groupSize, e = (s + groupSize > count) ? count : s + groupSize;
       fn(s, e, user);
     }
     return;
   }
-  pthread_mutex_lock(&gJobs.mu);
-  gJobs.fn = fn; gJobs.user = user; gJobs.count = count; gJobs.groupSize = groupSize; gJobs.groupCount = groups;
-  atomic_store(&gJobs.remaining, groups);
-  atomic_store(&gJobs.cursor, 0u);
-  gJobs.epoch++;
-  pthread_cond_broadcast(&gJobs.cvWork);
-  pthread_mutex_unlock(&gJobs.mu);
-  jobs_drain();                                   /* Wait(): the caller helps (sc_jobs.cpp:202-218) */
-  pthread_mutex_lock(&gJobs.mu);
-  while (atomic_load(&gJobs.remaining) != 0u) pthread_cond_wait(&gJobs.cvDone, &gJobs.mu);
-  pthread_mutex_unlock(&gJobs.mu);
+  atomic_store_explicit(&gJobs.fenceCount, (int)groups, memory_order_release);          /* allocFence(groupCount) */
+  for (uint32_t g = 0; g < groups; ++g) {                                                 /* Dispatch, sc_jobs.h:88-129 */
+    OrcJobItem job;
+    job.start = g * groupSize; job.end = (job.start + groupSize > count) ? count : job.start + groupSize;
+    job.fn = fn; job.user = user;
+    jobs_enqueue(&job);
+  }
+  while (atomic_load_explicit(&gJobs.fenceCount, memory_order_acquire) > 0) {            /* Wait, sc_jobs.cpp:202-218 */
+    if (jobs_run_one(gJobs.workers)) continue;
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    ts.tv_nsec += 200000; if (ts.tv_nsec >= 1000000000L) { ts.tv_nsec -= 1000000000L; ts.tv_sec += 1; }
+    pthread_mutex_lock(&gJobs.fenceMu);
+    if (atomic_load_explicit(&gJobs.fenceCount, memory_order_acquire) > 0) pthread_cond_timedwait(&gJobs.fenceCv, &gJobs.fenceMu, &ts);
+    pthread_mutex_unlock(&gJobs.fenceMu);
+  }
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -106,10 +106,13 @@ void orc_read_dirty(OrcWorld* w, uint8_t* outn);
 void orc_read_parents(OrcWorld* w, uint32_t* outn);
 void orc_read_local_scales(OrcWorld* w, float* out3n);
 
-/* ---- job pool stand-in for sc_jobs.h:70-134 Dispatch/Wait as used by culling ---- */
-int  orc_jobs_init(uint32_t workers);   /* workers = threads besides the caller; 0 = run inline */
+/* ---- JobSystem::Dispatch / Wait as used by culling (sc_jobs.h:70-134, sc_jobs.cpp:12-101, :202-218, :247-372):
+ *      per-worker 1024-slot rings, round-robin enqueue with linear fallback, inline execution when every ring is full,
+ *      own-ring-then-steal workers, a waiting caller that helps ---- */
+int  orc_jobs_init(uint32_t workers);   /* workers = threads besides the caller; 0 = no job system (ranges run in order on the caller) */
 void orc_jobs_shutdown(void);
 uint32_t orc_jobs_workers(void);
+unsigned long orc_jobs_ran_inline(void); /* jobs the dispatcher ran itself because every ring was full, since start */
 
 /* ---- systems ---- */
 void orc_transform_system(OrcWorld* w);                                    /* sc_ecs.cpp:118-211 */
