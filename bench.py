@@ -261,8 +261,6 @@ def main():
     t = WorldTick.from_world(w, device=local_rank, broadphase=("broadphase" in stages))
     view_proj = camera_view_proj(cam)
     t.set_view_proj(view_proj)
-    t.set_graph_mode(bool(args.graph))
-
     # N > 1: the broadphase's border boxes are the one exchange on the path.  The library owns it: its own RCCL communicator
     # (ncclCommInitRank from the id rank 0 made), the message buffers of both tick parities, and -- pipelined -- a second
     # stream on which exchange, merge and pair search of tick t run under the fused kernel of tick t+1.  A step is ONE call
@@ -277,9 +275,13 @@ def main():
             exchange = "REHEARSAL: host-staged point-to-point over the control plane (no RCCL)"
         else:
             uid = tiles.rendezvous_unique_id(rank, capi.comm_unique_id)
+            if args.graph:
+                args.pipeline = 0      # a captured step is one in-order graph per tick parity (successive launches of a graph cannot overlap)
             tiles.setup_tile(t, rank, grid, uid, pipelined=bool(args.pipeline))
             exchange = ("border AABBs to <=8 neighbour tiles per step: one group of ncclSend/ncclRecv issued by libsc_tick.so on its own "
                         "RCCL communicator" + (", on the pairs stream under the next tick's fused kernel" if args.pipeline else ""))
+
+    t.set_graph_mode(bool(args.graph))
 
     # The frame producer (config 3: every root nudged; config 5: vehicles and peds advanced) is part of every step.  It
     # runs fused into the end-of-tick kernel as the producer of the NEXT frame (SC_TICK_PRODUCE_NEXT): same work per

@@ -82,6 +82,8 @@ struct ScTickContext
   hipGraph_t graph[2] = { nullptr, nullptr };          // one per broadphase tick parity
   hipGraphExec_t graphExec[2] = { nullptr, nullptr };
   TickParams graphParams[2]{};
+  bool graphWhole[2] = { false, false };               // the captured graph holds the whole tile step (exchange + pair half)
+  bool captureWholeStep = false;                       // set by scTickTileStep around its scTickRun
   uint64_t topoEpoch = 0, graphEpoch[2] = { ~0ull, ~0ull };
 
   // broadphase
@@ -1080,6 +1082,18 @@ int scTickSetFreezeCulling(ScTickContext* c, int freeze)
   return 1;
 }
 
+static int exchangeBorders(ScTickContext* c, uint32_t parity, hipStream_t s);
+
+// merge what the neighbours sent, answer the ray queries, search the pairs: the half of a tile's step behind the exchange
+static void enqueuePairHalf(ScTickContext* c, const TickParams& pp, hipStream_t ps, bool withSnapshot)
+{
+  const DeviceState ds = stateFor(c, pp.parity);
+  launchBorderMerge(ds, pp, ps);
+  if (pp.flags & SC_TICK_RAYS) launchRayQueries(ds, pp, c->rays, ps);   // sees the neighbours' border boxes too
+  launchPairs(ds, pp, ps);
+  if (withSnapshot) launchSnapshotReset(ds, pp.parity, ps);
+}
+
 int scTickRun(ScTickContext* c, uint32_t flags)
 {
   if (!c) return 0;
@@ -1111,21 +1125,30 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   const uint32_t q = (flags & SC_TICK_BROADPHASE) ? c->parity : 0u;
   const bool sampledTick = c->profiling && (c->tickIndex % c->profPeriod) == 0;     // events need eager launches
   if (c->graphMode && !sampledTick) {
-    const bool stale = !c->graphExec[q] || c->graphEpoch[q] != c->topoEpoch || std::memcmp(&p, &c->graphParams[q], sizeof p) != 0;
+    const bool stale = !c->graphExec[q] || c->graphEpoch[q] != c->topoEpoch || std::memcmp(&p, &c->graphParams[q], sizeof p) != 0 || c->graphWhole[q] != c->captureWholeStep;
     if (stale) {
       dropGraph(c, (int)q);
-      HIP_OK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      // whole-step capture (scTickTileStep on a tile with neighbours): the RCCL group and the pair half join the graph, so a
+      // step of an in-order tile is ONE hipGraphLaunch.  RCCL operations are captured in relaxed mode (they touch the
+      // communicator's own resources from inside the capture).
+      const bool whole = c->captureWholeStep;
+      HIP_OK(c, hipStreamBeginCapture(c->stream, whole ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
       enqueueStages(c, p, grid, false);
-      HIP_OK(c, hipStreamEndCapture(c->stream, &c->graph[q]));
+      int okx = 1;
+      if (whole) { okx = exchangeBorders(c, p.parity, c->stream); if (okx) enqueuePairHalf(c, p, c->stream, false); }
+      const hipError_t ce = hipStreamEndCapture(c->stream, &c->graph[q]);
+      if (!okx) { if (c->graph[q]) { hipGraphDestroy(c->graph[q]); c->graph[q] = nullptr; } return 0; }       // (the RCCL error text is already set)
+      if (ce != hipSuccess) return fail(c, "hipStreamEndCapture", ce);
       HIP_OK(c, hipGraphInstantiate(&c->graphExec[q], c->graph[q], nullptr, nullptr, 0));
-      c->graphParams[q] = p; c->graphEpoch[q] = c->topoEpoch;
+      c->graphParams[q] = p; c->graphEpoch[q] = c->topoEpoch; c->graphWhole[q] = whole;
     }
     HIP_OK(c, hipGraphLaunch(c->graphExec[q], c->stream));
   } else {
     enqueueStages(c, p, grid, true);
   }
   if (flags & SC_TICK_BROADPHASE) {
-    if (flags & SC_TICK_SPLIT_PAIRS) { c->pairsPending = true; c->pendingParams = p; }
+    const bool pairHalfDone = c->graphMode && !sampledTick && c->captureWholeStep;
+    if ((flags & SC_TICK_SPLIT_PAIRS) && !pairHalfDone) { c->pairsPending = true; c->pendingParams = p; }
     else { c->lastParity = c->parity; c->parity ^= 1u; }           // (in-order flows alternate between two copies)
   }
   c->tickIndex++;
@@ -1140,18 +1163,14 @@ int scTickRunPairs(ScTickContext* c)
   if (!bind(c)) return 0;
   if (!c->pairsPending) return fail(c, "scTickRunPairs without a preceding scTickRun(... | SC_TICK_BROADPHASE | SC_TICK_SPLIT_PAIRS)");
   const uint32_t q = c->pendingParams.parity;
-  const DeviceState ds = stateFor(c, q);
   hipStream_t ps = c->pairsStream ? c->pairsStream : c->stream;
-  launchBorderMerge(ds, c->pendingParams, ps);
-  if (c->pendingParams.flags & SC_TICK_RAYS) launchRayQueries(ds, c->pendingParams, c->rays, ps);   // sees the neighbours' border boxes too
   if (c->pairsStream) {
-    launchPairs(ds, c->pendingParams, ps);
-    launchSnapshotReset(ds, q, ps);
+    enqueuePairHalf(c, c->pendingParams, ps, true);
     HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
     c->pairsInFlight[q] = true;
   } else {
     Scoped s(c, SC_TICK_K_PAIRS);
-    launchPairs(ds, c->pendingParams, ps);
+    enqueuePairHalf(c, c->pendingParams, ps, false);
   }
   c->pairsPending = false;
   c->lastParity = c->parity;
@@ -1996,6 +2015,19 @@ int scTickTileStep(ScTickContext* c, uint32_t flags)
   static const bool prof = std::getenv("SC_TICK_HOSTPROF") != nullptr;
   static double acc[3] = { 0, 0, 0 }; static uint64_t calls = 0;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  if (c->graphMode && !c->pairsStream) {
+    // in-order tile, graph replay: the whole step -- producer, fused kernel, compaction + pack, the RCCL group, merge, pair
+    // search -- is captured once per tick parity and replayed with one hipGraphLaunch
+    c->captureWholeStep = true;
+    const int okr = scTickRun(c, flags | SC_TICK_SPLIT_PAIRS);
+    c->captureWholeStep = false;
+    if (!okr) return 0;
+    if (c->pairsPending) {                 // a sampled (profiled) tick ran eagerly: finish it the eager way
+      if (!exchangeBorders(c, c->pendingParams.parity, c->stream)) return 0;
+      return scTickRunPairs(c);
+    }
+    return 1;
+  }
   const double t0 = prof ? now() : 0.0;
   if (!scTickRun(c, flags | SC_TICK_SPLIT_PAIRS)) return 0;
   const double t1 = prof ? now() : 0.0;

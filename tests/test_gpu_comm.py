@@ -37,8 +37,11 @@ def keys(t):
     return np.sort(p[:, 0].astype(np.uint64) << np.uint64(32) | p[:, 1].astype(np.uint64))
 
 
-@pytest.mark.parametrize("pipelined", [False, True])
-def test_rccl_loopback_equals_device_copy_loopback(pipelined):
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("pipelined,graph", [(False, False), (True, False), (False, True)])
+def test_rccl_loopback_equals_device_copy_loopback(pipelined, graph):
+    """graph=True: the in-order tile step of A -- fused kernel, compaction + pack, the RCCL group, merge, pair search -- is
+    captured once per tick parity and replayed with one hipGraphLaunch (BASELINE config 5: "hipGraph-captured frame")."""
     import torch
     w = centre_tile_world()
     vp = camera_view_proj(w.camera)
@@ -50,6 +53,7 @@ def test_rccl_loopback_equals_device_copy_loopback(pipelined):
     a.set_tile(RANK, 0xFF); a.set_tile_grid(1, 1, 3, 3)
     a.comm_init(capi.comm_unique_id(), 1, 0, peers=[0] * 8)
     a.set_pipelined(pipelined)
+    a.set_graph_mode(graph)
     # B: the twin, messages moved by device copies
     b = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 17)
     b.set_view_proj(vp)
