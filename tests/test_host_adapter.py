@@ -38,3 +38,22 @@ def test_adapter_systems_match_the_oracle_frame_by_frame():
     r = subprocess.run([BIN, "20000"], capture_output=True, text=True, timeout=300)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "all checks passed" in r.stdout
+
+
+TILE_BIN = os.path.join(ROOT, "tests", "host", "test_tile_host")
+
+
+def test_native_tile_host_builds():
+    build()
+    assert os.path.exists(TILE_BIN)
+
+
+@pytest.mark.gpu
+def test_native_tile_host_runs_the_library_owned_exchange():
+    """A C++-only host: communicator from the library (loop-back on one GPU), pipelined scTickTileStep, checked against the oracle."""
+    if not os.path.exists(TILE_BIN):
+        build()
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([TILE_BIN, "32", "40"], capture_output=True, text=True, timeout=300, env=env)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "all checks passed" in r.stdout
