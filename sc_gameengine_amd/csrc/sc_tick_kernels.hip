@@ -855,6 +855,7 @@ __device__ __forceinline__ bool ownsSector(const TickParams& p, float gx, float 
 
 constexpr uint32_t kPairTabSize = kBinCap * (kBinCap - 1) / 2;
 constexpr uint32_t kFineThreshold = 24;      // bins with more records than this use the 4x4 cell grid
+constexpr uint32_t kCastMax = 20;            // up to this many self-compatible (dynamic) records per bin are broadcast one by one
 
 // pair predicate shared by both search paths: group/mask filter, closed-interval overlap, and "this sector
 // holds the low corner of the intersection" (so the pair is reported from exactly one bin)
@@ -903,10 +904,12 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   const uint32_t runLog = p.pairRunLog2, runLen = 1u << runLog, runsPerRound = 64u >> runLog;
   for (uint32_t round = 0; ((round * runsPerRound) * totalWaves + waveGlobal) << runLog < sectors; ++round) {
     const uint32_t mySector = (((round * runsPerRound + (lane >> runLog)) * totalWaves + waveGlobal) << runLog) + ((lane + waveGlobal) & (runLen - 1u));
-    uint32_t myCount = 0;
+    uint32_t myCount = 0, myLay = 0;
+    const uint32_t myGx = mySector % p.binSX, myGz = mySector / p.binSX;     // once per 64 sectors, not once per sector
     if (mySector < sectors) {
       myCount = d.binCount[mySector];
       const uint32_t lay = d.binLayers[mySector];      // requested together with the count: one round trip, not two
+      myLay = lay;
       if (myCount) {
         d.binCount[mySector] = 0u; d.binLayers[mySector] = 0u;
         // no record of this bin can pass the group/mask filter against another one: nothing to read
@@ -926,6 +929,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     uint32_t n = __shfl(myCount, it, 64), nTrue = __shfl(myTrue, it, 64);
     float4 rmin = make_float4(0, 0, 0, 0), rmax = make_float4(0, 0, 0, 0);
     uint32_t s = __shfl(mySector, it, 64);            // (cross-lane reads stay outside divergent code: every lane takes part)
+    uint32_t gx = __shfl(myGx, it, 64), gz = __shfl(myGz, it, 64), binLay = __shfl(myLay, it, 64);
     if (lane < n) {
       const float4* r = d.bins + 2u * ((size_t)s * kBinCap + lane);
       rmin = r[0]; rmax = r[1];
@@ -935,11 +939,12 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       const int itNext = rest ? __ffsll((long long)rest) - 1 : -1;
       uint32_t nNext = 0, nTrueNext = 0;
       float4 nmin = make_float4(0, 0, 0, 0), nmax = make_float4(0, 0, 0, 0);
-      uint32_t sNext = 0;
+      uint32_t sNext = 0, gxNext = 0, gzNext = 0, binLayNext = 0;
       if (itNext >= 0) {
         rest &= ~(1ull << itNext);
         nNext = __shfl(myCount, itNext, 64); nTrueNext = __shfl(myTrue, itNext, 64);
         sNext = __shfl(mySector, itNext, 64);
+        gxNext = __shfl(myGx, itNext, 64); gzNext = __shfl(myGz, itNext, 64); binLayNext = __shfl(myLay, itNext, 64);
         if (lane < nNext) {
           const float4* r = d.bins + 2u * ((size_t)sNext * kBinCap + lane);
           nmin = r[0]; nmax = r[1];
@@ -951,7 +956,6 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       // pairs whose low corner lies there (it received these boxes through the border exchange)
       bool ours = true;
       {
-        const uint32_t gx = s % p.binSX, gz = s / p.binSX;
         const int dx = gx == 0 ? -1 : (gx == p.binSX - 1u ? 1 : 0), dz = gz == 0 ? -1 : (gz == p.binSZ - 1u ? 1 : 0);
         if ((dx != 0 && hasNb(p, dx, 0)) || (dz != 0 && hasNb(p, 0, dz))) ours = false;    // nearest tile is not this one
       }
@@ -961,15 +965,52 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       // against ANY other record of this bin is dropped before the box tests, and a bin without a single
       // admissible record (e.g. only static props: group 2 / mask 1) is skipped altogether.  The reported
       // pair set is unchanged -- the filter is part of the pair predicate either way.
-      uint32_t lay = valid ? __float_as_uint(rmin.w) : 0u;
-      uint32_t all = lay;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) all |= (uint32_t)__shfl_xor((int)all, o, 64);
+      // (the OR of the bin's layer words comes with the bin: the summary the fused kernel keeps -- it may hold a record more
+      //  than the tile does (overflow), which only makes this pre-filter a little weaker; pairHit applies the filter itself)
+      const uint32_t lay = valid ? __float_as_uint(rmin.w) : 0u;
+      const uint32_t all = binLay;
       const bool admissible = valid && ((lay & 0xFFFFu) & (all >> 16)) != 0u && ((all & 0xFFFFu) & (lay >> 16)) != 0u;
       const unsigned long long validMask = __ballot(admissible);
       const bool anyPairs = __popcll(validMask) >= 2;
-      const float secX = (float)(s % p.binSX), secZ = (float)(s / p.binSX);
-      if (anyPairs) {
+      const float secX = (float)gx, secZ = (float)gz;
+      // Who can collide at all?  Under Bullet's filter most boxes of a city are static bodies (group 2 / mask 1), which never
+      // pass against each other; the pairs worth testing are (record that passes against its own kind) x (any admissible
+      // record).  So the records that pass against their own layer word -- dynamic bodies -- are broadcast one after the
+      // other from LDS and every lane tests its own record against the broadcast one: D iterations for D dynamic records,
+      // all lanes busy, conflict-free LDS reads, instead of n(n-1)/2 table-driven pairs of which static-static ones only
+      // fail the filter.  It covers every pair unless two records that do NOT pass against their own kind pass against each
+      // other (say 4/8 against 8/4): the OR of those records' layer words tells; then the general paths below run.
+      const bool selfOk = admissible && filterPass(lay, lay);
+      const unsigned long long castMask = __ballot(selfOk);
+      // the other admissible records: when they all carry ONE layer word (the usual case: static props) they cannot pass
+      // against each other -- that word does not pass against itself; only a mix pays for the OR over the lanes
+      const unsigned long long others = __ballot(admissible && !selfOk);
+      bool crossPossible = false;
+      if (others) {
+        const uint32_t first = (uint32_t)__shfl((int)lay, __ffsll((long long)others) - 1, 64);
+        if (__ballot(admissible && !selfOk && lay != first)) {
+          uint32_t rest2 = (admissible && !selfOk) ? lay : 0u;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) rest2 |= (uint32_t)__shfl_xor((int)rest2, o, 64);
+          crossPossible = ((rest2 & 0xFFFFu) & (rest2 >> 16)) != 0u;
+        }
+      }
+      const bool castPath = (uint32_t)__popcll(castMask) <= kCastMax && !crossPossible;
+      if (anyPairs && castPath) {
+        T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long cm = castMask;
+        while (cm) {
+          const uint32_t c = (uint32_t)__ffsll((long long)cm) - 1u;
+          cm &= cm - 1ull;
+          const float4 tmin = T[2u * c], tmax = T[2u * c + 1u];
+          const bool cand = admissible && lane != c && (!selfOk || lane < c);      // two broadcast records meet once
+          if (!__ballot(cand && boxesOverlap(rmin, rmax, tmin, tmax))) continue;
+          uint32_t ia = 0, ib = 0;
+          const bool hit = cand && pairHit(p, rmin, rmax, tmin, tmax, secX, secZ, ia, ib);
+          sinkPush(d, p, sink, hit, ia, ib);
+        }
+      } else if (anyPairs) {
         T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
         __builtin_amdgcn_wave_barrier();
         if (n <= kFineThreshold) {
@@ -1119,7 +1160,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
         }
       }
       __builtin_amdgcn_wave_barrier();
-      it = itNext; n = nNext; nTrue = nTrueNext; s = sNext; rmin = nmin; rmax = nmax;
+      it = itNext; n = nNext; nTrue = nTrueNext; s = sNext; gx = gxNext; gz = gzNext; binLay = binLayNext; rmin = nmin; rmax = nmax;
     }
   }
 

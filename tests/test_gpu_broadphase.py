@@ -212,3 +212,19 @@ def test_one_sector_far_beyond_its_capacity_is_counted_not_silent(oracle):
     c = t.counts()
     assert c.bin_overflow >= 1400 and c.border_lost >= 1500 - 64 - 1024 - 40      # what the sector cannot hold is reported
     t.close()
+
+
+def test_layers_that_only_pass_across_kinds(oracle):
+    """Records that do not pass the filter against their own kind but do against another (4/8 vs 8/4) next to ordinary static
+    and dynamic ones: the pair search's broadcast path cannot cover those, the general paths must (and do)."""
+    w = worlds.random_world(4000, seed=51, spread=120.0, p_child=0.0, p_no_bounds=0.0)
+    rng = np.random.default_rng(6)
+    kind = rng.integers(0, 5, w.n)
+    w.group[:] = np.choose(kind, [1, 2, 4, 8, 2]).astype(np.uint32)
+    w.mask[:] = np.choose(kind, [0xFFFFFFFF, 1, 8, 4, 1]).astype(np.uint32)
+    t, ow = gpu_vs_oracle(oracle, w, ticks=2, nudge=0.8)
+    got, _ = t.pairs()
+    k = {(int(w.group[a]), int(w.group[b])) for a, b in got[:2000]}
+    assert (4, 8) in k or (8, 4) in k                      # such pairs really occur
+    assert (2, 2) not in k
+    t.close(); ow.close()

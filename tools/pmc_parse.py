@@ -22,7 +22,7 @@ def load(dirname, counter):
 
 
 def short(name):
-    for k in ("k_xform_cull", "k_pairs", "k_compact", "k_nudge_roots_x", "calib_copy_dword", "calib_copy_float4", "calib_soa13_to_rows"):
+    for k in ("k_xform_cull", "k_compact_pairs", "k_compact_pack", "k_pairs", "k_compact", "k_emit_draws_staged", "k_nudge_roots_x", "calib_copy_dword", "calib_copy_float4", "calib_soa13_to_rows"):
         if k in name:
             return k
     return None
@@ -44,13 +44,14 @@ def main(out):
                 continue
             vals = vals[len(vals) // 4:]                      # drop warm-up launches
             mean = sum(vals) / len(vals)
-            shape = "calib_soa13_to_rows" if s == "k_xform_cull" else "calib_copy_float4" if s == "k_pairs" else "calib_copy_dword"
+            shape = "calib_soa13_to_rows" if s == "k_xform_cull" else "calib_copy_float4" if s in ("k_pairs", "k_emit_draws_staged") else "calib_copy_dword"
             unit = res["calibration"].get(shape, {}).get(counter, {}).get("bytes_per_count")
             res["kernels"].setdefault(s, {})[counter] = {"counter_mean": mean, "launches": len(vals), "calibrated_with": shape,
                                                           "bytes_per_launch": mean * unit if unit else None}
     for s, k in res["kernels"].items():
         if all(k.get(c, {}).get("bytes_per_launch") is not None for c in ("FETCH_SIZE", "WRITE_SIZE")):
             k["hbm_bytes_per_launch"] = k["FETCH_SIZE"]["bytes_per_launch"] + k["WRITE_SIZE"]["bytes_per_launch"]
+    res["bench_config"] = {"stages": ["xform", "cull", "broadphase"], "entities_per_gpu": 1048576, "workload": os.environ.get("PMC_WORKLOAD", "config3")}
     json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))
 
