@@ -185,7 +185,10 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C sc_gameengine_amd/csrc).  There is no CPU fallback for the tick path.")
     lib = C.CDLL(LIB_PATH)
+    lax = bool(os.environ.get("SC_TICK_LAX_BIND"))     # tools/ab_step.py only: A/B against a build of an older commit
     for name, (res, args) in SYMBOLS.items():
+        if lax and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args

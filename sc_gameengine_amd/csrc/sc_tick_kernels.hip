@@ -14,6 +14,13 @@
 
 namespace sctick {
 
+// The pair role is bound by instruction issue and LDS latency: five waves per SIMD hide it measurably better than four
+// (config 5: 66 -> 55 us for the end-of-tick kernel).  Its rarely entered overflow phase would push the allocation to 107
+// VGPRs (four waves); held to five waves the compiler spills eight dwords instead, on that rare path.
+#ifndef SC_PAIR_OCC
+#define SC_PAIR_OCC __attribute__((amdgpu_waves_per_eu(5, 5)))
+#endif
+
 // ------------------------------------------------------------------------------------------
 // 3x4 affine helpers.  Row r of the world matrix is (M[r,0], M[r,1], M[r,2], M[r,3]); the
 // reference's column-major Mat4 has m[c*4+r] == M[r,c] and a constant last row (0,0,0,1).
@@ -628,9 +635,9 @@ __device__ __forceinline__ bool moverPosition(const DeviceState& d, uint32_t i, 
   const bool in = i < n;
   // everything is requested at once (one round trip); non-movers just drop what they fetched
   const uint32_t kind = in ? d.moverKind[i] : 0u;
-  if (kind == kMoverTraffic) return trafficAgentStep(d, i, dt, smooth, mult);
   float vx = 0, vz = 0, lox = 0, loz = 0, hix = 0, hiz = 0, x = 0, z = 0;
   if (in) { vx = d.mvx[i]; vz = d.mvz[i]; lox = d.mlox[i]; loz = d.mloz[i]; hix = d.mhix[i]; hiz = d.mhiz[i]; x = d.px[i]; z = d.pz[i]; }
+  if (kind == kMoverTraffic) return trafficAgentStep(d, i, dt, smooth, mult);      // (behind the loads: they must not wait for `kind`)
   if (kind) {
     x = x + vx * dt; z = z + vz * dt;
     if (kind == 1u) {
@@ -1120,9 +1127,13 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
           const bool has = q < m;
           float4 xmin = make_float4(0, 0, 0, 0), xmax = make_float4(0, 0, 0, 0);
           if (has) { const uint32_t e = ovfIdx[q]; xmin = d.spill[2u * (size_t)e]; xmax = d.spill[2u * (size_t)e + 1u]; }
-          // against the bin's records (still in registers: stage them)
+          // against the bin's records (re-read from the bin, L2-hot, rather than kept in registers across this rare phase)
           __builtin_amdgcn_wave_barrier();
-          T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
+          {
+            const float4* rec = d.bins + 2u * ((size_t)s * kBinCap + lane);
+            const float4 zero = make_float4(0, 0, 0, 0);
+            T[2u * lane] = lane < n ? rec[0] : zero; T[2u * lane + 1u] = lane < n ? rec[1] : zero;
+          }
           __builtin_amdgcn_wave_barrier();
           for (uint32_t j = 0; j < n; ++j) {
             // most boxes of a sector do not touch: the interval test alone decides, the rest only runs when some lane passes it
@@ -1188,7 +1199,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   sinkFlush(d, p, sink);
 }
 
-__global__ __launch_bounds__(kTile) void k_pairs(const DeviceState d, const TickParams p)
+__global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_pairs(const DeviceState d, const TickParams p)
 {
   __shared__ float4 tile[kTile / 64][2 * kBinCap];        // 2 KiB per wave: the bin as an LDS tile
   __shared__ uint16_t pairTab[kPairTabSize];              // q -> (i << 8 | j), 0 <= j < i < 64
@@ -1218,7 +1229,7 @@ __global__ __launch_bounds__(kTile) void k_gather_pairs(const DeviceState d, con
 }
 
 // compaction and pair search both depend only on the fused kernel: one launch, workgroups split by role
-__global__ __launch_bounds__(kTile) void k_compact_pairs(const DeviceState d, const TickParams p, uint32_t compactBlocks, uint32_t group)
+__global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_compact_pairs(const DeviceState d, const TickParams p, uint32_t compactBlocks, uint32_t group)
 {
   __shared__ float4 tile[kTile / 64][2 * kBinCap];
   __shared__ uint16_t pairTab[kPairTabSize];
