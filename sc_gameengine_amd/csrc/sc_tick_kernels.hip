@@ -670,8 +670,18 @@ __device__ __forceinline__ uint32_t blockSum(uint32_t v, uint32_t* scratch)
 
 // `group`: how many of the fused kernel's spans one compaction workgroup takes (their counts are summed here; fewer,
 // longer workgroups keep the whole end-of-tick kernel resident at once).
+//
+// The role is a handful of small dependent steps, so what it costs is memory round trips, not bytes.  Everything it reads is
+// therefore requested up front, before anything is stored (a store to a stream keeps the compiler from hoisting later loads of
+// that stream above it): the dirty / unreachable words, the producer's inputs for several tiles at once, the predecessors'
+// counts, and ONE visibility word per thread for the whole width (a word = one wave-tile of the fused kernel).  Then: block
+// scan of the words' popcounts -> (word, offset) pairs in LDS -> every thread scatters its own entities.  `words` is LDS
+// scratch of kCompactLdsWords dwords.
+constexpr uint32_t kCompactWordsMax = kTile;                  // visibility words (64 entities each) one workgroup handles the fast way
+constexpr uint32_t kCompactLdsWords = kCompactWordsMax * 6u;  // per word: vis (2 dwords), culled (2), offsets (2)
+
 __device__ __forceinline__ void compactBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks, uint32_t group,
-                                            uint32_t* scratch, uint32_t* moved)
+                                            uint32_t* scratch, uint32_t* moved, uint32_t* words)
 {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
@@ -681,28 +691,59 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
   const bool doCull = (p.flags & SC_TICK_CULL) != 0;
   const bool doCulled = (p.flags & SC_TICK_CULLED_LIST) != 0;
 
-  // requested before the prefix is known, so they travel together with the count loads
+  // ---- requests first
   const uint32_t wBegin = begin >> 5, wEnd = (end + 31u) >> 5;
   uint32_t dirtyKeep = 0; const uint32_t dirtyWord = wBegin + threadIdx.x;
   const bool clearDirty = (p.flags & SC_TICK_XFORM) && dirtyWord < wEnd;
   if (clearDirty) dirtyKeep = d.dirty[dirtyWord] & d.unreach[dirtyWord];
 
+  const uint32_t vBegin = begin >> 6, vEnd = (end + 63u) >> 6, vWords = vEnd - vBegin;
+  const bool fast = doCull && vWords <= kCompactWordsMax;
+  unsigned long long myVis = 0ull, myCul = 0ull;
+  if (fast && threadIdx.x < vWords) {
+    myVis = d.vis[vBegin + threadIdx.x];
+    if (doCulled) myCul = d.cand[vBegin + threadIdx.x] & ~myVis;
+  }
+  uint32_t pv = 0, pc = 0;
+  if (doCull) for (uint32_t j = threadIdx.x; j < bid * group; j += kTile) { pv += d.blockVis[j]; pc += d.blockCand[j]; }
+
   // SC_TICK_PRODUCE_NEXT: this tick is over for the span, so the NEXT frame's producer runs here instead of as a
-  // launch of its own.  Its position loads and stores go out first, alongside the loads above (nothing else in this
-  // kernel reads positions); the "moved" ballots wait in LDS and are OR-ed into the cleared dirty words below.
+  // launch of its own (nothing else in this kernel reads positions); the "moved" ballots wait in LDS and are OR-ed into
+  // the cleared dirty words below.
   const bool produce = (p.flags & SC_TICK_PRODUCE_NEXT) != 0;
   const bool produceEarly = produce && (wEnd - wBegin) <= kMaxSpanWords;
   if (produceEarly) {
-    for (uint32_t base = begin; base < end; base += kTile) {
-      const unsigned long long m = __ballot(producePosition(d, p, base + threadIdx.x));
-      if (lane == 0) { moved[((base >> 5) - wBegin) + 2u * wave] = (uint32_t)m; moved[((base >> 5) - wBegin) + 2u * wave + 1u] = (uint32_t)(m >> 32); }
+    if (p.producerKind == 1u) {
+      // root nudge: link word and x of four tiles are requested together, then written
+      constexpr uint32_t kBatch = 4;
+      for (uint32_t base = begin; base < end; base += kBatch * kTile) {
+        uint32_t lk[kBatch]; float x[kBatch];
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; ++u) {
+          const uint32_t i = base + u * kTile + threadIdx.x;
+          const bool in = i < end;
+          lk[u] = in ? d.link[i] : ((kUnreachable << kDepthShift) | 1u);
+          x[u] = in ? d.px[i] : 0.0f;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; ++u) {
+          const uint32_t tileBase = base + u * kTile, i = tileBase + threadIdx.x;
+          const bool root = i < end && (lk[u] & kParentMask) == kNoParent && linkDepth(lk[u]) != kUnreachable;
+          if (root) d.px[i] = x[u] + p.producerParam;
+          const unsigned long long m = __ballot(root);
+          if (lane == 0 && tileBase < end) { moved[((tileBase >> 5) - wBegin) + 2u * wave] = (uint32_t)m; moved[((tileBase >> 5) - wBegin) + 2u * wave + 1u] = (uint32_t)(m >> 32); }
+        }
+      }
+    } else {
+      for (uint32_t base = begin; base < end; base += kTile) {
+        const unsigned long long m = __ballot(producePosition(d, p, base + threadIdx.x));
+        if (lane == 0) { moved[((base >> 5) - wBegin) + 2u * wave] = (uint32_t)m; moved[((base >> 5) - wBegin) + 2u * wave + 1u] = (uint32_t)(m >> 32); }
+      }
     }
     __syncthreads();
   }
 
   if (doCull) {
-    uint32_t pv = 0, pc = 0;
-    for (uint32_t j = threadIdx.x; j < bid * group; j += kTile) { pv += d.blockVis[j]; pc += d.blockCand[j]; }
     uint32_t visBase = blockSum(pv, scratch);
     uint32_t culBase = blockSum(pc, scratch) - visBase;
     if (bid == nblocks - 1 && threadIdx.x == 0) {
@@ -713,31 +754,68 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
       d.counters[1] = tc - tv;       // CullingStats::culled
       d.counters[6] = tc;            // renderablesTotal
     }
-    const uint32_t nWords = (p.n + 63u) >> 6;
-    for (uint32_t base = begin; base < end; base += kTile) {
-      const uint32_t w0 = base >> 6;
-      unsigned long long m[4], c[4];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (fast) {
+      // exclusive scan of the words' popcounts over the workgroup (one word per thread)
+      uint32_t cv = (uint32_t)__popcll(myVis), cc = (uint32_t)__popcll(myCul);
+      uint32_t iv = cv, ic = cc;
 #pragma unroll
-      for (uint32_t k = 0; k < 4; ++k) {
-        const bool ok = (w0 + k) < nWords;
-        m[k] = ok ? d.vis[w0 + k] : 0ull;
-        c[k] = (doCulled && ok) ? (d.cand[w0 + k] & ~m[k]) : 0ull;
+      for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t uv = __shfl_up(iv, o, 64), uc = __shfl_up(ic, o, 64);
+        if (lane >= o) { iv += uv; ic += uc; }
       }
-      uint32_t off = visBase, coff = culBase;
+      __syncthreads();                                   // (blockSum's readers are done with `scratch`)
+      if (lane == 63u) scratch[wave] = iv | (ic << 16);    // a wave holds at most 64 x 64 = 4096 of either: 16 bits each
+      __syncthreads();
+      uint32_t bv = visBase, bc = culBase;
+      for (uint32_t k = 0; k < wave; ++k) { bv += scratch[k] & 0xFFFFu; bc += scratch[k] >> 16; }
+      unsigned long long* sVis = reinterpret_cast<unsigned long long*>(words);
+      unsigned long long* sCul = sVis + kCompactWordsMax;
+      uint32_t* sOffV = words + 4u * kCompactWordsMax;
+      uint32_t* sOffC = sOffV + kCompactWordsMax;
+      if (threadIdx.x < vWords) {
+        sVis[threadIdx.x] = myVis; sOffV[threadIdx.x] = bv + iv - cv;
+        if (doCulled) { sCul[threadIdx.x] = myCul; sOffC[threadIdx.x] = bc + ic - cc; }
+      }
+      __syncthreads();
+      for (uint32_t base = begin; base < end; base += kTile) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t wi = (i >> 6) - vBegin;           // this thread's wave-tile
+        if (wi < vWords) {
+          const unsigned long long m = sVis[wi];
+          if ((m >> lane) & 1ull) d.visibleIdx[sOffV[wi] + (uint32_t)__popcll(m & below)] = i;
+          if (doCulled) {
+            const unsigned long long c = sCul[wi];
+            if ((c >> lane) & 1ull) d.culledIdx[sOffC[wi] + (uint32_t)__popcll(c & below)] = i;
+          }
+        }
+      }
+    } else {
+      const uint32_t nWords = (p.n + 63u) >> 6;
+      for (uint32_t base = begin; base < end; base += kTile) {
+        const uint32_t w0 = base >> 6;
+        unsigned long long m[4], c[4];
 #pragma unroll
-      for (uint32_t k = 0; k < 4; ++k) {
-        if (k < wave) { off += (uint32_t)__popcll(m[k]); coff += (uint32_t)__popcll(c[k]); }
-      }
-      const unsigned long long mine = (wave == 0) ? m[0] : (wave == 1) ? m[1] : (wave == 2) ? m[2] : m[3];
-      const unsigned long long below = (1ull << lane) - 1ull;
-      const uint32_t i = base + threadIdx.x;
-      if ((mine >> lane) & 1ull) d.visibleIdx[off + (uint32_t)__popcll(mine & below)] = i;
-      if (doCulled) {
-        const unsigned long long cm = (wave == 0) ? c[0] : (wave == 1) ? c[1] : (wave == 2) ? c[2] : c[3];
-        if ((cm >> lane) & 1ull) d.culledIdx[coff + (uint32_t)__popcll(cm & below)] = i;
-      }
+        for (uint32_t k = 0; k < 4; ++k) {
+          const bool ok = (w0 + k) < nWords;
+          m[k] = ok ? d.vis[w0 + k] : 0ull;
+          c[k] = (doCulled && ok) ? (d.cand[w0 + k] & ~m[k]) : 0ull;
+        }
+        uint32_t off = visBase, coff = culBase;
 #pragma unroll
-      for (uint32_t k = 0; k < 4; ++k) { visBase += (uint32_t)__popcll(m[k]); culBase += (uint32_t)__popcll(c[k]); }
+        for (uint32_t k = 0; k < 4; ++k) {
+          if (k < wave) { off += (uint32_t)__popcll(m[k]); coff += (uint32_t)__popcll(c[k]); }
+        }
+        const unsigned long long mine = (wave == 0) ? m[0] : (wave == 1) ? m[1] : (wave == 2) ? m[2] : m[3];
+        const uint32_t i = base + threadIdx.x;
+        if ((mine >> lane) & 1ull) d.visibleIdx[off + (uint32_t)__popcll(mine & below)] = i;
+        if (doCulled) {
+          const unsigned long long cm = (wave == 0) ? c[0] : (wave == 1) ? c[1] : (wave == 2) ? c[2] : c[3];
+          if ((cm >> lane) & 1ull) d.culledIdx[coff + (uint32_t)__popcll(cm & below)] = i;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) { visBase += (uint32_t)__popcll(m[k]); culBase += (uint32_t)__popcll(c[k]); }
+      }
     }
   }
 
@@ -760,7 +838,8 @@ __global__ __launch_bounds__(kTile) void k_compact(const DeviceState d, const Ti
 {
   __shared__ uint32_t scratch[kTile / 64];
   __shared__ uint32_t moved[kMaxSpanWords];
-  compactBody(d, p, blockIdx.x, gridDim.x, group, scratch, moved);
+  __shared__ uint32_t words[kCompactLdsWords];
+  compactBody(d, p, blockIdx.x, gridDim.x, group, scratch, moved, words);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1237,7 +1316,9 @@ __global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_compact_pairs(const Devic
   __shared__ unsigned long long cellMembers[kTile / 64][16];
   __shared__ uint32_t scratch[kTile / 64];
   __shared__ uint32_t moved[kMaxSpanWords];
-  if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, group, scratch, moved);
+  // (a workgroup plays one role: the compaction role borrows the pair role's tile area -- 8 KiB >= kCompactLdsWords dwords)
+  static_assert(sizeof(tile) >= kCompactLdsWords * sizeof(uint32_t), "compaction scratch does not fit the pair tiles");
+  if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, group, scratch, moved, reinterpret_cast<uint32_t*>(&tile[0][0]));
   else pairsBody(d, p, blockIdx.x - compactBlocks, gridDim.x - compactBlocks, tile, pairTab, pairBuf, cellMembers);
 }
 
@@ -1390,7 +1471,8 @@ __global__ __launch_bounds__(kTile) void k_compact_pack(const DeviceState d, con
 {
   __shared__ uint32_t scratch[kTile / 64];
   __shared__ uint32_t moved[kMaxSpanWords];
-  if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, group, scratch, moved);
+  __shared__ uint32_t words[kCompactLdsWords];
+  if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, group, scratch, moved, words);
   else borderPackBody(d, p, blockIdx.x - compactBlocks);
 }
 
