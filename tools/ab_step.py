@@ -39,8 +39,10 @@ flags = capi.FULL | capi.PRODUCE_NEXT
 
 ctxs = {}
 for path in args.libs:
+    lib_path, _, variant = path.partition("@")            # "lib.so@48": SC_TICK_VARIANT for this context (tuning knobs)
+    os.environ["SC_TICK_VARIANT"] = variant or "0"
     capi._LIB = None
-    capi.LIB_PATH = os.path.abspath(path)
+    capi.LIB_PATH = os.path.abspath(lib_path)
     t = WorldTick.from_world(w, broadphase=True)
     t.set_view_proj(vp)
     t.set_frame_producer(kind, param)
