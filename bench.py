@@ -317,10 +317,10 @@ def main():
     fence()
     # Kernel durations come from events that take the dispatch's own begin / end timestamps.  Timing a launch that way costs
     # about 12 us of extra gap per step (measured: 60.8 against 51.5 us per step with every step timed), so inside the timed
-    # region only every n-th step is timed (default 8th: >= 2 launches at 20 steps), and right after it -- same process,
+    # region only every n-th step is timed (default: every 8th, two launches in all for runs of 32 steps or fewer), and right after it -- same process,
     # same resident world, the next frames -- a second pass of the same length times EVERY launch.  Both averages are
     # reported; the roofline uses the every-launch pass.
-    sample = args.sample if args.sample > 0 else 8
+    sample = args.sample if args.sample > 0 else (8 if args.steps > 32 else max(args.steps // 2, 1))
     t.set_profiling(sample)
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -941,6 +941,7 @@ __device__ __forceinline__ bool ownsSector(const TickParams& p, float gx, float 
 
 constexpr uint32_t kPairTabSize = kBinCap * (kBinCap - 1) / 2;
 constexpr uint32_t kFineThreshold = 24;      // bins with more records than this use the 4x4 cell grid
+constexpr uint32_t kCellWords = 16u * (1u + kOvfPerSector / 64u);     // 4x4 cell masks for the bin tile and every overflow tile of a sector
 constexpr uint32_t kCastMax = 20;            // up to this many self-compatible (dynamic) records per bin are broadcast one by one
 
 // pair predicate shared by both search paths: group/mask filter, closed-interval overlap, and "this sector
@@ -957,7 +958,7 @@ __device__ __forceinline__ bool pairHit(const TickParams& p, const float4& amin,
 
 __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks,
                                           float4 (*tile)[2 * kBinCap], uint16_t* pairTab, uint2 (*pairBuf)[kWavePairBuf],
-                                          unsigned long long (*cellMembers)[16])
+                                          unsigned long long (*cellMembers)[kCellWords])
 {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
@@ -1200,41 +1201,62 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
         }
         if (m > kOvfPerSector) { if (lane == 0) atomicAdd(&d.counters[ctr + kCtrBorderLost], m - kOvfPerSector); m = kOvfPerSector; }
         __threadfence_block();                                  // the index row was written by other lanes of this wave
-        const uint32_t tiles = (m + 63u) / 64u;
-        for (uint32_t k = 0; k < tiles; ++k) {
-          const uint32_t q = k * 64u + lane;
-          const bool has = q < m;
-          float4 xmin = make_float4(0, 0, 0, 0), xmax = make_float4(0, 0, 0, 0);
-          if (has) { const uint32_t e = ovfIdx[q]; xmin = d.spill[2u * (size_t)e]; xmax = d.spill[2u * (size_t)e + 1u]; }
-          // against the bin's records (re-read from the bin, L2-hot, rather than kept in registers across this rare phase)
-          __builtin_amdgcn_wave_barrier();
-          {
+        // The sector's records as tiles of 64: tile 0 = the bin, tiles 1.. = its overflow records.  As in the dense-bin path
+        // the sector is cut into 4x4 cells; every tile keeps, per cell, the lanes whose box touches it (LDS, one 64-bit mask
+        // per tile and cell: any monotone cell function keeps every overlapping pair, clamping included).  A lane then meets
+        // only the records that share a cell with its own box: at the engine's 200 boxes per sector about a dozen per tile
+        // pair instead of 64.
+        const uint32_t tiles = (m + 63u) / 64u + 1u;
+        unsigned long long* CM = cellMembers[wave];
+        for (uint32_t t = lane; t < tiles * 16u; t += 64u) CM[t] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        const float ox = (secX + p.binOx) * 4.0f, oz = (secZ + p.binOz) * 4.0f, inv4 = p.invSector * 4.0f;
+        auto loadRec = [&](uint32_t t, float4& lo, float4& hi) -> bool {
+          lo = make_float4(0, 0, 0, 0); hi = make_float4(0, 0, 0, 0);
+          if (t == 0u) {
+            if (lane >= n) return false;
             const float4* rec = d.bins + 2u * ((size_t)s * kBinCap + lane);
-            const float4 zero = make_float4(0, 0, 0, 0);
-            T[2u * lane] = lane < n ? rec[0] : zero; T[2u * lane + 1u] = lane < n ? rec[1] : zero;
+            lo = rec[0]; hi = rec[1];
+            return true;
           }
-          __builtin_amdgcn_wave_barrier();
-          for (uint32_t j = 0; j < n; ++j) {
-            // most boxes of a sector do not touch: the interval test alone decides, the rest only runs when some lane passes it
-            const float4 tmin = T[2u * j], tmax = T[2u * j + 1u];
-            if (!__ballot(has && boxesOverlap(xmin, xmax, tmin, tmax))) continue;
-            uint32_t ia = 0, ib = 0;
-            const bool hit = has && pairHit(p, xmin, xmax, tmin, tmax, secX, secZ, ia, ib);
-            sinkPush(d, p, sink, hit, ia, ib);
-          }
-          // against the overflow tiles before this one, and against this one's earlier lanes
+          const uint32_t q = (t - 1u) * 64u + lane;
+          if (q >= m) return false;
+          const uint32_t e = ovfIdx[q];
+          lo = d.spill[2u * (size_t)e]; hi = d.spill[2u * (size_t)e + 1u];
+          return true;
+        };
+        auto cellRange = [&](const float4& lo, const float4& hi, int& cx0, int& cx1, int& cz0, int& cz1) {
+          cx0 = min(3, max(0, (int)floorf(lo.x * inv4 - ox))); cx1 = min(3, max(0, (int)floorf(hi.x * inv4 - ox)));
+          cz0 = min(3, max(0, (int)floorf(lo.z * inv4 - oz))); cz1 = min(3, max(0, (int)floorf(hi.z * inv4 - oz)));
+        };
+        for (uint32_t t = 0; t < tiles; ++t) {                   // registration
+          float4 lo, hi; int cx0, cx1, cz0, cz1;
+          const bool has = loadRec(t, lo, hi);
+          cellRange(lo, hi, cx0, cx1, cz0, cz1);
+          if (has) for (int cz = cz0; cz <= cz1; ++cz) for (int cx = cx0; cx <= cx1; ++cx) atomicOr(&CM[t * 16u + (uint32_t)(cz * 4 + cx)], 1ull << lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k = 1; k < tiles; ++k) {                   // (tile 0 against itself is the main path's work)
+          float4 xmin, xmax; int cx0, cx1, cz0, cz1;
+          const bool has = loadRec(k, xmin, xmax);
+          cellRange(xmin, xmax, cx0, cx1, cz0, cz1);
           for (uint32_t jt = 0; jt <= k; ++jt) {
             __builtin_amdgcn_wave_barrier();
             if (jt == k) { T[2u * lane] = xmin; T[2u * lane + 1u] = xmax; }
-            else { const uint32_t e = ovfIdx[jt * 64u + lane]; T[2u * lane] = d.spill[2u * (size_t)e]; T[2u * lane + 1u] = d.spill[2u * (size_t)e + 1u]; }
+            else { float4 lo, hi; loadRec(jt, lo, hi); T[2u * lane] = lo; T[2u * lane + 1u] = hi; }
             __builtin_amdgcn_wave_barrier();
-            const uint32_t cnt = (m - jt * 64u) < 64u ? (m - jt * 64u) : 64u;
-            for (uint32_t i = 0; i < cnt; ++i) {
-              const float4 tmin = T[2u * i], tmax = T[2u * i + 1u];
-              const bool cand = has && (jt < k || i < lane);
-              if (!__ballot(cand && boxesOverlap(xmin, xmax, tmin, tmax))) continue;
-              uint32_t ia = 0, ib = 0;
-              const bool hit = cand && pairHit(p, xmin, xmax, tmin, tmax, secX, secZ, ia, ib);
+            unsigned long long cand = 0ull;
+            if (has) {
+              for (int cz = cz0; cz <= cz1; ++cz) for (int cx = cx0; cx <= cx1; ++cx) cand |= CM[jt * 16u + (uint32_t)(cz * 4 + cx)];
+              if (jt == k) cand &= (1ull << lane) - 1ull;          // inside a tile: partners in lower lanes
+            }
+            while (__ballot(cand != 0ull)) {
+              bool hit = false; uint32_t ia = 0, ib = 0;
+              if (cand) {
+                const uint32_t i = (uint32_t)__ffsll((long long)cand) - 1u;
+                cand &= cand - 1ull;
+                hit = pairHit(p, xmin, xmax, T[2u * i], T[2u * i + 1u], secX, secZ, ia, ib);
+              }
               sinkPush(d, p, sink, hit, ia, ib);
             }
           }
@@ -1283,7 +1305,7 @@ __global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_pairs(const DeviceState d
   __shared__ float4 tile[kTile / 64][2 * kBinCap];        // 2 KiB per wave: the bin as an LDS tile
   __shared__ uint16_t pairTab[kPairTabSize];              // q -> (i << 8 | j), 0 <= j < i < 64
   __shared__ uint2 pairBuf[kTile / 64][kWavePairBuf];     // 2 KiB per wave: hits waiting for a flush
-  __shared__ unsigned long long cellMembers[kTile / 64][16];   // per wave: which records touch each of the 4x4 cells
+  __shared__ unsigned long long cellMembers[kTile / 64][kCellWords];   // per wave: which records touch each of the 4x4 cells, per tile of 64
   pairsBody(d, p, blockIdx.x, gridDim.x, tile, pairTab, pairBuf, cellMembers);
 }
 
@@ -1313,7 +1335,7 @@ __global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_compact_pairs(const Devic
   __shared__ float4 tile[kTile / 64][2 * kBinCap];
   __shared__ uint16_t pairTab[kPairTabSize];
   __shared__ uint2 pairBuf[kTile / 64][kWavePairBuf];
-  __shared__ unsigned long long cellMembers[kTile / 64][16];
+  __shared__ unsigned long long cellMembers[kTile / 64][kCellWords];
   __shared__ uint32_t scratch[kTile / 64];
   __shared__ uint32_t moved[kMaxSpanWords];
   // (a workgroup plays one role: the compaction role borrows the pair role's tile area -- 8 KiB >= kCompactLdsWords dwords)
