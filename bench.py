@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity gate (profiling sessions only; the line then says so)")
     ap.add_argument("--pipeline", type=int, default=1, help="N>1: pair-search half of tick t on a second stream under the fused kernel of tick t+1")
-    ap.add_argument("--control", default="gloo", help="torch.distributed backend of the CONTROL plane at N>1 (rendezvous of the RCCL id, barrier, "
+    ap.add_argument("--control", default="nccl", help="torch.distributed backend of the CONTROL plane at N>1 (rendezvous of the RCCL id, barrier, "
                                                        "max-over-ranks timing); the data path is the library's own RCCL communicator either way")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on one GPU: every rank uses GPU 0 and the messages move by host staging (no RCCL)")
     args = ap.parse_args()
@@ -235,12 +235,24 @@ def main():
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if args.same_device:
         local_rank = 0
+        args.control = "gloo"          # several ranks on one GPU cannot form an RCCL communicator
     torch.cuda.set_device(local_rank)
     if world_size > 1:
-        if args.control == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.control)
+        # stdout carries ONE JSON line; some backends announce themselves there ("[Gloo] Rank 0 is connected ..."): keep the
+        # descriptor pointed at stderr while the process group comes up
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.control == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(args.control)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     ctl_device = "cuda" if (world_size > 1 and args.control == "nccl") else "cpu"
 
     grid = tiles.tile_grid(world_size)

@@ -38,10 +38,11 @@ def keys(t):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("pipelined,graph", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("pipelined,graph", [(False, False), (True, False), (2, False), (4, False), (False, True)])
 def test_rccl_loopback_equals_device_copy_loopback(pipelined, graph):
     """graph=True: the in-order tile step of A -- fused kernel, compaction + pack, the RCCL group, merge, pair search -- is
-    captured once per tick parity and replayed with one hipGraphLaunch (BASELINE config 5: "hipGraph-captured frame")."""
+    captured once per tick parity and replayed with one hipGraphLaunch (BASELINE config 5: "hipGraph-captured frame").
+    pipelined = 2 / 4: that many copies of the per-tick broadphase state on A's side (True = the default, 3)."""
     import torch
     w = centre_tile_world()
     vp = camera_view_proj(w.camera)
