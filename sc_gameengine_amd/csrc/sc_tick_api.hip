@@ -592,7 +592,8 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
   c->maxPairs = desc->max_pairs ? desc->max_pairs : desc->capacity * 4u;
   c->maxPairs = ((c->maxPairs + kPairShards - 1u) / kPairShards) * kPairShards;   // equal shard segments
   if (ok && c->sectors) {
-    if ((uint64_t)desc->tile_sectors_x * desc->tile_sectors_z > (1u << 24)) ok = fail(c, "tile rectangle too large");
+    if ((uint64_t)desc->tile_sectors_x * desc->tile_sectors_z > (1u << 24) || desc->tile_sectors_x > 65533u || desc->tile_sectors_z > 65533u)
+      ok = fail(c, "tile rectangle too large");           // (the pair search carries a sector's grid coordinates as 16 + 16 bits)
     ok = ok && dalloc(c, d.binCount, c->sectors) && dalloc(c, d.binLayers, c->sectors) && dalloc(c, d.bins, (size_t)c->sectors * kBinCap * 2u, false)
             && dalloc(c, d.bigList, (N + 8u * kBorderBigCap) * 2u, false) && dalloc(c, d.spill, 2u * N, false) && dalloc(c, d.spillSector, N)
             && dalloc(c, d.ovfIdx, (size_t)kOvfWaves * kOvfPerSector, false) && dalloc(c, d.ovfLo, c->sectors, false) && dalloc(c, d.ovfHi, c->sectors)

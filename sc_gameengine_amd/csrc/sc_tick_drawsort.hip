@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kTile) void k_draw_keys(const DeviceState d, const 
       st.key[0][t] = key;
       st.idx[0][t] = t;
     }
-    const uint64_t okLanes = __ballot(ok);
+    const uint64_t okLanes = ballot64(ok);
     if ((threadIdx.x & 63u) == 0 && okLanes) atomicAdd(&d.counters[kCtrDrawsSorted], (uint32_t)__popcll(okLanes));
   }
 }
@@ -153,11 +153,11 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const PassArgs a)
   for (uint32_t r = 0; r < kRounds; ++r) {
     const uint32_t i = first + r * 64u;
     const bool live = i < n;
-    uint64_t peers = __ballot(live);
+    uint64_t peers = ballot64(live);
 #pragma unroll
     for (uint32_t b = 0; b < 8; ++b) {
       const bool bit = (digit[r] >> b) & 1u;
-      const uint64_t bal = __ballot(live && bit);
+      const uint64_t bal = ballot64(live && bit);
       peers &= bit ? bal : ~bal;
     }
     const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));

@@ -6,6 +6,12 @@
 
 namespace sctick {
 
+#ifdef __HIPCC__
+// the wave's predicate mask straight from the compare (HIP's __ballot goes through an integer: v_cndmask + v_cmp_ne per call)
+__device__ __forceinline__ unsigned long long ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+#endif
+
+
 // ---- link word: one dword per entity carries topology + component flags --------------------
 //   bits  0..23  dense index of the parent (kNoParent = root)          Transform::parent
 //   bit   24     has RenderMesh  (culling candidate)                   sc_world_partition.cpp:1206-1210

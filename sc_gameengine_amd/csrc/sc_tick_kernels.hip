@@ -236,13 +236,13 @@ __device__ __forceinline__ void appendBig(const DeviceState& d, const TickParams
 __device__ __forceinline__ void binInsertWave(const DeviceState& d, const TickParams& p, bool want, uint32_t sector,
                                               const float4& rmin, const float4& rmax)
 {
-  const unsigned long long act = __ballot(want);
+  const unsigned long long act = ballot64(want);
   if (!act) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t key = want ? sector : 0xFFFFFFFFu;
   const uint32_t prev = __shfl_up(key, 1, 64);
   const bool head = want && (lane == 0 || prev != key);
-  const unsigned long long heads = __ballot(head);
+  const unsigned long long heads = ballot64(head);
   const unsigned long long upto = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
   const uint32_t myHead = (63u - (uint32_t)__clzll(heads & upto)) & 63u;
   const unsigned long long above = (myHead == 63u) ? 0ull : ~((2ull << myHead) - 1ull);
@@ -252,7 +252,7 @@ __device__ __forceinline__ void binInsertWave(const DeviceState& d, const TickPa
   // word): one cross-lane read decides; only a wave with a mixed run pays the segmented OR.
   uint32_t lay = want ? __float_as_uint(rmin.w) : 0u;
   const uint32_t headLay = (uint32_t)__shfl((int)lay, (int)myHead, 64);
-  if (__ballot(want && headLay != lay)) {
+  if (ballot64(want && headLay != lay)) {
 #pragma unroll
     for (uint32_t o = 1; o < 64u; o <<= 1) {
       const uint32_t other = (uint32_t)__shfl_down((int)lay, o, 64);
@@ -269,7 +269,7 @@ __device__ __forceinline__ void binInsertWave(const DeviceState& d, const TickPa
   }
   // bin full: the record joins the sector overflow list (one reservation per wave)
   const bool over = want && slot >= kBinCap;
-  const unsigned long long mo = __ballot(over);
+  const unsigned long long mo = ballot64(over);
   if (mo) {
     const uint32_t ctr = kCtrPar + 8u * p.parity;
     const uint32_t first = (uint32_t)__ffsll((long long)mo) - 1u;
@@ -438,7 +438,7 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
     }
 
     if (hasDeep) {
-      const unsigned long long rm = __ballot(recompute);
+      const unsigned long long rm = ballot64(recompute);
       if (lane == 0 && (base + wave * 64u) < p.n) d.recomp[(base >> 6) + wave] = rm;
     }
 
@@ -457,8 +457,8 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
         }
         // deeper entities get their matrix (and their bit) from the level kernels
         if (doXform && depth > kChain && depth != kUnreachable) visible = false;
-        const unsigned long long vm = __ballot(visible);
-        const unsigned long long cm = __ballot(cand);
+        const unsigned long long vm = ballot64(visible);
+        const unsigned long long cm = ballot64(cand);
         if (lane == 0 && (base + wave * 64u) < p.n) {
           d.vis[(base >> 6) + wave] = vm;
           if (wantCand) d.cand[(base >> 6) + wave] = cm;
@@ -547,7 +547,7 @@ __device__ __forceinline__ bool nudgePosition(const DeviceState& d, uint32_t i, 
 __device__ __forceinline__ void markDirtyWave(const DeviceState& d, uint32_t i, uint32_t n, bool moved)
 {
   const uint32_t lane = threadIdx.x & 63u;
-  const unsigned long long m = __ballot(moved);
+  const unsigned long long m = ballot64(moved);
   const uint32_t mine = lane < 32u ? (uint32_t)m : (uint32_t)(m >> 32);
   if (i < n && (lane & 31u) == 0u && mine) d.dirty[i >> 5] |= mine;
 }
@@ -730,13 +730,13 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
           const uint32_t tileBase = base + u * kTile, i = tileBase + threadIdx.x;
           const bool root = i < end && (lk[u] & kParentMask) == kNoParent && linkDepth(lk[u]) != kUnreachable;
           if (root) d.px[i] = x[u] + p.producerParam;
-          const unsigned long long m = __ballot(root);
+          const unsigned long long m = ballot64(root);
           if (lane == 0 && tileBase < end) { moved[((tileBase >> 5) - wBegin) + 2u * wave] = (uint32_t)m; moved[((tileBase >> 5) - wBegin) + 2u * wave + 1u] = (uint32_t)(m >> 32); }
         }
       }
     } else {
       for (uint32_t base = begin; base < end; base += kTile) {
-        const unsigned long long m = __ballot(producePosition(d, p, base + threadIdx.x));
+        const unsigned long long m = ballot64(producePosition(d, p, base + threadIdx.x));
         if (lane == 0) { moved[((base >> 5) - wBegin) + 2u * wave] = (uint32_t)m; moved[((base >> 5) - wBegin) + 2u * wave + 1u] = (uint32_t)(m >> 32); }
       }
     }
@@ -897,7 +897,7 @@ __device__ __forceinline__ void sinkFlush(const DeviceState& d, const TickParams
 }
 __device__ __forceinline__ void sinkPush(const DeviceState& d, const TickParams& p, PairSink& k, bool hit, uint32_t ia, uint32_t ib)
 {
-  const unsigned long long m = __ballot(hit);
+  const unsigned long long m = ballot64(hit);
   if (!m) return;
   const uint32_t lane = threadIdx.x & 63u;
   if (hit) k.buf[k.count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(ia < ib ? ia : ib, ia < ib ? ib : ia);
@@ -942,6 +942,7 @@ __device__ __forceinline__ bool ownsSector(const TickParams& p, float gx, float 
 constexpr uint32_t kPairTabSize = kBinCap * (kBinCap - 1) / 2;
 constexpr uint32_t kFineThreshold = 24;      // bins with more records than this use the 4x4 cell grid
 constexpr uint32_t kCellWords = 16u * (1u + kOvfPerSector / 64u);     // 4x4 cell masks for the bin tile and every overflow tile of a sector
+constexpr uint32_t kCastDirect = 2;          // this few cast records are broadcast one after the other (no re-ordering of the bin)
 constexpr uint32_t kCastMax = 20;            // up to this many self-compatible (dynamic) records per bin are broadcast one by one
 
 // pair predicate shared by both search paths: group/mask filter, closed-interval overlap, and "this sector
@@ -976,6 +977,11 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   for (uint32_t i = 1u + threadIdx.x / 64u * 16u; i < kBinCap && i < 17u + threadIdx.x / 64u * 16u; ++i)
     for (uint32_t j = lane; j < i; j += 64u) pairTab[i * (i - 1u) / 2u + j] = (uint16_t)(i << 8 | j);
 
+  // broadcast path: with D records to cast, lane l plays (record l / G, partner phase l % G), G = 64 / D; the division by
+  // the wave-uniform G is a multiplication by ceil(2^16 / G) (exact for l < 64)
+  __shared__ uint32_t castTab[kCastMax + 1u];
+  if (threadIdx.x >= 1u && threadIdx.x <= kCastMax) { const uint32_t G = 64u / threadIdx.x; castTab[threadIdx.x] = G | ((65536u / G + 1u) << 8); }
+
   // next tick's counter set starts clean (pipelined tiles do this in a small kernel behind the pair kernel instead:
   // there the next tick's fused kernel may already be filling it while this pair search runs)
   if (!(p.flags & kFlagDeferredReset)) resetOtherParity(d, p, bid, nblocks);
@@ -1006,17 +1012,29 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
         }
       }
     }
-    const uint32_t myTrue = myCount;                   // records the sector holds, bin and overflow list together
-    if (myCount > kBinCap) myCount = kBinCap;
-    const unsigned long long work = __ballot(myCount != 0u);
+    const bool myOver = myCount > kBinCap;             // the sector holds more records than its bin: the rest is in the overflow list
+    if (myOver) myCount = kBinCap;
+    const unsigned long long work = ballot64(myCount != 0u);
     if (!work) continue;
 
+    // a ring sector on a side where a neighbour tile exists belongs to that neighbour: it reports the pairs whose low
+    // corner lies there (it received these boxes through the border exchange).  Decided here, once per 64 sectors.
+    bool mine = true;
+    {
+      const int dx = myGx == 0 ? -1 : (myGx == p.binSX - 1u ? 1 : 0), dz = myGz == 0 ? -1 : (myGz == p.binSZ - 1u ? 1 : 0);
+      if ((dx != 0 && hasNb(p, dx, 0)) || (dz != 0 && hasNb(p, 0, dz))) mine = false;    // nearest tile is not this one
+    }
+    const unsigned long long oursMask = ballot64(mine), overMask = ballot64(myOver);
+    // what a sector's turn needs from the lane that holds it: index, count, layer summary, grid coordinates -- four
+    // cross-lane reads.  (ds_bpermute although the picked lane is wave-uniform: v_readlane measured slower, 27.1 against
+    // 26.3 us on config3dyn -- a VALU slot each plus SGPR-hazard waits; and recomputing the index from the lane number
+    // made the compiler re-load a kernel argument inside this loop: the scalar registers are all taken.)
+    const uint32_t myGxz = myGx | (myGz << 16);
     // software pipeline: records of the next non-empty sector are in flight while this one is tested
     int it = __ffsll((long long)work) - 1;
-    uint32_t n = __shfl(myCount, it, 64), nTrue = __shfl(myTrue, it, 64);
-    float4 rmin = make_float4(0, 0, 0, 0), rmax = make_float4(0, 0, 0, 0);
+    uint32_t n = __shfl(myCount, it, 64), gxz = __shfl(myGxz, it, 64), binLay = __shfl(myLay, it, 64);
     uint32_t s = __shfl(mySector, it, 64);            // (cross-lane reads stay outside divergent code: every lane takes part)
-    uint32_t gx = __shfl(myGx, it, 64), gz = __shfl(myGz, it, 64), binLay = __shfl(myLay, it, 64);
+    float4 rmin = make_float4(0, 0, 0, 0), rmax = make_float4(0, 0, 0, 0);
     if (lane < n) {
       const float4* r = d.bins + 2u * ((size_t)s * kBinCap + lane);
       rmin = r[0]; rmax = r[1];
@@ -1024,29 +1042,22 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     unsigned long long rest = work & ~(1ull << it);
     while (it >= 0) {
       const int itNext = rest ? __ffsll((long long)rest) - 1 : -1;
-      uint32_t nNext = 0, nTrueNext = 0;
+      uint32_t nNext = 0, gxzNext = 0, binLayNext = 0, sNext = 0;
       float4 nmin = make_float4(0, 0, 0, 0), nmax = make_float4(0, 0, 0, 0);
-      uint32_t sNext = 0, gxNext = 0, gzNext = 0, binLayNext = 0;
       if (itNext >= 0) {
         rest &= ~(1ull << itNext);
-        nNext = __shfl(myCount, itNext, 64); nTrueNext = __shfl(myTrue, itNext, 64);
+        nNext = __shfl(myCount, itNext, 64); gxzNext = __shfl(myGxz, itNext, 64); binLayNext = __shfl(myLay, itNext, 64);
         sNext = __shfl(mySector, itNext, 64);
-        gxNext = __shfl(myGx, itNext, 64); gzNext = __shfl(myGz, itNext, 64); binLayNext = __shfl(myLay, itNext, 64);
         if (lane < nNext) {
           const float4* r = d.bins + 2u * ((size_t)sNext * kBinCap + lane);
           nmin = r[0]; nmax = r[1];
         }
       }
 
-      bool valid = lane < n;
-      // a ring sector on a side where a neighbour tile exists belongs to that neighbour: it reports the
-      // pairs whose low corner lies there (it received these boxes through the border exchange)
-      bool ours = true;
-      {
-        const int dx = gx == 0 ? -1 : (gx == p.binSX - 1u ? 1 : 0), dz = gz == 0 ? -1 : (gz == p.binSZ - 1u ? 1 : 0);
-        if ((dx != 0 && hasNb(p, dx, 0)) || (dz != 0 && hasNb(p, 0, dz))) ours = false;    // nearest tile is not this one
-      }
-      valid = valid && ours;
+      const uint32_t gx = gxz & 0xFFFFu, gz = gxz >> 16;
+      const bool over = (overMask >> it) & 1ull;
+      const bool ours = (oursMask >> it) & 1ull;
+      const bool valid = lane < n && ours;
       // Filter first (integer, cheap): like btDbvtBroadphase, which keeps static bodies in a separate set
       // and never tests fixed-vs-fixed, a record that cannot pass (a.group & b.mask) && (b.group & a.mask)
       // against ANY other record of this bin is dropped before the box tests, and a bin without a single
@@ -1057,7 +1068,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       const uint32_t lay = valid ? __float_as_uint(rmin.w) : 0u;
       const uint32_t all = binLay;
       const bool admissible = valid && ((lay & 0xFFFFu) & (all >> 16)) != 0u && ((all & 0xFFFFu) & (lay >> 16)) != 0u;
-      const unsigned long long validMask = __ballot(admissible);
+      const unsigned long long validMask = ballot64(admissible);
       const bool anyPairs = __popcll(validMask) >= 2;
       const float secX = (float)gx, secZ = (float)gz;
       // Who can collide at all?  Under Bullet's filter most boxes of a city are static bodies (group 2 / mask 1), which never
@@ -1068,14 +1079,14 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       // fail the filter.  It covers every pair unless two records that do NOT pass against their own kind pass against each
       // other (say 4/8 against 8/4): the OR of those records' layer words tells; then the general paths below run.
       const bool selfOk = admissible && filterPass(lay, lay);
-      const unsigned long long castMask = __ballot(selfOk);
+      const unsigned long long castMask = ballot64(selfOk);
       // the other admissible records: when they all carry ONE layer word (the usual case: static props) they cannot pass
       // against each other -- that word does not pass against itself; only a mix pays for the OR over the lanes
-      const unsigned long long others = __ballot(admissible && !selfOk);
+      const unsigned long long others = ballot64(admissible && !selfOk);
       bool crossPossible = false;
       if (others) {
         const uint32_t first = (uint32_t)__shfl((int)lay, __ffsll((long long)others) - 1, 64);
-        if (__ballot(admissible && !selfOk && lay != first)) {
+        if (ballot64(admissible && !selfOk && lay != first)) {
           uint32_t rest2 = (admissible && !selfOk) ? lay : 0u;
 #pragma unroll
           for (int o = 32; o > 0; o >>= 1) rest2 |= (uint32_t)__shfl_xor((int)rest2, o, 64);
@@ -1084,18 +1095,54 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       }
       const bool castPath = (uint32_t)__popcll(castMask) <= kCastMax && !crossPossible;
       if (anyPairs && castPath) {
-        T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
-        __builtin_amdgcn_wave_barrier();
-        unsigned long long cm = castMask;
-        while (cm) {
-          const uint32_t c = (uint32_t)__ffsll((long long)cm) - 1u;
-          cm &= cm - 1ull;
-          const float4 tmin = T[2u * c], tmax = T[2u * c + 1u];
-          const bool cand = admissible && lane != c && (!selfOk || lane < c);      // two broadcast records meet once
-          if (!__ballot(cand && boxesOverlap(rmin, rmax, tmin, tmax))) continue;
-          uint32_t ia = 0, ib = 0;
-          const bool hit = cand && pairHit(p, rmin, rmax, tmin, tmax, secX, secZ, ia, ib);
-          sinkPush(d, p, sink, hit, ia, ib);
+        // The records that can collide at all go to LDS, cast records first: slot = rank among the cast records, or D + rank
+        // among the other admissible ones.  Lane (c, g) then tests cast record c against the slots g, g + G, g + 2G, ...
+        // that are either an earlier cast record (two cast records meet once) or not a cast record: n D / 64 rounds with
+        // all lanes busy, where broadcasting the D records one after the other took D rounds with n lanes busy.
+        const uint32_t D = (uint32_t)__popcll(castMask), nAdm = (uint32_t)__popcll(validMask);
+        if (D && D <= kCastDirect) {
+          // one or two cast records (a lone vehicle among props): staged as they lie, the cast record is broadcast from LDS
+          // and every lane tests the record it already holds in registers
+          T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
+          __builtin_amdgcn_wave_barrier();
+          unsigned long long cm = castMask;
+          while (cm) {
+            const uint32_t c = (uint32_t)__ffsll((long long)cm) - 1u;
+            cm &= cm - 1ull;
+            const float4 tmin = T[2u * c], tmax = T[2u * c + 1u];
+            const bool cand = admissible && (!selfOk || lane < c);      // two cast records meet once
+            if (!ballot64(cand && boxesOverlap(rmin, rmax, tmin, tmax))) continue;
+            uint32_t ia = 0, ib = 0;
+            const bool hit = cand && pairHit(p, rmin, rmax, tmin, tmax, secX, secZ, ia, ib);
+            sinkPush(d, p, sink, hit, ia, ib);
+          }
+        } else if (D) {
+          const unsigned long long below = (1ull << lane) - 1ull;
+          const uint32_t slot = selfOk ? (uint32_t)__popcll(castMask & below) : D + (uint32_t)__popcll(validMask & ~castMask & below);
+          if (admissible) { T[2u * slot] = rmin; T[2u * slot + 1u] = rmax; }
+          const uint32_t gi = castTab[D], G = gi & 0xFFu;
+          const uint32_t c = (lane * (gi >> 8)) >> 16;
+          // lane (c, g) may meet slot j iff j < nLane and j is outside [c, D): one unsigned compare each
+          const uint32_t nLane = c < D ? nAdm : 0u, span = D - c;
+          uint32_t j = lane - c * G;
+          __builtin_amdgcn_wave_barrier();
+          const float4 cmin = T[2u * (c & 63u)], cmax = T[2u * (c & 63u) + 1u];       // (idle lanes read some record; nLane = 0 keeps them out)
+          const uint32_t clay = __float_as_uint(cmin.w), cid = __float_as_uint(cmax.w) & ~kPrimary;
+          for (uint32_t j0 = 0; j0 < nAdm; j0 += G, j += G) {
+            // (a slot index past the bin reads another wave's tile or zeros: the lane is masked out by j < nLane)
+            const float4 tmin = T[2u * j], tmax = T[2u * j + 1u];
+            // mask arithmetic instead of short-circuit branches: 6 + 2 compares, and the wave skips the round on an empty mask
+            const unsigned long long m = ballot64(j < nLane) & ballot64(j - c >= span) &
+                                         ballot64(cmin.x <= tmax.x) & ballot64(tmin.x <= cmax.x) & ballot64(cmin.y <= tmax.y) &
+                                         ballot64(tmin.y <= cmax.y) & ballot64(cmin.z <= tmax.z) & ballot64(tmin.z <= cmax.z);
+            if (!m) continue;
+            const bool touch = (m >> lane) & 1ull;
+            const uint32_t tid = __float_as_uint(tmax.w) & ~kPrimary;
+            const float lx = cmin.x > tmin.x ? cmin.x : tmin.x, lz = cmin.z > tmin.z ? cmin.z : tmin.z;        // as pairHit
+            const bool hit = touch && filterPass(clay, __float_as_uint(tmin.w)) && cid != tid &&
+                             (floorf(lx * p.invSector) - p.binOx) == secX && (floorf(lz * p.invSector) - p.binOz) == secZ;
+            sinkPush(d, p, sink, hit, cid, tid);
+          }
         }
       } else if (anyPairs) {
         T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
@@ -1139,7 +1186,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
           __builtin_amdgcn_wave_barrier();
           unsigned long long cand = 0ull;
           if (small) cand = (cells[c00] | cells[c01] | cells[c10] | cells[c11]) & ((1ull << lane) - 1ull);   // partners j < i
-          while (__ballot(cand != 0ull)) {
+          while (ballot64(cand != 0ull)) {
             bool hit = false; uint32_t ia = 0, ib = 0;
             if (cand) {
               const uint32_t j = (uint32_t)__ffsll((long long)cand) - 1u;
@@ -1148,7 +1195,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
             }
             sinkPush(d, p, sink, hit, ia, ib);
           }
-          unsigned long long wides = __ballot(wide);
+          unsigned long long wides = ballot64(wide);
           while (wides) {
             const uint32_t wI = (uint32_t)__ffsll((long long)wides) - 1u;
             wides &= wides - 1ull;
@@ -1177,7 +1224,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       // The wave gathers the list indices of its sector in one sweep (scratch row in global memory), then walks them in
       // tiles of 64: tile k in registers (one record per lane) against the bin and against tiles 0..k staged in LDS.
       // Cost: one sweep of the list per overflowing sector + (records of the sector)^2 / 64 tests.
-      if (nTrue > kBinCap && novf) {
+      if (over && novf) {
         // the slice of the list that holds this sector's records; the wave that consumes a sector resets its slice
         uint32_t eLo = d.ovfLo[s], eHi = d.ovfHi[s];
         if (lane == 0) { d.ovfLo[s] = 0xFFFFFFFFu; d.ovfHi[s] = 0u; }
@@ -1191,7 +1238,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
 #pragma unroll
           for (uint32_t u = 0; u < 4u; ++u) {
             const bool match = tag[u] == s;
-            const unsigned long long mm = __ballot(match);
+            const unsigned long long mm = ballot64(match);
             if (match) {
               const uint32_t at = m + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
               if (at < kOvfPerSector) ovfIdx[at] = e0 + u * 64u + lane;
@@ -1250,7 +1297,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
               for (int cz = cz0; cz <= cz1; ++cz) for (int cx = cx0; cx <= cx1; ++cx) cand |= CM[jt * 16u + (uint32_t)(cz * 4 + cx)];
               if (jt == k) cand &= (1ull << lane) - 1ull;          // inside a tile: partners in lower lanes
             }
-            while (__ballot(cand != 0ull)) {
+            while (ballot64(cand != 0ull)) {
               bool hit = false; uint32_t ia = 0, ib = 0;
               if (cand) {
                 const uint32_t i = (uint32_t)__ffsll((long long)cand) - 1u;
@@ -1272,7 +1319,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
         }
       }
       __builtin_amdgcn_wave_barrier();
-      it = itNext; n = nNext; nTrue = nTrueNext; s = sNext; gx = gxNext; gz = gzNext; binLay = binLayNext; rmin = nmin; rmax = nmax;
+      it = itNext; n = nNext; s = sNext; gxz = gxzNext; binLay = binLayNext; rmin = nmin; rmax = nmax;
     }
   }
 
@@ -1630,7 +1677,7 @@ __global__ __launch_bounds__(kTile) void k_traffic_tiers(const DeviceState d, ui
     else want = (dist < tp.aEnter) ? kTierPhysics : ((dist < tp.bEnter) ? kTierKinematic : kTierOnRails);
     d.aDesired[i] = want;
   }
-  const unsigned long long mp = __ballot(agent && want == kTierPhysics), mk = __ballot(agent && want == kTierKinematic), mr = __ballot(agent && want == kTierOnRails);
+  const unsigned long long mp = ballot64(agent && want == kTierPhysics), mk = ballot64(agent && want == kTierKinematic), mr = ballot64(agent && want == kTierOnRails);
   if ((threadIdx.x & 63u) == 0u) {
     if (mp) atomicAdd(&d.tierCounts[0], (uint32_t)__popcll(mp));
     if (mk) atomicAdd(&d.tierCounts[1], (uint32_t)__popcll(mk));

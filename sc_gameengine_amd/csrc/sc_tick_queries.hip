@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kTile) void k_ray_queries(const DeviceState d, cons
     best = other < best ? other : best;
   }
   const bool found = bid != 0xFFFFFFFFu && key == best;
-  const unsigned long long winners = __ballot(found);
+  const unsigned long long winners = ballot64(found);
   if (!winners) { if (lane == 0) q.hits[r] = out; return; }
   if (lane == (uint32_t)__ffsll((long long)winners) - 1u) {
     out.hit = 1u; out.id = bid; out.distance = bt; out.layer = blayer;
