@@ -228,3 +228,38 @@ def test_layers_that_only_pass_across_kinds(oracle):
     assert (4, 8) in k or (8, 4) in k                      # such pairs really occur
     assert (2, 2) not in k
     t.close(); ow.close()
+
+
+@pytest.mark.parametrize("dyn_per_sector", [1, 2, 3, 5, 9, 16, 17, 20, 21, 30])
+def test_every_count_of_dynamic_records_per_sector(oracle, dyn_per_sector):
+    """The pair search picks its path by the number D of records in a bin that pass the filter against their own kind
+    (dynamic bodies): D <= 2 broadcast as they lie, D <= 20 lane (record, phase) over the re-ordered bin (G = 64 / D partner
+    phases: every quotient is exercised here), above that the general paths.  Sectors hold D dynamic boxes among static
+    ones, some sectors nothing but dynamic ones, crowded enough that cast records meet each other and the statics."""
+    rng = np.random.default_rng(100 + dyn_per_sector)
+    SX = 6
+    pos, scl, grp, msk = [], [], [], []
+    for sz in range(SX):
+        for sx in range(SX):
+            ox, oz = (sx - SX // 2) * 64.0, (sz - SX // 2) * 64.0
+            d = dyn_per_sector if (sx + sz) % 5 else min(dyn_per_sector + 3, 40)        # a few sectors with a different count
+            s = 0 if (sx * 7 + sz) % 6 == 0 else int(rng.integers(0, max(1, 50 - d)))    # some bins hold dynamic boxes only
+            k = d + s
+            # clustered so that boxes really overlap: a third of them around two hot spots, the rest anywhere in the sector
+            hot = rng.uniform(8, 56, (2, 2))
+            xz = np.where(rng.random((k, 1)) < 0.35, hot[rng.integers(0, 2, k)] + rng.normal(0, 2.0, (k, 2)), rng.uniform(1, 63, (k, 2)))
+            pos.append(np.column_stack([ox + xz[:, 0], rng.uniform(0.3, 1.5, k), oz + xz[:, 1]]))
+            scl.append(rng.uniform(0.5, 4.0, (k, 3)))
+            grp.append(np.r_[np.full(d, sw.GROUP_DYNAMIC), np.full(s, sw.GROUP_STATIC)])
+            msk.append(np.r_[np.full(d, sw.MASK_ALL), np.full(s, sw.MASK_STATIC)])
+    w = worlds.random_world(sum(len(p) for p in pos), seed=7, spread=10.0, p_child=0.0, p_no_bounds=0.0)
+    w.pos[:] = np.concatenate(pos).astype(np.float32); w.scale[:] = np.concatenate(scl).astype(np.float32); w.rot[:] = 0.0
+    w.rot[:, 1] = rng.uniform(0, 6.28, w.n).astype(np.float32)
+    w.group[:] = np.concatenate(grp).astype(np.uint32); w.mask[:] = np.concatenate(msk).astype(np.uint32)
+    perm = rng.permutation(w.n)                      # dense order (= record order in a bin) unrelated to the kind
+    for a in ("pos", "scale", "rot", "group", "mask"):
+        getattr(w, a)[:] = getattr(w, a)[perm]
+    t, ow = gpu_vs_oracle(oracle, w, ticks=2, nudge=0.9)
+    c = t.counts()
+    assert c.pairs > 20 * dyn_per_sector and c.pairs_truncated == 0 and c.border_lost == 0
+    t.close(); ow.close()
