@@ -460,7 +460,9 @@ int scTickQueryOccupied(ScTickContext* ctx, uint32_t count, const float* pos3, c
 int scTickSetProfiling(ScTickContext* ctx, int enable);
 /* durations (ms) of the launches of `kernel` recorded since profiling was enabled; synchronises */
 int scTickGetKernelTimes(ScTickContext* ctx, uint32_t kernel, float* ms, uint32_t capacity, uint32_t* count);
-/* capture the current stage sequence into a hipGraph and replay it on scTickRun (0 = eager launches) */
+/* capture the current stage sequence into a hipGraph and replay it on scTickRun (0 = eager launches).  scTickTileStep on
+ * an in-order tile replays the whole step (RCCL group included) as one graph; on a pipelined tile each half of the step is
+ * a graph of its own, on its own stream.  Not combinable with the frame read-back. */
 int scTickSetGraphMode(ScTickContext* ctx, int enable);
 /* native stream handle (hipStream_t) for callers that order their own work against the tick */
 void* scTickGetStream(ScTickContext* ctx);

@@ -79,12 +79,20 @@ struct ScTickContext
 
   // graph
   bool graphMode = false;
-  hipGraph_t graph[2] = { nullptr, nullptr };          // one per broadphase tick parity
-  hipGraphExec_t graphExec[2] = { nullptr, nullptr };
-  TickParams graphParams[2]{};
-  bool graphWhole[2] = { false, false };               // the captured graph holds the whole tile step (exchange + pair half)
+  hipGraph_t graph[kMaxParity] = {};                   // one per broadphase tick parity
+  hipGraphExec_t graphExec[kMaxParity] = {};
+  TickParams graphParams[kMaxParity]{};
+  bool graphWhole[kMaxParity] = {};                    // the captured graph holds the whole tile step (exchange + pair half)
   bool captureWholeStep = false;                       // set by scTickTileStep around its scTickRun
-  uint64_t topoEpoch = 0, graphEpoch[2] = { ~0ull, ~0ull };
+  uint64_t topoEpoch = 0, graphEpoch[kMaxParity] = { ~0ull, ~0ull, ~0ull, ~0ull };
+  // pipelined tile + graph replay: the pair half (exchange, merge, queries, pair search, snapshot) is a graph of its own,
+  // replayed on the pairs stream; the two graphs of a step are ordered by events recorded between them, outside any capture
+  hipGraph_t pairGraph[kMaxParity] = {};
+  hipGraphExec_t pairGraphExec[kMaxParity] = {};
+  TickParams pairGraphParams[kMaxParity]{};
+  bool pairGraphExchange[kMaxParity] = {};
+  uint64_t pairGraphEpoch[kMaxParity] = { ~0ull, ~0ull, ~0ull, ~0ull };
+  bool lastTickSampled = false;                        // the last scTickRun recorded profiling events (ran eagerly)
 
   // broadphase
   uint32_t sectors = 0, maxPairs = 0;
@@ -419,6 +427,27 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.tileX = c->tileX; p.tileZ = c->tileZ; p.tilesX = c->tilesX; p.tilesZ = c->tilesZ;
 }
 
+// pipelined tiles: a tick refills the bins, counters and big-box bits of its parity, which the pair half of pipeDepth ticks
+// ago read.  That half finished long ago unless the exchange is very slow; wait for it.  (Cross-stream: never captured.)
+void waitParityFree(ScTickContext* c, const TickParams& p)
+{
+  if (!(p.flags & kFlagDeferredReset) || !c->pairsInFlight[p.parity]) return;
+  // (a queue-to-queue wait costs a bubble of ~10 us on the device even when it is already satisfied: ask first)
+  if (hipEventQuery(c->pairsDone[p.parity]) != hipSuccess) hipStreamWaitEvent(c->stream, c->pairsDone[p.parity], 0);
+  (void)hipGetLastError();                        // hipErrorNotReady from the query is not an error
+  c->pairsInFlight[p.parity] = false;
+}
+
+// pipelined tiles: whatever is queued on the pairs stream from here on (the exchange) is ordered behind this tick's pack
+void publishPacked(ScTickContext* c, const TickParams& p)
+{
+  if (!c->pairsStream || !(p.flags & SC_TICK_BROADPHASE) || !(p.flags & SC_TICK_SPLIT_PAIRS)) return;
+  hipEventRecord(c->packed[p.parity], c->stream);
+  hipStreamWaitEvent(c->pairsStream, c->packed[p.parity], 0);
+}
+
+// the tick's launches on c->stream, nothing else: safe inside a stream capture (the callers put waitParityFree before
+// and publishPacked behind it)
 void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool allowProfile)
 {
   const uint32_t flags = p.flags;
@@ -426,16 +455,6 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
   const bool prof = allowProfile && c->profiling;
   const bool saved = c->profiling;
   c->profiling = prof;
-  // pipelined tiles: this tick refills the bins, counters and big-box bits of its parity, which the pair half of two ticks ago
-  // read.  That half finished long ago unless the exchange is very slow; wait for it, then clear the small state.
-  if (flags & kFlagDeferredReset) {
-    if (c->pairsInFlight[p.parity]) {
-      // (a queue-to-queue wait costs a bubble of ~10 us on the device even when it is already satisfied: ask first)
-      if (hipEventQuery(c->pairsDone[p.parity]) != hipSuccess) hipStreamWaitEvent(c->stream, c->pairsDone[p.parity], 0);
-      (void)hipGetLastError();                        // hipErrorNotReady from the query is not an error
-      c->pairsInFlight[p.parity] = false;
-    }
-  }
   if (c->producerKind && !(flags & SC_TICK_PRODUCE_NEXT)) {
     Scoped s(c, SC_TICK_K_NUDGE);
     if (c->producerKind == 1) launchNudgeRootsX(ds, c->n, c->producerParam, c->stream);
@@ -479,8 +498,6 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     if (flags & SC_TICK_BROADPHASE) {
       if (flags & SC_TICK_SPLIT_PAIRS) {                                            // the caller exchanges, then scTickRunPairs
         if (!packToo) launchBorderPack(ds, p, c->stream);
-        // pipelined: whatever the caller queues on the pairs stream from here on (the exchange) is ordered behind the pack
-        if (c->pairsStream) { hipEventRecord(c->packed[p.parity], c->stream); hipStreamWaitEvent(c->pairsStream, c->packed[p.parity], 0); }
       }
       else { Scoped s(c, SC_TICK_K_PAIRS); launchPairs(ds, p, c->stream); }
     }
@@ -518,10 +535,19 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
 
 void dropGraph(ScTickContext* c, int q = -1)
 {
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < (int)kMaxParity; ++k) {
     if (q >= 0 && k != q) continue;
     if (c->graphExec[k]) { hipGraphExecDestroy(c->graphExec[k]); c->graphExec[k] = nullptr; }
     if (c->graph[k]) { hipGraphDestroy(c->graph[k]); c->graph[k] = nullptr; }
+  }
+}
+
+void dropPairGraph(ScTickContext* c, int q = -1)
+{
+  for (int k = 0; k < (int)kMaxParity; ++k) {
+    if (q >= 0 && k != q) continue;
+    if (c->pairGraphExec[k]) { hipGraphExecDestroy(c->pairGraphExec[k]); c->pairGraphExec[k] = nullptr; }
+    if (c->pairGraph[k]) { hipGraphDestroy(c->pairGraph[k]); c->pairGraph[k] = nullptr; }
   }
 }
 
@@ -623,8 +649,9 @@ void scTickDestroyContext(ScTickContext* c)
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->pairsStream) hipStreamSynchronize(c->pairsStream);
   c->stream = c->ownStream;
-  dropGraph(c);
+  dropGraph(c); dropPairGraph(c);
   for (auto& v : c->times) for (auto& p : v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : c->eventPool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (uint32_t k = 0; k < kMaxParity; ++k) { if (c->packed[k]) hipEventDestroy(c->packed[k]); if (c->pairsDone[k]) hipEventDestroy(c->pairsDone[k]); }
@@ -1114,7 +1141,6 @@ int scTickRun(ScTickContext* c, uint32_t flags)
     if (!c->producerKind) return fail(c, "SC_TICK_PRODUCE_NEXT needs scTickSetFrameProducer first");
   }
   if (c->pairsStream && (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS)) return fail(c, "a pairs stream is set: run the broadphase with SC_TICK_SPLIT_PAIRS + scTickRunPairs");
-  if (c->pairsStream && c->graphMode) return fail(c, "graph replay and a pairs stream cannot be combined");
   if (c->rb.bytes && c->graphMode) return fail(c, "graph replay and the frame read-back cannot be combined");
   if ((flags & SC_TICK_RAYS) && !(flags & SC_TICK_BROADPHASE)) return fail(c, "SC_TICK_RAYS needs SC_TICK_BROADPHASE in the same run (the queries read this tick's bins)");
   if ((flags & SC_TICK_SORT_DRAWS) && !c->sort.pipeline) return fail(c, "SC_TICK_SORT_DRAWS needs scTickSetDrawSortTable first");
@@ -1125,6 +1151,8 @@ int scTickRun(ScTickContext* c, uint32_t flags)
 
   const uint32_t q = (flags & SC_TICK_BROADPHASE) ? c->parity : 0u;
   const bool sampledTick = c->profiling && (c->tickIndex % c->profPeriod) == 0;     // events need eager launches
+  c->lastTickSampled = sampledTick;
+  waitParityFree(c, p);
   if (c->graphMode && !sampledTick) {
     const bool stale = !c->graphExec[q] || c->graphEpoch[q] != c->topoEpoch || std::memcmp(&p, &c->graphParams[q], sizeof p) != 0 || c->graphWhole[q] != c->captureWholeStep;
     if (stale) {
@@ -1147,6 +1175,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   } else {
     enqueueStages(c, p, grid, true);
   }
+  publishPacked(c, p);
   if (flags & SC_TICK_BROADPHASE) {
     const bool pairHalfDone = c->graphMode && !sampledTick && c->captureWholeStep;
     if ((flags & SC_TICK_SPLIT_PAIRS) && !pairHalfDone) { c->pairsPending = true; c->pendingParams = p; }
@@ -1158,18 +1187,38 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   return 1;
 }
 
-int scTickRunPairs(ScTickContext* c)
+// the pair half of a pending tick; withExchange: the library's own RCCL group goes first (scTickTileStep).  On a pipelined
+// tile with graph replay on, the half is a graph of its own on the pairs stream (captured once per tick parity, relaxed mode
+// when the RCCL group is inside: it touches the communicator's resources during capture).
+static int runPendingPairs(ScTickContext* c, bool withExchange)
 {
-  if (!c) return 0;
-  if (!bind(c)) return 0;
-  if (!c->pairsPending) return fail(c, "scTickRunPairs without a preceding scTickRun(... | SC_TICK_BROADPHASE | SC_TICK_SPLIT_PAIRS)");
   const uint32_t q = c->pendingParams.parity;
   hipStream_t ps = c->pairsStream ? c->pairsStream : c->stream;
   if (c->pairsStream) {
-    enqueuePairHalf(c, c->pendingParams, ps, true);
+    const TickParams& pp = c->pendingParams;
+    if (c->graphMode && !c->lastTickSampled) {
+      const bool stale = !c->pairGraphExec[q] || c->pairGraphEpoch[q] != c->topoEpoch || c->pairGraphExchange[q] != withExchange ||
+                         std::memcmp(&pp, &c->pairGraphParams[q], sizeof pp) != 0;
+      if (stale) {
+        dropPairGraph(c, (int)q);
+        HIP_OK(c, hipStreamBeginCapture(ps, withExchange ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
+        const int okx = withExchange ? exchangeBorders(c, q, ps) : 1;
+        if (okx) enqueuePairHalf(c, pp, ps, true);
+        const hipError_t ce = hipStreamEndCapture(ps, &c->pairGraph[q]);
+        if (!okx) { if (c->pairGraph[q]) { hipGraphDestroy(c->pairGraph[q]); c->pairGraph[q] = nullptr; } return 0; }   // (the RCCL error text is already set)
+        if (ce != hipSuccess) return fail(c, "hipStreamEndCapture (pair half)", ce);
+        HIP_OK(c, hipGraphInstantiate(&c->pairGraphExec[q], c->pairGraph[q], nullptr, nullptr, 0));
+        c->pairGraphParams[q] = pp; c->pairGraphEpoch[q] = c->topoEpoch; c->pairGraphExchange[q] = withExchange;
+      }
+      HIP_OK(c, hipGraphLaunch(c->pairGraphExec[q], ps));
+    } else {
+      if (withExchange && !exchangeBorders(c, q, ps)) return 0;
+      enqueuePairHalf(c, pp, ps, true);
+    }
     HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
     c->pairsInFlight[q] = true;
   } else {
+    if (withExchange && !exchangeBorders(c, q, ps)) return 0;
     Scoped s(c, SC_TICK_K_PAIRS);
     enqueuePairHalf(c, c->pendingParams, ps, false);
   }
@@ -1179,6 +1228,14 @@ int scTickRunPairs(ScTickContext* c)
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(c, "kernel launch", e);
   return 1;
+}
+
+int scTickRunPairs(ScTickContext* c)
+{
+  if (!c) return 0;
+  if (!bind(c)) return 0;
+  if (!c->pairsPending) return fail(c, "scTickRunPairs without a preceding scTickRun(... | SC_TICK_BROADPHASE | SC_TICK_SPLIT_PAIRS)");
+  return runPendingPairs(c, false);
 }
 
 int scTickSetTile(ScTickContext* c, uint32_t rank, uint32_t neighbourMask)
@@ -1643,7 +1700,7 @@ int scTickSetGraphMode(ScTickContext* c, int enable)
   if (!c) return 0;
   if (!bind(c)) return 0;
   c->graphMode = enable != 0;
-  if (!enable) { sync(c); dropGraph(c); }
+  if (!enable) { sync(c); dropGraph(c); dropPairGraph(c); }
   return 1;
 }
 
@@ -2011,10 +2068,14 @@ int scTickExchangeBorders(ScTickContext* c)
 int scTickTileStep(ScTickContext* c, uint32_t flags)
 {
   if (!c) return 0;
-  if (!(flags & SC_TICK_BROADPHASE) || !c->neighbourMask) return scTickRun(c, flags & ~(uint32_t)SC_TICK_SPLIT_PAIRS);   // nothing to exchange
+  if (!(flags & SC_TICK_BROADPHASE) || !c->neighbourMask) {                                                                // nothing to exchange
+    if (!(flags & SC_TICK_BROADPHASE) || !c->pairsStream) return scTickRun(c, flags & ~(uint32_t)SC_TICK_SPLIT_PAIRS);
+    if (!scTickRun(c, flags | SC_TICK_SPLIT_PAIRS)) return 0;                 // a lone pipelined tile: the pair half still runs on its own stream
+    return runPendingPairs(c, false);
+  }
   if (!c->comm) return fail(c, "no communicator: scTickCommInit first (a tile with neighbours cannot skip the exchange)");
   static const bool prof = std::getenv("SC_TICK_HOSTPROF") != nullptr;
-  static double acc[3] = { 0, 0, 0 }; static uint64_t calls = 0;
+  static double acc[2] = { 0, 0 }; static uint64_t calls = 0;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   if (c->graphMode && !c->pairsStream) {
     // in-order tile, graph replay: the whole step -- producer, fused kernel, compaction + pack, the RCCL group, merge, pair
@@ -2023,21 +2084,18 @@ int scTickTileStep(ScTickContext* c, uint32_t flags)
     const int okr = scTickRun(c, flags | SC_TICK_SPLIT_PAIRS);
     c->captureWholeStep = false;
     if (!okr) return 0;
-    if (c->pairsPending) {                 // a sampled (profiled) tick ran eagerly: finish it the eager way
-      if (!exchangeBorders(c, c->pendingParams.parity, c->stream)) return 0;
-      return scTickRunPairs(c);
-    }
+    if (c->pairsPending) return runPendingPairs(c, true);          // a sampled (profiled) tick ran eagerly: finish it the eager way
     return 1;
   }
+  // eager, or a pipelined tile: the tick on its stream, then exchange + pair half on theirs (with graph replay on, each
+  // half of a pipelined step is one hipGraphLaunch; the events that order them are recorded between the two)
   const double t0 = prof ? now() : 0.0;
   if (!scTickRun(c, flags | SC_TICK_SPLIT_PAIRS)) return 0;
   const double t1 = prof ? now() : 0.0;
-  if (!exchangeBorders(c, c->pendingParams.parity, c->pairsStream ? c->pairsStream : c->stream)) return 0;
-  const double t2 = prof ? now() : 0.0;
-  const int ok = scTickRunPairs(c);
+  const int ok = runPendingPairs(c, true);
   if (prof) {
-    acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += now() - t2;
-    if (++calls % 200 == 0) { std::fprintf(stderr, "[sc_tick hostprof] per step over 200: run %.1f us, exchange %.1f us, run_pairs %.1f us\n", acc[0] / 200, acc[1] / 200, acc[2] / 200); acc[0] = acc[1] = acc[2] = 0; }
+    acc[0] += t1 - t0; acc[1] += now() - t1;
+    if (++calls % 200 == 0) { std::fprintf(stderr, "[sc_tick hostprof] per step over 200: tick half %.1f us, exchange + pair half %.1f us\n", acc[0] / 200, acc[1] / 200); acc[0] = acc[1] = 0; }
   }
   return ok;
 }

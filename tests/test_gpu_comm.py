@@ -38,11 +38,13 @@ def keys(t):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("pipelined,graph", [(False, False), (True, False), (2, False), (4, False), (False, True)])
+@pytest.mark.parametrize("pipelined,graph", [(False, False), (True, False), (2, False), (4, False), (False, True), (True, True), (2, True)])
 def test_rccl_loopback_equals_device_copy_loopback(pipelined, graph):
     """graph=True: the in-order tile step of A -- fused kernel, compaction + pack, the RCCL group, merge, pair search -- is
     captured once per tick parity and replayed with one hipGraphLaunch (BASELINE config 5: "hipGraph-captured frame").
-    pipelined = 2 / 4: that many copies of the per-tick broadphase state on A's side (True = the default, 3)."""
+    pipelined = 2 / 4: that many copies of the per-tick broadphase state on A's side (True = the default, 3).
+    pipelined AND graph: each half of a step -- the tick on its stream; RCCL group, merge and pair search on theirs -- is a
+    graph of its own, two hipGraphLaunch per step with the ordering events between them."""
     import torch
     w = centre_tile_world()
     vp = camera_view_proj(w.camera)
@@ -115,3 +117,24 @@ def test_single_tile_step_is_a_plain_tick(oracle):
     t.tile_step(capi.FULL)
     assert np.array_equal(t.visible(), ow.visible())
     t.close(); ow.close()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_a_lone_pipelined_tile_steps_without_a_communicator(oracle, graph):
+    """No neighbours, but the pipelined flow is on (a host that configures every tile alike): the step runs the tick on its
+    stream and the pair half on the pairs stream -- with graph replay each as one graph -- and equals the in-order tick."""
+    w = sw.generate(12, 12, 15)
+    dyn = (np.arange(w.n) % 5) == 2
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    vp = camera_view_proj(w.camera)
+    flags = capi.FULL | capi.PRODUCE_NEXT
+    a = WorldTick.from_world(w, broadphase=True); b = WorldTick.from_world(w, broadphase=True)
+    for t in (a, b):
+        t.set_view_proj(vp); t.set_frame_producer(1, 0.4); t.nudge_roots_x(0.4)
+    a.set_pipelined(True); a.set_graph_mode(graph)
+    for step in range(8):
+        a.tile_step(flags); b.run(flags)
+        if step >= 5:
+            assert np.array_equal(keys(a), keys(b)) and len(keys(a)) > 50
+            assert np.array_equal(a.visible(), b.visible())
+    a.close(); b.close()
