@@ -1129,8 +1129,9 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
           const float4 cmin = T[2u * (c & 63u)], cmax = T[2u * (c & 63u) + 1u];       // (idle lanes read some record; nLane = 0 keeps them out)
           const uint32_t clay = __float_as_uint(cmin.w), cid = __float_as_uint(cmax.w) & ~kPrimary;
           for (uint32_t j0 = 0; j0 < nAdm; j0 += G, j += G) {
-            // (a slot index past the bin reads another wave's tile or zeros: the lane is masked out by j < nLane)
-            const float4 tmin = T[2u * j], tmax = T[2u * j + 1u];
+            // (a slot index past the bin is held inside the wave's tile; the lane is masked out by j < nLane)
+            const uint32_t jj = j < kBinCap ? j : kBinCap - 1u;
+            const float4 tmin = T[2u * jj], tmax = T[2u * jj + 1u];
             // mask arithmetic instead of short-circuit branches: 6 + 2 compares, and the wave skips the round on an empty mask
             const unsigned long long m = ballot64(j < nLane) & ballot64(j - c >= span) &
                                          ballot64(cmin.x <= tmax.x) & ballot64(tmin.x <= cmax.x) & ballot64(cmin.y <= tmax.y) &
