@@ -31,7 +31,8 @@ w.camera = sw.default_camera(3.0 * S * 64.0)          # the middle of the 3x3 wo
 if args.workload == "config3dyn":
     dyn = (np.arange(w.n) % 16) == 4
     w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
-out = {"world": f"{w.n} entities, centre tile of a 3x3 grid, loop-back RCCL (8 sends + 8 receives per step)"}
+out = {"world": f"{w.n} entities, centre tile of a 3x1 grid, loop-back RCCL (2 sends + 2 receives per step)" if args.row else
+                f"{w.n} entities, centre tile of a 3x3 grid, loop-back RCCL (8 sends + 8 receives per step)", "graph_replay": bool(args.graph)}
 flags = capi.FULL | capi.PRODUCE_NEXT
 for pipelined in (0, 2, 3, 4):
     if args.only >= 0 and pipelined != args.only:
