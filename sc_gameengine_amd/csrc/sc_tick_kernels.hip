@@ -1458,28 +1458,36 @@ __device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickP
   // 2 * kTile ring bins at a time (one pass for a 256-sector side): a thread takes two neighbouring bins, finds their
   // offsets (parallel scan, carry across chunks) and copies their records.  Ring bins are sparse, and 512 bins in flight
   // hide the latency that a wave-per-bin walk would serialise (measured: 59 us against 14).
-  auto copyBin = [&](uint32_t cell, uint32_t off, uint32_t take) {
+  // (the kernel is a chain of dependent memory round trips, nothing else: a bin's FIRST record is requested together with its
+  //  count -- its address does not depend on the count, most ring bins hold none or one -- and so is the big-box count below)
+  const uint32_t ctr = kCtrPar + 8u * p.parity;
+  const uint32_t nLocal = min(d.counters[ctr + kCtrBig], p.bigCap);          // the merge has not run yet: only this tile's boxes
+  auto copyBin = [&](uint32_t cell, uint32_t off, uint32_t take, const float4& lo0, const float4& hi0) {
     const float4* src = d.bins + 2u * ((size_t)cell * kBinCap);
     float4* dst = records + 2u * (size_t)off;
-    for (uint32_t r = 0; r < take; ++r) { dst[2u * r] = src[2u * r]; dst[2u * r + 1u] = src[2u * r + 1u]; }
+    dst[0] = lo0; dst[1] = hi0;
+    for (uint32_t r = 1; r < take; ++r) { dst[2u * r] = src[2u * r]; dst[2u * r + 1u] = src[2u * r + 1u]; }
   };
   uint32_t carry = 0;
   for (uint32_t base = 0; base < L; base += 2u * kTile) {
     const uint32_t l0 = base + 2u * threadIdx.x, l1 = l0 + 1u;
     uint32_t c0 = 0, c1 = 0, cell0 = 0, cell1 = 0;
+    float4 a0 = make_float4(0, 0, 0, 0), b0 = a0, a1 = a0, b1 = a0;
     // (a ring sector carries at most one bin's worth of boxes across the border: what overflowed there is counted as lost)
     uint32_t over = 0;
-    if (l0 < L) { bool send = false; cell0 = ringCell(p, dx, dz, l0, &send); if (send) { c0 = d.binCount[cell0]; if (c0 > kBinCap) { over += c0 - kBinCap; c0 = kBinCap; } } }
-    if (l1 < L) { bool send = false; cell1 = ringCell(p, dx, dz, l1, &send); if (send) { c1 = d.binCount[cell1]; if (c1 > kBinCap) { over += c1 - kBinCap; c1 = kBinCap; } } }
-    if (over) atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBorderLost], over);
+    if (l0 < L) { bool send = false; cell0 = ringCell(p, dx, dz, l0, &send); if (send) { c0 = d.binCount[cell0]; const float4* r = d.bins + 2u * ((size_t)cell0 * kBinCap); a0 = r[0]; b0 = r[1]; } }
+    if (l1 < L) { bool send = false; cell1 = ringCell(p, dx, dz, l1, &send); if (send) { c1 = d.binCount[cell1]; const float4* r = d.bins + 2u * ((size_t)cell1 * kBinCap); a1 = r[0]; b1 = r[1]; } }
+    if (c0 > kBinCap) { over += c0 - kBinCap; c0 = kBinCap; }
+    if (c1 > kBinCap) { over += c1 - kBinCap; c1 = kBinCap; }
+    if (over) atomicAdd(&d.counters[ctr + kCtrBorderLost], over);
     uint32_t total;
     const uint32_t off0 = blockScanExclusive(c0 + c1, carry, sWave, &total), off1 = off0 + c0;
     const uint32_t take0 = (off0 + c0 <= cap) ? c0 : (off0 < cap ? cap - off0 : 0u);
     const uint32_t take1 = (off1 + c1 <= cap) ? c1 : (off1 < cap ? cap - off1 : 0u);
     if (l0 < L) msg[kBorderHeader + l0] = take0;
     if (l1 < L) msg[kBorderHeader + l1] = take1;
-    if (take0) copyBin(cell0, off0, take0);
-    if (take1) copyBin(cell1, off1, take1);
+    if (take0) copyBin(cell0, off0, take0, a0, b0);
+    if (take1) copyBin(cell1, off1, take1, a1, b1);
     carry = total;
   }
   if (threadIdx.x == 0) { msg[0] = carry < cap ? carry : cap; msg[1] = carry > cap ? 1u : 0u; }
@@ -1490,8 +1498,6 @@ __device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickP
   __shared__ uint32_t bigCount, bigLost;
   if (threadIdx.x == 0) { bigCount = 0u; bigLost = 0u; }
   __syncthreads();
-  const uint32_t ctr = kCtrPar + 8u * p.parity;
-  const uint32_t nLocal = min(d.counters[ctr + kCtrBig], p.bigCap);          // the merge has not run yet: only this tile's boxes
   if (p.tilesX) {
     const float SX = (float)(p.binSX - 2u), SZ = (float)(p.binSZ - 2u);
     const float inf = INFINITY;
@@ -1557,14 +1563,18 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
   const uint32_t ctr = kCtrPar + 8u * p.parity;
   if (threadIdx.x == 0 && msg[1]) atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);   // sender ran out of message space
   const float4* records = reinterpret_cast<const float4*>(msg + kBorderHeader + L);
+  // (requested up front, used at the end: the kernel is a chain of dependent round trips)
+  const uint32_t* big = msg + borderBinWords(dir, p.binSX - 2u, p.binSZ - 2u);
+  const uint32_t bigHead0 = big[0], bigHead1 = big[1];
   auto landBin = [&](uint32_t l, uint32_t off, uint32_t c) {
     // the sender's ring cell l on its side (-dx,-dz) is this tile's cell l along its own side (dx,dz)
     const uint32_t sector = landingCell(p, dx, dz, l);
-    const uint32_t slot0 = atomicAdd(&d.binCount[sector], c);
     const float4* src = records + 2u * (size_t)off;
+    const float4 lo0 = src[0], hi0 = src[1];                      // in flight together with the slot reservation
+    const uint32_t slot0 = atomicAdd(&d.binCount[sector], c);
     uint32_t lay = 0;
     for (uint32_t r = 0; r < c; ++r) {
-      const float4 lo = src[2u * r], hi = src[2u * r + 1u];
+      const float4 lo = r ? src[2u * r] : lo0, hi = r ? src[2u * r + 1u] : hi0;
       lay |= __float_as_uint(lo.w);
       if (slot0 + r < kBinCap) {
         float4* dst = d.bins + 2u * ((size_t)sector * kBinCap + slot0 + r);
@@ -1593,11 +1603,10 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
     carry = total;
   }
   // the neighbour's big boxes that reach this tile join the big list behind this tile's own
-  const uint32_t* big = msg + borderBinWords(dir, p.binSX - 2u, p.binSZ - 2u);
-  const uint32_t m = big[0] < kBorderBigCap ? big[0] : kBorderBigCap;
+  const uint32_t m = bigHead0 < kBorderBigCap ? bigHead0 : kBorderBigCap;
   if (threadIdx.x == 0) {
     sOff[0] = m ? atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBig], m) : 0u;
-    if (big[1]) atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBorderLost], 1u);
+    if (bigHead1) atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrBorderLost], 1u);
   }
   __syncthreads();
   const uint32_t at = sOff[0];
