@@ -286,6 +286,24 @@ __device__ __forceinline__ void binInsertWave(const DeviceState& d, const TickPa
   }
 }
 
+// One record into one sector's bin by the lane itself (or into the sector overflow list when the bin is full).
+__device__ __forceinline__ void binInsertLane(const DeviceState& d, const TickParams& p, uint32_t sector, const float4& rmin, const float4& rm)
+{
+  const uint32_t slot = atomicAdd(&d.binCount[sector], 1u);
+  atomicOr(&d.binLayers[sector], __float_as_uint(rmin.w));
+  if (slot < kBinCap) {
+    float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
+    r[0] = rmin; r[1] = rm;
+  } else {
+    const uint32_t ctr = kCtrPar + 8u * p.parity;
+    const uint32_t at = atomicAdd(&d.counters[ctr + kCtrSpill], 1u);
+    if (at < p.ovfCap) {
+      d.spill[2u * (size_t)at] = rmin; d.spill[2u * (size_t)at + 1u] = rm; d.spillSector[at] = sector;
+      atomicMin(&d.ovfLo[sector], at); atomicMax(&d.ovfHi[sector], at + 1u);
+    }
+  }
+}
+
 // Whole-wave broadphase step for one entity per lane: world AABB -> bins / big list.
 __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickParams& p, uint32_t i, bool collider,
                                               const Aff& M, const BoundsCE& b)
@@ -301,13 +319,22 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
   }
   const bool binned = plan.collide && !plan.big;
   const uint32_t sx = (uint32_t)plan.x0, sz = (uint32_t)plan.z0;
-#pragma unroll
-  for (uint32_t k = 0; k < 4; ++k) {
-    const uint32_t dx = k & 1u, dz = k >> 1;
-    const bool want = binned && dx < plan.nx && dz < plan.nz;
+  // the primary copy (every box has exactly one): consecutive lanes mostly share the sector -- one reservation per run
+  {
     float4 rm = rmax;
-    if (k == 0) rm.w = __uint_as_float(i | p.rankBits | kPrimary);   // exactly one primary copy per box
-    binInsertWave(d, p, want, (sz + dz) * p.binSX + (sx + dx), rmin, rm);
+    rm.w = __uint_as_float(i | p.rankBits | kPrimary);
+    binInsertWave(d, p, binned, sz * p.binSX + sx, rmin, rm);
+  }
+  // the copies in the neighbouring sectors of a box that straddles a sector edge: a few lanes per wave (a prop is a few
+  // metres wide in a 64 m sector), almost never two of them for one sector -- a whole-wave insertion round per direction
+  // (ballots, run detection, cross-lane reads: ~40 instructions each, and nearly every wave has SOME straddler) cost
+  // more than the lanes concerned reserving their slot themselves
+  if (binned && (plan.nx > 1u || plan.nz > 1u)) {
+#pragma unroll
+    for (uint32_t k = 1; k < 4; ++k) {
+      const uint32_t dx = k & 1u, dz = k >> 1;
+      if (dx < plan.nx && dz < plan.nz) binInsertLane(d, p, (sz + dz) * p.binSX + (sx + dx), rmin, rmax);
+    }
   }
   if (plan.collide && plan.big) appendBig(d, p, rmin, rmax);
 }
@@ -326,21 +353,8 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
   for (uint32_t k = 0; k < 4; ++k) {
     const uint32_t dx = k & 1u, dz = k >> 1;
     if (!(dx < plan.nx && dz < plan.nz)) continue;
-    const uint32_t sector = (sz + dz) * p.binSX + (sx + dx);
-    const uint32_t slot = atomicAdd(&d.binCount[sector], 1u);
-    atomicOr(&d.binLayers[sector], __float_as_uint(rmin.w));
     float4 rm = rmax; if (k == 0) rm.w = __uint_as_float(i | p.rankBits | kPrimary);
-    if (slot < kBinCap) {
-      float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
-      r[0] = rmin; r[1] = rm;
-    } else {
-      const uint32_t ctr = kCtrPar + 8u * p.parity;
-      const uint32_t at = atomicAdd(&d.counters[ctr + kCtrSpill], 1u);
-      if (at < p.ovfCap) {
-        d.spill[2u * (size_t)at] = rmin; d.spill[2u * (size_t)at + 1u] = rm; d.spillSector[at] = sector;
-        atomicMin(&d.ovfLo[sector], at); atomicMax(&d.ovfHi[sector], at + 1u);
-      }
-    }
+    binInsertLane(d, p, (sz + dz) * p.binSX + (sx + dx), rmin, rm);
   }
 }
 
