@@ -143,11 +143,14 @@ __device__ __forceinline__ bool sphereVisible(const Aff& M, const BoundsCE& b, c
   c0 = M.r0[0] * b.cx + M.r0[1] * b.cy + M.r0[2] * b.cz + M.r0[3];
   c1 = M.r1[0] * b.cx + M.r1[1] * b.cy + M.r1[2] * b.cz + M.r1[3];
   c2 = M.r2[0] * b.cx + M.r2[1] * b.cy + M.r2[2] * b.cz + M.r2[3];
-  const float sx = sqrtf(M.r0[0] * M.r0[0] + M.r1[0] * M.r1[0] + M.r2[0] * M.r2[0]);
-  const float sy = sqrtf(M.r0[1] * M.r0[1] + M.r1[1] * M.r1[1] + M.r2[1] * M.r2[1]);
-  const float sz = sqrtf(M.r0[2] * M.r0[2] + M.r1[2] * M.r1[2] + M.r2[2] * M.r2[2]);
-  const float syz = (sy < sz) ? sz : sy;               // std::max(a,b) == (a<b)?b:a
-  const float maxScale = (sx < syz) ? syz : sx;
+  // max of the three column norms (std::max(a,b) == (a<b)?b:a): the correctly rounded square root is monotone and keeps
+  // NaN, so selecting among the SQUARED norms with the same comparisons and taking one root gives the value the
+  // reference gets from three roots (equal roots of unequal squares are the same value either way)
+  const float nx = M.r0[0] * M.r0[0] + M.r1[0] * M.r1[0] + M.r2[0] * M.r2[0];
+  const float ny = M.r0[1] * M.r0[1] + M.r1[1] * M.r1[1] + M.r2[1] * M.r2[1];
+  const float nz = M.r0[2] * M.r0[2] + M.r1[2] * M.r1[2] + M.r2[2] * M.r2[2];
+  const float nyz = (ny < nz) ? nz : ny;
+  const float maxScale = sqrtf((nx < nyz) ? nyz : nx);
   const float radius = sqrtf(b.ex * b.ex + b.ey * b.ey + b.ez * b.ez) * maxScale;
   bool out = false;
 #pragma unroll
@@ -166,11 +169,12 @@ __device__ __forceinline__ bool sphereVisibleAt(const Aff& M, const BoundsCE& b,
   const float c0 = M.r0[0] * b.cx + M.r0[1] * b.cy + M.r0[2] * b.cz + M.r0[3];
   const float c1 = M.r1[0] * b.cx + M.r1[1] * b.cy + M.r1[2] * b.cz + M.r1[3];
   const float c2 = M.r2[0] * b.cx + M.r2[1] * b.cy + M.r2[2] * b.cz + M.r2[3];
-  const float sx = sqrtf(M.r0[0] * M.r0[0] + M.r1[0] * M.r1[0] + M.r2[0] * M.r2[0]);
-  const float sy = sqrtf(M.r0[1] * M.r0[1] + M.r1[1] * M.r1[1] + M.r2[1] * M.r2[1]);
-  const float sz = sqrtf(M.r0[2] * M.r0[2] + M.r1[2] * M.r1[2] + M.r2[2] * M.r2[2]);
-  const float syz = (sy < sz) ? sz : sy;
-  const float maxScale = (sx < syz) ? syz : sx;
+  // (one root of the largest squared column norm instead of three roots: see sphereVisible)
+  const float nx = M.r0[0] * M.r0[0] + M.r1[0] * M.r1[0] + M.r2[0] * M.r2[0];
+  const float ny = M.r0[1] * M.r0[1] + M.r1[1] * M.r1[1] + M.r2[1] * M.r2[1];
+  const float nz = M.r0[2] * M.r0[2] + M.r1[2] * M.r1[2] + M.r2[2] * M.r2[2];
+  const float nyz = (ny < nz) ? nz : ny;
+  const float maxScale = sqrtf((nx < nyz) ? nyz : nx);
   const float radius = sqrtf(b.ex * b.ex + b.ey * b.ey + b.ez * b.ez) * maxScale;
   bool out = false;
 #pragma unroll
