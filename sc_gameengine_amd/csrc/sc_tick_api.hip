@@ -699,7 +699,7 @@ int scTickUploadLocals(ScTickContext* c, uint32_t first, uint32_t count, const f
     const uint8_t triv = (uint8_t)(((s[0][i] == 0.0f && s[1][i] == 1.0f) ? 4u : 0u) | ((s[2][i] == 0.0f && s[3][i] == 1.0f) ? 8u : 0u) |
                                    ((s[4][i] == 0.0f && s[5][i] == 1.0f) ? 16u : 0u));
     uint8_t& f = c->hFlags[first + i];
-    const uint8_t want = (f & 32u) ? 0u : triv;       // traffic agents: the device rewrites their yaw, every axis stays streamed
+    const uint8_t want = (f & 32u) ? (uint8_t)(triv & ~8u) : triv;       // traffic agents: the device rewrites their yaw -- Y is always streamed
     if ((f & 28u) != want) { f = (uint8_t)((f & ~28u) | want); c->linksStale = true; }
   }
   DeviceState& d = c->d;
@@ -1843,8 +1843,8 @@ int scTickUploadTrafficAgents(ScTickContext* c, uint32_t first, uint32_t count, 
     md[i] = mode[i];
     look[i] = lookAhead ? lookAhead[i] : 12.0f;              // TrafficAgent::lookAheadDist, sc_traffic_common.h:32
     uint8_t& f = c->hFlags[first + i];
-    const uint8_t nf = isAgent[i] ? (uint8_t)((f | 32u) & ~28u) : (uint8_t)(f & ~32u);
-    if (nf != f) { f = nf; c->linksStale = true; }            // an agent's rotation axes are always streamed (the device rewrites its yaw)
+    const uint8_t nf = isAgent[i] ? (uint8_t)((f | 32u) & ~8u) : (uint8_t)(f & ~32u);
+    if (nf != f) { f = nf; c->linksStale = true; }            // an agent's yaw is always streamed (the device rewrites it; X and Z it sets to (0, 1))
   }
   const bool ok = h2d(c, d.moverKind + first, kind.data(), (size_t)count * 4u) && h2d(c, d.aLane + first, laneId, (size_t)count * 4u) &&
                   h2d(c, d.aS + first, laneS, (size_t)count * 4u) && h2d(c, d.aSpeed + first, targetSpeed, (size_t)count * 4u) &&
