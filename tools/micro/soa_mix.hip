@@ -54,7 +54,27 @@ __global__ __launch_bounds__(256) void k_dword_x4(const float4* __restrict__ in,
   o2[4u * i + 2u] = make_float4(v[8].z + s.z, v[9].z, v[10].z, v[11].z); o2[4u * i + 3u] = make_float4(v[8].w + s.w, v[9].w, v[10].w, v[11].w);
   o3[i] = s; o4[i] = make_float4(v[0].x + s.x, v[0].y + s.y, v[0].z + s.z, v[0].w + s.w);
 }
-// fewer streams of dwords: does the COUNT of streams matter?  (same bytes per entity: 7 streams read 4 times over)
+// the layouts under discussion for the fused kernel, same bytes: NDW dword streams + NF4 float4 streams in (16 + 3: today --
+// 16 dword fields and the parent's rows; 4 + 6: position and link as dwords, the per-entity constants in three float4 groups)
+template <int NDW, int NF4>
+__global__ __launch_bounds__(256) void k_mixed(const float* __restrict__ in, const float4* __restrict__ in4, float4* __restrict__ o0, float4* __restrict__ o1, float4* __restrict__ o2, float* __restrict__ o3, float* __restrict__ o4, uint32_t n, uint32_t stride)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  float v[NDW]; float4 q[NF4];
+#pragma unroll
+  for (int k = 0; k < NDW; ++k) v[k] = in[(size_t)k * stride + i];
+#pragma unroll
+  for (int k = 0; k < NF4; ++k) q[k] = in4[(size_t)k * stride + i];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NDW; ++k) s += v[k];
+  float4 t = make_float4(s, s, s, s);
+#pragma unroll
+  for (int k = 0; k < NF4; ++k) { t.x += q[k].x; t.y += q[k].y; t.z += q[k].z; t.w += q[k].w; }
+  o0[i] = t; o1[i] = make_float4(t.y, t.x, t.w, t.z); o2[i] = make_float4(t.z, t.w, t.x, t.y);
+  o3[i] = s; o4[i] = t.x + s;
+}
 int main()
 {
   const uint32_t n = 1u << 20, stride = n + 4096u;
@@ -72,6 +92,14 @@ int main()
   run("dword SoA, 28 streams in", [&] { hipLaunchKernelGGL(k_dword<28>, dim3(n / 256), dim3(256), 0, 0, in, o0, o1, o2, o3, o4, n, stride); });
   run("float4 streams, 7 in", [&] { hipLaunchKernelGGL(k_float4, dim3(n / 256), dim3(256), 0, 0, (const float4*)in, o0, o1, o2, (float2*)o3, n, stride); });
   run("dword SoA, lane = 4 entities (16 B/lane)", [&] { hipLaunchKernelGGL(k_dword_x4, dim3(n / 1024), dim3(256), 0, 0, (const float4*)in, o0, o1, o2, (float4*)o3, (float4*)o4, n / 4, stride / 4); });
+  {
+    float4* in4; if (hipMalloc(&in4, (size_t)8 * stride * 16) != hipSuccess) return 1;
+    hipMemset(in4, 0, (size_t)8 * stride * 16);
+    run("16 dword + 3 float4 in (today)", [&] { hipLaunchKernelGGL((k_mixed<16, 3>), dim3(n / 256), dim3(256), 0, 0, in, in4, o0, o1, o2, o3, o4, n, stride); });
+    run("4 dword + 6 float4 in (constants packed)", [&] { hipLaunchKernelGGL((k_mixed<4, 6>), dim3(n / 256), dim3(256), 0, 0, in, in4, o0, o1, o2, o3, o4, n, stride); });
+    run("16 dword + 3 float4 in (today) again", [&] { hipLaunchKernelGGL((k_mixed<16, 3>), dim3(n / 256), dim3(256), 0, 0, in, in4, o0, o1, o2, o3, o4, n, stride); });
+    run("1 dword + 7 float4 in (all packed)", [&] { hipLaunchKernelGGL((k_mixed<1, 7>), dim3(n / 256), dim3(256), 0, 0, in, in4, o0, o1, o2, o3, o4, n, stride); });
+  }
   run("dword SoA again", [&] { hipLaunchKernelGGL(k_dword<28>, dim3(n / 256), dim3(256), 0, 0, in, o0, o1, o2, o3, o4, n, stride); });
   return 0;
 }
