@@ -70,6 +70,15 @@ for pipelined in (0, 2, 3, 4):
         lone.append(time.perf_counter() - t1)
     t.sync()
     out[key + "_host_issue_idle_queue_us"] = round(float(np.median(lone)) * 1e6, 2)
+    # the tick stream's own kernels under this flow (every 8th step sampled: events are not free)
+    t.set_profiling(8)
+    for _ in range(160):
+        t.tile_step(flags)
+    t.sync()
+    kx, kc = t.kernel_times_ms(capi.K_XFORM_CULL), t.kernel_times_ms(capi.K_COMPACT)
+    t.set_profiling(0)
+    out[key + "_k_xform_cull_us"] = round(float(np.median(kx)) * 1e3, 2) if len(kx) else None
+    out[key + "_k_compact_pack_us"] = round(float(np.median(kc)) * 1e3, 2) if len(kc) else None
     c = t.counts()
     out[key + "_visible"] = int(c.visible)
     out[key + "_border_lost"] = int(c.border_lost)
