@@ -93,6 +93,8 @@ struct ScTickContext
   bool pairGraphExchange[kMaxParity] = {};
   uint64_t pairGraphEpoch[kMaxParity] = { ~0ull, ~0ull, ~0ull, ~0ull };
   bool lastTickSampled = false;                        // the last scTickRun recorded profiling events (ran eagerly)
+  bool capturing = false;                              // enqueueStages runs inside a stream capture
+  bool packedRides = false;                            // this tick's `packed` event was attached to the compaction + pack dispatch
 
   // broadphase
   uint32_t sectors = 0, maxPairs = 0;
@@ -442,7 +444,8 @@ void waitParityFree(ScTickContext* c, const TickParams& p)
 void publishPacked(ScTickContext* c, const TickParams& p)
 {
   if (!c->pairsStream || !(p.flags & SC_TICK_BROADPHASE) || !(p.flags & SC_TICK_SPLIT_PAIRS)) return;
-  hipEventRecord(c->packed[p.parity], c->stream);
+  if (!c->packedRides) hipEventRecord(c->packed[p.parity], c->stream);
+  c->packedRides = false;
   hipStreamWaitEvent(c->pairsStream, c->packed[p.parity], 0);
 }
 
@@ -490,7 +493,10 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     const bool packToo = needCompact && (flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_SPLIT_PAIRS) && !(c->variant & 8u);
     if (packToo) {
       Scoped s(c, SC_TICK_K_COMPACT);
-      launchCompactPack(ds, p, grid, c->stream);                                    // compaction and pack share a launch
+      // pipelined tile, eager: the `packed` event rides on the dispatch (publishPacked then only makes the pairs stream wait)
+      const bool ride = c->pairsStream && !c->capturing && !s.on && (c->variant & 4u) == 0u;
+      launchCompactPack(ds, p, grid, c->stream, ride ? c->packed[p.parity] : nullptr);      // compaction and pack share a launch
+      c->packedRides = ride;
     } else if (needCompact) {
       Scoped s(c, SC_TICK_K_COMPACT);
       launchCompact(ds, p, grid, c->stream);
@@ -1113,13 +1119,13 @@ int scTickSetFreezeCulling(ScTickContext* c, int freeze)
 static int exchangeBorders(ScTickContext* c, uint32_t parity, hipStream_t s);
 
 // merge what the neighbours sent, answer the ray queries, search the pairs: the half of a tile's step behind the exchange
-static void enqueuePairHalf(ScTickContext* c, const TickParams& pp, hipStream_t ps, bool withSnapshot)
+static void enqueuePairHalf(ScTickContext* c, const TickParams& pp, hipStream_t ps, bool withSnapshot, hipEvent_t done = nullptr)
 {
   const DeviceState ds = stateFor(c, pp.parity);
   launchBorderMerge(ds, pp, ps);
   if (pp.flags & SC_TICK_RAYS) launchRayQueries(ds, pp, c->rays, ps);   // sees the neighbours' border boxes too
   launchPairs(ds, pp, ps);
-  if (withSnapshot) launchSnapshotReset(ds, pp.parity, ps);
+  if (withSnapshot) launchSnapshotReset(ds, pp.parity, ps, done);       // (`done` rides on the half's last dispatch)
 }
 
 int scTickRun(ScTickContext* c, uint32_t flags)
@@ -1162,7 +1168,9 @@ int scTickRun(ScTickContext* c, uint32_t flags)
       // communicator's own resources from inside the capture).
       const bool whole = c->captureWholeStep;
       HIP_OK(c, hipStreamBeginCapture(c->stream, whole ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
+      c->capturing = true;
       enqueueStages(c, p, grid, false);
+      c->capturing = false;
       int okx = 1;
       if (whole) { okx = exchangeBorders(c, p.parity, c->stream); if (okx) enqueuePairHalf(c, p, c->stream, false); }
       const hipError_t ce = hipStreamEndCapture(c->stream, &c->graph[q]);
@@ -1211,11 +1219,12 @@ static int runPendingPairs(ScTickContext* c, bool withExchange)
         c->pairGraphParams[q] = pp; c->pairGraphEpoch[q] = c->topoEpoch; c->pairGraphExchange[q] = withExchange;
       }
       HIP_OK(c, hipGraphLaunch(c->pairGraphExec[q], ps));
+      HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
     } else {
       if (withExchange && !exchangeBorders(c, q, ps)) return 0;
-      enqueuePairHalf(c, pp, ps, true);
+      if (c->variant & 4u) { enqueuePairHalf(c, pp, ps, true); HIP_OK(c, hipEventRecord(c->pairsDone[q], ps)); }
+      else enqueuePairHalf(c, pp, ps, true, c->pairsDone[q]);
     }
-    HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
     c->pairsInFlight[q] = true;
   } else {
     if (withExchange && !exchangeBorders(c, q, ps)) return 0;

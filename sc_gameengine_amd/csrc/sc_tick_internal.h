@@ -218,7 +218,7 @@ void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s);
 uint32_t pairRunLog2(uint32_t sectors);
 void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s, hipEvent_t evA = nullptr, hipEvent_t evB = nullptr);
 void launchGatherPairs(const DeviceState& d, const TickParams& p, uint32_t parity, uint2* dst, uint32_t* total, hipStream_t s);
-void launchCompactPack(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
+void launchCompactPack(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t done = nullptr);
 void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchBorderMerge(const DeviceState& d, const TickParams& p, hipStream_t s);
 void launchNudgeRootsX(const DeviceState& d, uint32_t n, float dx, hipStream_t s);
@@ -231,7 +231,7 @@ void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, h
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);
 void launchMoveEntities(const DeviceState& d, const uint32_t* src, const uint32_t* dst, uint32_t moves, hipStream_t s);
 void launchSetFrustum(const DeviceState& d, const Frustum6& fr, hipStream_t s);
-void launchSnapshotReset(const DeviceState& d, uint32_t q, hipStream_t s);
+void launchSnapshotReset(const DeviceState& d, uint32_t q, hipStream_t s, hipEvent_t done = nullptr);
 void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s);
 void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s);
 void launchEmitDraws(const DeviceState& d, uint32_t budget, void* items, hipStream_t s);

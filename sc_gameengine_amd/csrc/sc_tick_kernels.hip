@@ -1972,11 +1972,13 @@ void launchGatherPairs(const DeviceState& d, const TickParams& p, uint32_t parit
 {
   hipLaunchKernelGGL(k_gather_pairs, dim3(kPairShards), dim3(kTile), 0, s, d, p, parity, dst, total);
 }
-void launchCompactPack(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s)
+void launchCompactPack(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t done)
 {
   const uint32_t g = compactGroup(p, grid, false);
   const uint32_t blocks = (grid + g - 1) / g;
-  hipLaunchKernelGGL(k_compact_pack, dim3(blocks + 8u), dim3(kTile), 0, s, d, p, blocks, g);
+  // `done`: recorded by the dispatch itself (its completion signal) -- no marker packet behind the kernel on the tick queue
+  if (done) hipExtLaunchKernelGGL(k_compact_pack, dim3(blocks + 8u), dim3(kTile), 0, s, nullptr, done, 0, d, p, blocks, g);
+  else hipLaunchKernelGGL(k_compact_pack, dim3(blocks + 8u), dim3(kTile), 0, s, d, p, blocks, g);
 }
 void launchBorderPack(const DeviceState& d, const TickParams& p, hipStream_t s)
 {
@@ -2036,9 +2038,11 @@ void launchSetFrustum(const DeviceState& d, const Frustum6& fr, hipStream_t s)
 {
   hipLaunchKernelGGL(k_set_frustum, dim3(1), dim3(64), 0, s, const_cast<float*>(d.frustum), fr);
 }
-void launchSnapshotReset(const DeviceState& d, uint32_t q, hipStream_t s)
+void launchSnapshotReset(const DeviceState& d, uint32_t q, hipStream_t s, hipEvent_t done)
 {
-  hipLaunchKernelGGL(k_snapshot_reset, dim3(1), dim3(kTile), 0, s, d, q);
+  // `done`: recorded by the dispatch itself, as in launchCompactPack
+  if (done) hipExtLaunchKernelGGL(k_snapshot_reset, dim3(1), dim3(kTile), 0, s, nullptr, done, 0, d, q);
+  else hipLaunchKernelGGL(k_snapshot_reset, dim3(1), dim3(kTile), 0, s, d, q);
 }
 void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s)
 {
