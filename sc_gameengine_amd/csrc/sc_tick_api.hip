@@ -526,10 +526,10 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     }
     const uint32_t drawMode = (flags & SC_TICK_DRAWS) ? ((flags & SC_TICK_SORT_DRAWS) ? 2u : 1u) : 0u;
     if (stagedEmit) {
-      launchEmitDrawsStaged(ds, drawBudget, rb.dBlock[f], rb.maxVisible, rb.frames, c->stream);
+      launchEmitDrawsStaged(ds, drawBudget, rb.dBlock[f], rb.maxVisible, rb.frames, c->stream, rb.staged[f]);
       c->lastDraws = rb.dBlock[f] + kFrameHeaderWords + rb.maxVisible;       // what scTickReadDraws returns for this tick
-    } else launchStageFrame(ds, rb.dBlock[f], rb.maxVisible, rb.maxDraws, c->dDraws, drawMode, rb.frames, c->stream);
-    hipEventRecord(rb.staged[f], c->stream);
+    } else launchStageFrame(ds, rb.dBlock[f], rb.maxVisible, rb.maxDraws, c->dDraws, drawMode, rb.frames, c->stream, rb.staged[f]);
+    // (`staged` rides on the staging dispatch: its completion signal, no marker packet on the tick queue)
     hipStreamWaitEvent(rb.copyStream, rb.staged[f], 0);
     hipMemcpyAsync(rb.hBlock[f], rb.dBlock[f], rb.bytes, hipMemcpyDeviceToHost, rb.copyStream);
     hipEventRecord(rb.copied[f], rb.copyStream);

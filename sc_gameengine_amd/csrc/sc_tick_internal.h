@@ -237,8 +237,8 @@ void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count,
 void launchEmitDraws(const DeviceState& d, uint32_t budget, void* items, hipStream_t s);
 // frame read-back block: header (kFrameHeaderWords), visible indices, draw items
 constexpr uint32_t kFrameHeaderWords = 16;
-void launchEmitDrawsStaged(const DeviceState& d, uint32_t budget, uint32_t* block, uint32_t maxVisible, uint64_t tick, hipStream_t s);
+void launchEmitDrawsStaged(const DeviceState& d, uint32_t budget, uint32_t* block, uint32_t maxVisible, uint64_t tick, hipStream_t s, hipEvent_t done = nullptr);
 void launchStageFrame(const DeviceState& d, uint32_t* block, uint32_t maxVisible, uint32_t maxDraws, const void* items, uint32_t drawMode /*0 none, 1 plain, 2 sorted*/,
-                      uint64_t tick, hipStream_t s);
+                      uint64_t tick, hipStream_t s, hipEvent_t done = nullptr);
 
 } // namespace sctick

@@ -1872,19 +1872,23 @@ __global__ __launch_bounds__(kTile) void k_emit_draws_staged(const DeviceState d
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-void launchEmitDrawsStaged(const DeviceState& d, uint32_t budget, uint32_t* block, uint32_t maxVisible, uint64_t tick, hipStream_t s)
+// `done` (may be null): recorded by the dispatch itself -- the event the copy stream waits for, without a marker packet
+void launchEmitDrawsStaged(const DeviceState& d, uint32_t budget, uint32_t* block, uint32_t maxVisible, uint64_t tick, hipStream_t s, hipEvent_t done)
 {
   const uint32_t work = std::max(maxVisible, budget);
   const uint32_t blocks = std::max(1u, std::min((work + kTile - 1) / kTile, 64u));
-  hipLaunchKernelGGL(k_emit_draws_staged, dim3(blocks), dim3(kTile), 0, s, d, budget, block, maxVisible, (uint32_t)tick, (uint32_t)(tick >> 32));
+  if (done) hipExtLaunchKernelGGL(k_emit_draws_staged, dim3(blocks), dim3(kTile), 0, s, nullptr, done, 0, d, budget, block, maxVisible, (uint32_t)tick, (uint32_t)(tick >> 32));
+  else hipLaunchKernelGGL(k_emit_draws_staged, dim3(blocks), dim3(kTile), 0, s, d, budget, block, maxVisible, (uint32_t)tick, (uint32_t)(tick >> 32));
 }
 void launchStageFrame(const DeviceState& d, uint32_t* block, uint32_t maxVisible, uint32_t maxDraws, const void* items, uint32_t drawMode,
-                      uint64_t tick, hipStream_t s)
+                      uint64_t tick, hipStream_t s, hipEvent_t done)
 {
   const uint32_t work = std::max(maxVisible, maxDraws * 5u);
   const uint32_t blocks = std::max(1u, std::min((work + kTile - 1) / kTile, 64u));
-  hipLaunchKernelGGL(k_stage_frame, dim3(blocks), dim3(kTile), 0, s, d, block, maxVisible, maxDraws, (const uint4*)items, drawMode,
-                     (uint32_t)tick, (uint32_t)(tick >> 32));
+  if (done) hipExtLaunchKernelGGL(k_stage_frame, dim3(blocks), dim3(kTile), 0, s, nullptr, done, 0, d, block, maxVisible, maxDraws, (const uint4*)items, drawMode,
+                                  (uint32_t)tick, (uint32_t)(tick >> 32));
+  else hipLaunchKernelGGL(k_stage_frame, dim3(blocks), dim3(kTile), 0, s, d, block, maxVisible, maxDraws, (const uint4*)items, drawMode,
+                          (uint32_t)tick, (uint32_t)(tick >> 32));
 }
 // evA / evB (both or neither): events that take the kernel's own begin / end timestamps (hipExtLaunchKernelGGL), so the
 // duration bench.py reports is the dispatch's, like the kernel trace's -- not the gap-inclusive span between two
