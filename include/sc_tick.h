@@ -194,8 +194,9 @@ int scTickRunPairs(ScTickContext* ctx);
  * everything the two halves share -- bins, big list, spill list, border messages -- exists `depth` times (3 unless
  * scTickSetPipelined chose otherwise, at most 4), selected by tick parity t mod depth (counters, big-box bits and the pair
  * output already are).  The library orders the halves with events: scTickRun makes the pairs stream wait for the pack of its
- * tick, and tick t+depth, which reuses tick t's bins and counters, first waits for the pair half of tick t.  With depth 3 the
- * pair half (exchange latency included) may take up to two ticks before it holds anything up.  The caller issues the exchange
+ * tick, and tick t+depth-1, whose end-of-tick kernel clears the counters tick t+depth fills again, first waits for the pair half
+ * of tick t.  With depth d the pair half (exchange latency included) may take up to d-2 ticks before it holds anything up;
+ * until that clearing, the parity keeps tick t's results (counts, pair shard counters) for the host to read.  The caller issues the exchange
  * of tick t on the pairs stream after scTickRun (border buffers of parity t mod depth, counted from the moment the pairs stream
  * was set: scTickBindBorderBuffersParity), then calls scTickRunPairs -- e.g. the pairs
  * stream is torch's current stream, where its RCCL operations go, and the tick runs on the context's own stream.
@@ -218,7 +219,7 @@ int scTickBindBorderBuffersParity(ScTickContext* ctx, uint32_t parity, uint32_t 
  * Nothing in it waits on the host.  A tile without neighbours (1x1 grid) runs scTickRun(flags).  A tile WITH neighbours
  * and no communicator fails: the exchange is never skipped silently.
  * scTickSetPipelined(n) = scTickSetPairsStream with a second stream of the library's own: n = 0 off, 1 = on with the default
- * depth (3 copies of the per-tick broadphase state), 2..4 = on with that depth. */
+ * depth (4 copies of the per-tick broadphase state), 2..4 = on with that depth (2 leaves the pair half no tick to hide under). */
 #define SC_TICK_COMM_ID_BYTES 128
 int scTickCommGetUniqueId(uint8_t id[SC_TICK_COMM_ID_BYTES]);
 int scTickCommInit(ScTickContext* ctx, const uint8_t id[SC_TICK_COMM_ID_BYTES], uint32_t world_size, uint32_t rank);

@@ -420,7 +420,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.variant = c->variant;
   p.chain = std::min(c->maxDepth, kMaxChain);
   p.ovfCap = c->cap;
-  if (c->pairsStream && (flags & SC_TICK_BROADPHASE)) p.flags |= kFlagDeferredReset;
+  if (c->pairsStream && (flags & SC_TICK_BROADPHASE)) { p.flags |= kFlagDeferredReset; p.resetParity = (c->parity + 1u) % c->pipeDepth; }
   if (flags & SC_TICK_PRODUCE_NEXT) { p.producerKind = c->producerKind; p.producerParam = c->producerParam; }
   p.trafficSmooth = 1.0f - std::exp(-2.5f * c->producerParam);       // smoothExp(current, target, 2.5f, dt), sc_traffic_ai.cpp:58-62, :437
   p.trafficMult = c->trafficMult;
@@ -429,15 +429,19 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.tileX = c->tileX; p.tileZ = c->tileZ; p.tilesX = c->tilesX; p.tilesZ = c->tilesZ;
 }
 
-// pipelined tiles: a tick refills the bins, counters and big-box bits of its parity, which the pair half of pipeDepth ticks
-// ago read.  That half finished long ago unless the exchange is very slow; wait for it.  (Cross-stream: never captured.)
+// pipelined tiles: a tick refills the bins and counters of its parity, which the pair half of pipeDepth ticks ago read, and
+// the tick before it clears those counters.  That half finished long ago unless the exchange is very slow; wait for it.
+// (Cross-stream: never captured.)
 void waitParityFree(ScTickContext* c, const TickParams& p)
 {
-  if (!(p.flags & kFlagDeferredReset) || !c->pairsInFlight[p.parity]) return;
+  // this tick's end-of-tick kernel clears the NEXT tick's parity (TickParams::resetParity), whose last pair half -- pipeDepth - 1
+  // ticks ago -- must be over by then; this tick's own parity was made free one tick ago the same way
+  const uint32_t q = p.resetParity;
+  if (!(p.flags & kFlagDeferredReset) || !c->pairsInFlight[q]) return;
   // (a queue-to-queue wait costs a bubble of ~10 us on the device even when it is already satisfied: ask first)
-  if (hipEventQuery(c->pairsDone[p.parity]) != hipSuccess) hipStreamWaitEvent(c->stream, c->pairsDone[p.parity], 0);
+  if (hipEventQuery(c->pairsDone[q]) != hipSuccess) hipStreamWaitEvent(c->stream, c->pairsDone[q], 0);
   (void)hipGetLastError();                        // hipErrorNotReady from the query is not an error
-  c->pairsInFlight[p.parity] = false;
+  c->pairsInFlight[q] = false;
 }
 
 // pipelined tiles: whatever is queued on the pairs stream from here on (the exchange) is ordered behind this tick's pack
@@ -503,7 +507,10 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     }
     if (flags & SC_TICK_BROADPHASE) {
       if (flags & SC_TICK_SPLIT_PAIRS) {                                            // the caller exchanges, then scTickRunPairs
-        if (!packToo) launchBorderPack(ds, p, c->stream);
+        if (!packToo) {
+          launchBorderPack(ds, p, c->stream);
+          if (flags & kFlagDeferredReset) launchResetParity(ds, p.resetParity, c->stream);      // (the fused launch does it itself)
+        }
       }
       else { Scoped s(c, SC_TICK_K_PAIRS); launchPairs(ds, p, c->stream); }
     }
@@ -1119,13 +1126,13 @@ int scTickSetFreezeCulling(ScTickContext* c, int freeze)
 static int exchangeBorders(ScTickContext* c, uint32_t parity, hipStream_t s);
 
 // merge what the neighbours sent, answer the ray queries, search the pairs: the half of a tile's step behind the exchange
-static void enqueuePairHalf(ScTickContext* c, const TickParams& pp, hipStream_t ps, bool withSnapshot, hipEvent_t done = nullptr)
+// `done` (may be null) rides on the half's last dispatch; false = it could not (nothing launched): record it on the stream
+static bool enqueuePairHalf(ScTickContext* c, const TickParams& pp, hipStream_t ps, hipEvent_t done = nullptr)
 {
   const DeviceState ds = stateFor(c, pp.parity);
   launchBorderMerge(ds, pp, ps);
   if (pp.flags & SC_TICK_RAYS) launchRayQueries(ds, pp, c->rays, ps);   // sees the neighbours' border boxes too
-  launchPairs(ds, pp, ps);
-  if (withSnapshot) launchSnapshotReset(ds, pp.parity, ps, done);       // (`done` rides on the half's last dispatch)
+  return launchPairs(ds, pp, ps, done);
 }
 
 int scTickRun(ScTickContext* c, uint32_t flags)
@@ -1172,7 +1179,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
       enqueueStages(c, p, grid, false);
       c->capturing = false;
       int okx = 1;
-      if (whole) { okx = exchangeBorders(c, p.parity, c->stream); if (okx) enqueuePairHalf(c, p, c->stream, false); }
+      if (whole) { okx = exchangeBorders(c, p.parity, c->stream); if (okx) enqueuePairHalf(c, p, c->stream); }
       const hipError_t ce = hipStreamEndCapture(c->stream, &c->graph[q]);
       if (!okx) { if (c->graph[q]) { hipGraphDestroy(c->graph[q]); c->graph[q] = nullptr; } return 0; }       // (the RCCL error text is already set)
       if (ce != hipSuccess) return fail(c, "hipStreamEndCapture", ce);
@@ -1211,7 +1218,7 @@ static int runPendingPairs(ScTickContext* c, bool withExchange)
         dropPairGraph(c, (int)q);
         HIP_OK(c, hipStreamBeginCapture(ps, withExchange ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
         const int okx = withExchange ? exchangeBorders(c, q, ps) : 1;
-        if (okx) enqueuePairHalf(c, pp, ps, true);
+        if (okx) enqueuePairHalf(c, pp, ps);
         const hipError_t ce = hipStreamEndCapture(ps, &c->pairGraph[q]);
         if (!okx) { if (c->pairGraph[q]) { hipGraphDestroy(c->pairGraph[q]); c->pairGraph[q] = nullptr; } return 0; }   // (the RCCL error text is already set)
         if (ce != hipSuccess) return fail(c, "hipStreamEndCapture (pair half)", ce);
@@ -1222,14 +1229,14 @@ static int runPendingPairs(ScTickContext* c, bool withExchange)
       HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
     } else {
       if (withExchange && !exchangeBorders(c, q, ps)) return 0;
-      if (c->variant & 4u) { enqueuePairHalf(c, pp, ps, true); HIP_OK(c, hipEventRecord(c->pairsDone[q], ps)); }
-      else enqueuePairHalf(c, pp, ps, true, c->pairsDone[q]);
+      const bool rides = enqueuePairHalf(c, pp, ps, (c->variant & 4u) ? nullptr : c->pairsDone[q]);
+      if (!rides || (c->variant & 4u)) HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
     }
     c->pairsInFlight[q] = true;
   } else {
     if (withExchange && !exchangeBorders(c, q, ps)) return 0;
     Scoped s(c, SC_TICK_K_PAIRS);
-    enqueuePairHalf(c, c->pendingParams, ps, false);
+    enqueuePairHalf(c, c->pendingParams, ps);
   }
   c->pairsPending = false;
   c->lastParity = c->parity;
@@ -1440,7 +1447,7 @@ int scTickGetCounts(ScTickContext* c, ScTickCounts* out)
   uint32_t k[kCounterWords] = {};
   if (!d2h(c, k, c->d.counters, sizeof k) || !sync(c)) return 0;
   std::memset(out, 0, sizeof *out);
-  const uint32_t resultSlot = c->pairsStream ? kSnapSet : c->lastParity;      // pipelined tiles: the snapshot the pair kernel left
+  const uint32_t resultSlot = c->lastParity;      // (a pipelined tile's parity keeps its results until the tick before its next use clears it)
   const uint32_t* bp = k + kCtrPar + 8u * resultSlot;
   out->entities = c->n;
   out->renderables_total = k[6];
@@ -1581,7 +1588,7 @@ int scTickReadPairs(ScTickContext* c, uint32_t* pairs2, uint32_t cap, uint32_t* 
   if (!joinPairs(c)) return 0;
   // the pair list is kept in per-shard segments on the device; gather them into one list first
   TickParams pp{}; pp.maxPairs = c->maxPairs;
-  const uint32_t slot = c->pairsStream ? kSnapSet : c->lastParity;          // pipelined tiles: the snapshot the pair kernel left
+  const uint32_t slot = c->lastParity;
   launchGatherPairs(c->d, pp, slot, c->dPairsOut, c->dPairTotal, c->stream);
   uint32_t tot[2] = {};
   if (!d2h(c, tot, c->dPairTotal, sizeof tot) || !sync(c)) return 0;
@@ -2027,8 +2034,11 @@ int scTickSetPipelined(ScTickContext* c, int enable)
   if (!c) return 0;
   if (!bind(c)) return 0;
   if (!enable) return scTickSetPairsStream(c, nullptr);
-  if (enable > (int)kMaxParity) return fail(c, "pipeline depth must be 2..4 (1 = the default, 3)");
-  const uint32_t depth = enable == 1 ? 3u : (uint32_t)enable;
+  if (enable > (int)kMaxParity) return fail(c, "pipeline depth must be 2..4 (1 = the default, 4)");
+  // depth d: the pair half of a tick may take up to d - 2 ticks before it holds anything up (a tick's counters are cleared by
+  // the tick before it, which therefore waits for the pair half d - 1 ticks back).  4 on the loop-back: 56 us per step
+  // against 63 with 3; 2 leaves no overlap of the pair half with the next tick at all.
+  const uint32_t depth = enable == 1 ? 4u : (uint32_t)enable;
   if (depth != c->pipeDepth) {
     if (c->pairsStream && !scTickSetPairsStream(c, nullptr)) return 0;     // re-enter with the new depth
     c->pipeDepth = depth;

@@ -141,8 +141,7 @@ constexpr uint32_t kCtrPar = 8, kCtrPairs = 0, kCtrBig = 1, kCtrBinFull = 2, kCt
 // Tick "parity": which copy of the per-tick broadphase state a tick works on.  The in-order flows alternate between two
 // copies; pipelined tiles rotate through `depth` (2..kMaxParity) copies, so that the pair half of tick t may still run while
 // the fused kernels of ticks t+1 .. t+depth-1 refill the others.
-constexpr uint32_t kMaxParity = 4, kSnapSet = kMaxParity, kCounterWords = kCtrPar + 8u * (kMaxParity + 1u);
-// counter set kSnapSet and shard counter set kSnapSet: pipelined tiles' snapshot of the last pair search
+constexpr uint32_t kMaxParity = 4, kCounterWords = kCtrPar + 8u * (kMaxParity + 1u);
 // (kCtrBig counts the big list: this tile's boxes, then -- after the border merge -- its neighbours' that reach it;
 //  kCtrBigLocal keeps this tile's own count; kCtrBorderLost: records or boxes a border message had no room for, or
 //  big boxes that reach beyond the eight neighbouring tiles -- pairs may be missing)
@@ -162,6 +161,7 @@ struct TickParams {
   uint32_t neighbourMask;   // bit d set: a neighbour tile exists in direction d (its ring side is foreign)
   uint32_t variant;         // kernel variant selector (A/B tuning; 0 = default)
   uint32_t chain;           // min(deepest hierarchy level, kMaxChain): selects the fused kernel's specialisation
+  uint32_t resetParity;     // kFlagDeferredReset: the parity whose counters this tick's end-of-tick kernel clears (the next tick's)
   uint32_t tileX, tileZ, tilesX, tilesZ;   // this tile's place in the grid of equal tiles (tilesX == 0: unknown, no big-box exchange)
   uint32_t producerKind; float producerParam;   // with SC_TICK_PRODUCE_NEXT: the frame producer fused into the end-of-tick kernel
   float trafficSmooth, trafficMult;             // movers: 1 - exp(-2.5 dt) (smoothExp, sc_traffic_ai.cpp:58-62; host libm) and dbg->speedMultiplier
@@ -214,7 +214,7 @@ void launchOccupancy(const DeviceState& d, uint32_t n, const float4* q, uint32_t
 void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA = nullptr, hipEvent_t evB = nullptr);
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
-void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s);
+bool launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s, hipEvent_t done = nullptr);
 uint32_t pairRunLog2(uint32_t sectors);
 void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s, hipEvent_t evA = nullptr, hipEvent_t evB = nullptr);
 void launchGatherPairs(const DeviceState& d, const TickParams& p, uint32_t parity, uint2* dst, uint32_t* total, hipStream_t s);
@@ -231,7 +231,7 @@ void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, h
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);
 void launchMoveEntities(const DeviceState& d, const uint32_t* src, const uint32_t* dst, uint32_t moves, hipStream_t s);
 void launchSetFrustum(const DeviceState& d, const Frustum6& fr, hipStream_t s);
-void launchSnapshotReset(const DeviceState& d, uint32_t q, hipStream_t s, hipEvent_t done = nullptr);
+void launchResetParity(const DeviceState& d, uint32_t q, hipStream_t s);
 void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s);
 void launchGatherRows(const DeviceState& d, const uint32_t* idx, uint32_t count, float* out12, hipStream_t s);
 void launchEmitDraws(const DeviceState& d, uint32_t budget, void* items, hipStream_t s);

@@ -931,21 +931,19 @@ __device__ __forceinline__ void resetOtherParity(const DeviceState& d, const Tic
   (void)nblocks;
 }
 
-// Pipelined tiles: queued on the pairs stream right behind the pair kernel of parity q.  Nobody else may clear this parity's
-// state -- the next fused kernel of the OTHER parity is already running, the next of THIS parity waits for this stream -- so
-// the results are copied to the snapshot slot the host reads (counter set kSnapSet, shard counter set kSnapSet) and counters and
-// shard counters are cleared here.  (Doing it in the pair kernel's last workgroup needs a ticket per workgroup:
-// a thousand device-scope atomics on one word cost more than this launch.)
-__global__ __launch_bounds__(kTile) void k_snapshot_reset(const DeviceState d, uint32_t q)
+// Pipelined tiles: a parity's counter set and pair shard counters are cleared on the TICK stream, by the end-of-tick
+// kernel of the tick BEFORE the one that fills them again (TickParams::resetParity; the host has made sure that parity's
+// pair half is over).  Until then they hold that pair half's results for the host to read -- no snapshot, no kernel behind
+// the pair search.  (Clearing in the pair kernel's last workgroup would need a ticket per workgroup: a thousand device-scope
+// atomics on one word; a kernel of its own behind the pair search cost 4 us + a dispatch gap on the pairs stream.)
+__device__ __forceinline__ void resetParity(const DeviceState& d, uint32_t q)
 {
-  const uint32_t ctr = kCtrPar + 8u * q;
-  if (blockIdx.x == 0) {
-    uint32_t cv = 0, sv = 0;
-    if (threadIdx.x < 8) cv = d.counters[ctr + threadIdx.x];
-    if (threadIdx.x < kPairShards) sv = d.pairShardCount[(q * kPairShards + threadIdx.x) * kShardStride];
-    if (threadIdx.x < 8) { d.counters[kCtrPar + 8u * kSnapSet + threadIdx.x] = cv; d.counters[ctr + threadIdx.x] = 0u; }
-    if (threadIdx.x < kPairShards) { d.pairShardCount[(kSnapSet * kPairShards + threadIdx.x) * kShardStride] = sv; d.pairShardCount[(q * kPairShards + threadIdx.x) * kShardStride] = 0u; }
-  }
+  if (threadIdx.x < 8) d.counters[kCtrPar + 8u * q + threadIdx.x] = 0u;
+  if (threadIdx.x < kPairShards) d.pairShardCount[(q * kPairShards + threadIdx.x) * kShardStride] = 0u;
+}
+__global__ __launch_bounds__(kTile) void k_reset_parity(const DeviceState d, uint32_t q)
+{
+  if (blockIdx.x == 0) resetParity(d, q);
 }
 
 // Does this tile own sector (gx, gz) of its bin grid (coordinates may lie outside the grid)?  A sector belongs to
@@ -1000,7 +998,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   __shared__ uint32_t castTab[kCastMax + 1u];
   if (threadIdx.x >= 1u && threadIdx.x <= kCastMax) { const uint32_t G = 64u / threadIdx.x; castTab[threadIdx.x] = G | ((65536u / G + 1u) << 8); }
 
-  // next tick's counter set starts clean (pipelined tiles do this in a small kernel behind the pair kernel instead:
+  // next tick's counter set starts clean (pipelined tiles do this in the end-of-tick kernel on the tick stream instead:
   // there the next tick's fused kernel may already be filling it while this pair search runs)
   if (!(p.flags & kFlagDeferredReset)) resetOtherParity(d, p, bid, nblocks);
   __syncthreads();
@@ -1566,6 +1564,7 @@ __global__ __launch_bounds__(kTile) void k_compact_pack(const DeviceState d, con
   __shared__ uint32_t scratch[kTile / 64];
   __shared__ uint32_t moved[kMaxSpanWords];
   __shared__ uint32_t words[kCompactLdsWords];
+  if (blockIdx.x == 0 && (p.flags & kFlagDeferredReset)) resetParity(d, p.resetParity);      // pipelined tiles: next tick's counters
   if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, group, scratch, moved, words);
   else borderPackBody(d, p, blockIdx.x - compactBlocks);
 }
@@ -1959,10 +1958,13 @@ static uint32_t pairGridFor(const TickParams& p)
   const uint32_t waves = (runs + rounds - 1u) / rounds;
   return std::max(1u, (waves + kTile / 64u - 1u) / (kTile / 64u));
 }
-void launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s)
+// `done` (may be null): recorded by the dispatch itself; false = nothing launched (no sectors)
+bool launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s, hipEvent_t done)
 {
-  if (!(p.binSX * p.binSZ)) return;
-  hipLaunchKernelGGL(k_pairs, dim3(pairGridFor(p)), dim3(kTile), 0, s, d, p);
+  if (!(p.binSX * p.binSZ)) return false;
+  if (done) hipExtLaunchKernelGGL(k_pairs, dim3(pairGridFor(p)), dim3(kTile), 0, s, nullptr, done, 0, d, p);
+  else hipLaunchKernelGGL(k_pairs, dim3(pairGridFor(p)), dim3(kTile), 0, s, d, p);
+  return true;
 }
 void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s, hipEvent_t evA, hipEvent_t evB)
 {
@@ -2042,11 +2044,9 @@ void launchSetFrustum(const DeviceState& d, const Frustum6& fr, hipStream_t s)
 {
   hipLaunchKernelGGL(k_set_frustum, dim3(1), dim3(64), 0, s, const_cast<float*>(d.frustum), fr);
 }
-void launchSnapshotReset(const DeviceState& d, uint32_t q, hipStream_t s, hipEvent_t done)
+void launchResetParity(const DeviceState& d, uint32_t q, hipStream_t s)
 {
-  // `done`: recorded by the dispatch itself, as in launchCompactPack
-  if (done) hipExtLaunchKernelGGL(k_snapshot_reset, dim3(1), dim3(kTile), 0, s, nullptr, done, 0, d, q);
-  else hipLaunchKernelGGL(k_snapshot_reset, dim3(1), dim3(kTile), 0, s, d, q);
+  hipLaunchKernelGGL(k_reset_parity, dim3(1), dim3(kTile), 0, s, d, q);
 }
 void launchPatchParents(const DeviceState& d, const uint32_t* pairs, uint32_t count, hipStream_t s)
 {

@@ -374,7 +374,7 @@ class WorldTick:
         self._ok(self.lib.scTickCommDestroy(self.ctx), "scTickCommDestroy")
 
     def set_pipelined(self, on):
-        """False / 0 = off, True / 1 = on (default depth 3), 2..4 = on with that many copies of the per-tick broadphase state"""
+        """False / 0 = off, True / 1 = on (default depth 4), 2..4 = on with that many copies of the per-tick broadphase state"""
         self._ok(self.lib.scTickSetPipelined(self.ctx, int(on)), "scTickSetPipelined")
 
     def tile_step(self, flags):

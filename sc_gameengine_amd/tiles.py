@@ -74,7 +74,7 @@ class BorderBuffers:
     batched isend/irecv group costs about 25 us per operation, 200 us for eight neighbours, four ticks' worth.
     send[d] / recv[d] are views of those tensors per direction (what the single-GPU tile tests copy between contexts)."""
 
-    PIPE_DEPTH = 3          # copies a pipelined tile rotates through (scTickSetPipelined's default)
+    PIPE_DEPTH = 3          # copies a pipelined tile with a CALLER-run exchange rotates through (scTickSetPairsStream's depth)
 
     def __init__(self, tick, rank, grid, device, world_size=None, pipelined=False):
         import torch

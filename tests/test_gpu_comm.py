@@ -42,7 +42,7 @@ def keys(t):
 def test_rccl_loopback_equals_device_copy_loopback(pipelined, graph):
     """graph=True: the in-order tile step of A -- fused kernel, compaction + pack, the RCCL group, merge, pair search -- is
     captured once per tick parity and replayed with one hipGraphLaunch (BASELINE config 5: "hipGraph-captured frame").
-    pipelined = 2 / 4: that many copies of the per-tick broadphase state on A's side (True = the default, 3).
+    pipelined = 2 / 4: that many copies of the per-tick broadphase state on A's side (True = the default, 4).
     pipelined AND graph: each half of a step -- the tick on its stream; RCCL group, merge and pair search on theirs -- is a
     graph of its own, two hipGraphLaunch per step with the ordering events between them."""
     import torch
