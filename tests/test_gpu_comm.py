@@ -3,6 +3,8 @@ neighbours are all the rank itself.  What a tile sends in direction d comes back
 through real ncclSend / ncclRecv groups on the streams the tick uses.  A twin context does the same loop-back with device
 copies; both must report the same pairs, tick after tick, in the in-order and in the pipelined flow -- so the transport
 (buffers, group, posting order, stream order against the kernels around it) is what is being compared."""
+import os
+
 import numpy as np
 import pytest
 
@@ -64,12 +66,14 @@ def test_rccl_loopback_equals_device_copy_loopback(pipelined, graph):
     if pipelined:
         b.set_pairs_stream(s2.cuda_stream)
     bufs = tiles.BorderBuffers(b, RANK, GRID, "cuda", pipelined=pipelined)
+    nudge = float(os.environ.get("SC_TICK_TWIN_NUDGE", "0.6"))      # (with many steps take a small one: the boxes must stay around the tile)
     for t in (a, b):
-        t.set_frame_producer(1, 0.6)
-        t.nudge_roots_x(0.6)
+        t.set_frame_producer(1, nudge)
+        t.nudge_roots_x(nudge)
 
     seen = 0
-    for step in range(6):
+    steps = int(os.environ.get("SC_TICK_TWIN_STEPS", "6"))          # (a long run now and then: SC_TICK_TWIN_STEPS=300)
+    for step in range(steps):
         a.tile_step(flags)
         b.run(flags | capi.SPLIT_PAIRS)
         q = (step % len(bufs.sets)) if pipelined else 0
@@ -84,7 +88,7 @@ def test_rccl_loopback_equals_device_copy_loopback(pipelined, graph):
                 recv[7 - d].copy_(send[d])
             torch.cuda.synchronize()
         b.run_pairs()
-        if step >= 3:                                       # reading results joins the streams: do it on the later steps only
+        if step >= steps - 3:                               # reading results joins the streams: do it on the last steps only
             ka, kb = keys(a), keys(b)
             assert np.array_equal(ka, kb), f"step {step}: {len(ka)} vs {len(kb)} pairs"
             assert np.array_equal(a.visible(), b.visible())
