@@ -397,6 +397,17 @@ struct Scoped
   ~Scoped() { if (on) { hipEventRecord(p.b, c->stream); c->times[k].push_back(p); } }
 };
 
+// Capacity of the sector overflow list, in records.  A box has at most four records (the sectors its xz range touches), a
+// bin keeps 64 of a sector's, so 4 x capacity can never run out for a tile's own boxes however crowded its sectors are; the
+// neighbours' border records that find their landing bin full come on top (what a border message can carry, eight messages).
+uint32_t ovfRecords(const ScTickContext* c)
+{
+  const uint64_t own = 4ull * c->cap;
+  uint64_t border = 0;
+  for (uint32_t d = 0; d < 8; ++d) border += borderRecCap(borderLen(d, c->desc.tile_sectors_x, c->desc.tile_sectors_z));
+  return (uint32_t)std::min<uint64_t>(own + border, 0xFFFFFF00ull);
+}
+
 void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
 {
   std::memset(&p, 0, sizeof p);
@@ -419,7 +430,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.neighbourMask = c->neighbourMask;
   p.variant = c->variant;
   p.chain = std::min(c->maxDepth, kMaxChain);
-  p.ovfCap = c->cap;
+  p.ovfCap = ovfRecords(c);
   if (c->pairsStream && (flags & SC_TICK_BROADPHASE)) { p.flags |= kFlagDeferredReset; p.resetParity = (c->parity + 1u) % c->pipeDepth; }
   if (flags & SC_TICK_PRODUCE_NEXT) { p.producerKind = c->producerKind; p.producerParam = c->producerParam; }
   p.trafficSmooth = 1.0f - std::exp(-2.5f * c->producerParam);       // smoothExp(current, target, 2.5f, dt), sc_traffic_ai.cpp:58-62, :437
@@ -634,7 +645,7 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
     if ((uint64_t)desc->tile_sectors_x * desc->tile_sectors_z > (1u << 24) || desc->tile_sectors_x > 65533u || desc->tile_sectors_z > 65533u)
       ok = fail(c, "tile rectangle too large");           // (the pair search carries a sector's grid coordinates as 16 + 16 bits)
     ok = ok && dalloc(c, d.binCount, c->sectors) && dalloc(c, d.binLayers, c->sectors) && dalloc(c, d.bins, (size_t)c->sectors * kBinCap * 2u, false)
-            && dalloc(c, d.bigList, (N + 8u * kBorderBigCap) * 2u, false) && dalloc(c, d.spill, 2u * N, false) && dalloc(c, d.spillSector, N)
+            && dalloc(c, d.bigList, (N + 8u * kBorderBigCap) * 2u, false) && dalloc(c, d.spill, 2u * (size_t)ovfRecords(c), false) && dalloc(c, d.spillSector, ovfRecords(c))
             && dalloc(c, d.ovfIdx, (size_t)kOvfWaves * kOvfPerSector, false) && dalloc(c, d.ovfLo, c->sectors, false) && dalloc(c, d.ovfHi, c->sectors)
             && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, (kMaxParity + 1u) * kPairShards * kShardStride)
             && dalloc(c, c->dPairsOut, c->maxPairs, false) && dalloc(c, c->dPairTotal, 4);
@@ -1341,7 +1352,7 @@ int scTickSetPairsStream(ScTickContext* c, void* stream)
     const size_t N = c->cap;
     if (!a.bins && (!dalloc(c, a.binCount, c->sectors) || !dalloc(c, a.binLayers, c->sectors) ||
         !dalloc(c, a.bins, (size_t)c->sectors * kBinCap * 2u, false) || !dalloc(c, a.bigList, (N + 8u * kBorderBigCap) * 2u, false) ||
-        !dalloc(c, a.spill, 2u * N, false) || !dalloc(c, a.spillSector, N) || !dalloc(c, a.ovfLo, c->sectors, false) || !dalloc(c, a.ovfHi, c->sectors))) return 0;
+        !dalloc(c, a.spill, 2u * (size_t)ovfRecords(c), false) || !dalloc(c, a.spillSector, ovfRecords(c)) || !dalloc(c, a.ovfLo, c->sectors, false) || !dalloc(c, a.ovfHi, c->sectors))) return 0;
     if (q > 1u && !a.borderSend[0] && !a.borderRecv[0])      // (buffers bound without a parity serve every copy)
       for (int k = 0; k < 8; ++k) { a.borderSend[k] = c->alt[0].borderSend[k]; a.borderRecv[k] = c->alt[0].borderRecv[k]; }
   }

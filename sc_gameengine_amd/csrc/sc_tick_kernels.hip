@@ -286,7 +286,7 @@ __device__ __forceinline__ void binInsertWave(const DeviceState& d, const TickPa
       // sector's slice bound, the last one raises it (two atomics per run, not per record)
       if (slot == kBinCap || lane == myHead) atomicMin(&d.ovfLo[sector], at);
       if (lane + 1u == runEnd) atomicMax(&d.ovfHi[sector], at + 1u);
-    }
+    } else if (over) atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);      // (cannot happen with the list sized by ovfRecords(): never silent anyway)
   }
 }
 
@@ -304,7 +304,7 @@ __device__ __forceinline__ void binInsertLane(const DeviceState& d, const TickPa
     if (at < p.ovfCap) {
       d.spill[2u * (size_t)at] = rmin; d.spill[2u * (size_t)at + 1u] = rm; d.spillSector[at] = sector;
       atomicMin(&d.ovfLo[sector], at); atomicMax(&d.ovfHi[sector], at + 1u);
-    }
+    } else atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);               // (cannot happen with the list sized by ovfRecords(): never silent anyway)
   }
 }
 

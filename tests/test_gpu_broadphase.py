@@ -263,3 +263,15 @@ def test_every_count_of_dynamic_records_per_sector(oracle, dyn_per_sector):
     c = t.counts()
     assert c.pairs > 20 * dyn_per_sector and c.pairs_truncated == 0 and c.border_lost == 0
     t.close(); ow.close()
+
+
+def test_overflow_list_holds_every_copy_of_every_box(oracle):
+    """Two thousand boxes around one corner where four sectors meet: most of them straddle an edge, so there are MORE overflow
+    records than entities (up to four copies of a box, 64 per bin kept).  The list is sized for that (4 x capacity); it used to
+    hold one record per entity, and what did not fit was dropped without a count (found by tools/stress_broadphase.py)."""
+    w = worlds.random_world(1956, seed=54, spread=20.0, max_depth=0, p_child=0.0, p_no_bounds=0.05)
+    w.group[:] = sw.GROUP_DYNAMIC; w.mask[:] = sw.MASK_ALL
+    t, ow = gpu_vs_oracle(oracle, w, ticks=2, nudge=0.8, max_pairs=1 << 20)
+    c = t.counts()
+    assert c.bin_overflow > w.n and c.border_lost == 0 and c.pairs_truncated == 0 and c.pairs > 10000
+    t.close(); ow.close()
