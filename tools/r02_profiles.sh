@@ -28,5 +28,5 @@ timeout -k 10 300 python3 tools/pipeline_check.py > $OUT/tile_step_16ops.log 2>&
 timeout -k 10 300 python3 tools/pipeline_check.py --row 1 > $OUT/tile_step_4ops.log 2>&1; tail -1 $OUT/tile_step_4ops.log > $OUT/tile_step_4ops.json
 timeout -k 10 300 python3 tools/pipeline_check.py --graph 1 --only 0 > $OUT/tile_step_graph.log 2>&1; tail -1 $OUT/tile_step_graph.log > $OUT/tile_step_graph.json
 timeout -k 10 300 python3 tools/crowd_probe.py > $OUT/crowd.log 2>&1; tail -2 $OUT/crowd.log > $OUT/crowded_sectors.json
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_tile -o pipe -- python3 tools/pipeline_check.py --steps 60 --only 3 --row 1 > $OUT/trace_tile.log 2>&1 && python3 tools/trace_timeline.py $OUT/trace_tile 400 | sed -n 1,60p > $OUT/tile_step_timeline_4ops.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_tile -o pipe -- python3 tools/pipeline_check.py --steps 60 --only 4 --row 1 > $OUT/trace_tile.log 2>&1 && python3 tools/trace_timeline.py $OUT/trace_tile 400 | sed -n 1,60p > $OUT/tile_step_timeline_4ops.txt
 cat $OUT/tile_step_16ops.json $OUT/tile_step_4ops.json $OUT/tile_step_graph.json $OUT/crowded_sectors.json | cut -c1-400
