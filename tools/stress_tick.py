@@ -57,6 +57,10 @@ for seed in range(args.seeds):
     graph = bool(rng.integers(0, 2)) and not use_bp
     if graph:
         t.set_graph_mode(True)
+    readback = (not graph) and bool(rng.integers(0, 2))         # the per-frame block on the copy stream (not combinable with graph replay)
+    rb_vis, rb_draws = min(n, int(rng.choice([16, 4096, 200000]))), min(n, int(rng.choice([64, 100000])))      # (at most the context's capacity)
+    if readback:
+        t.set_frame_readback(rb_vis, rb_draws)
     why = None
     for tick in range(4):
         if tick and n > 4:
@@ -88,6 +92,16 @@ for seed in range(args.seeds):
         c = t.counts()
         if not (np.array_equal(idx, ent) and np.array_equal(gmesh, mesh) and np.array_equal(gmat, mat) and np.array_equal(gmodel, model) and c.draws_dropped == dropped):
             why = "draw items differ"; break
+        if readback:
+            fr, fvis, fdraws = t.acquire_frame()
+            nv = min(len(ow.visible()), rb_vis)
+            nd = min(len(ent), rb_draws)
+            if not (fr.visible == len(ow.visible()) and fr.visible_in_buffer == nv and np.array_equal(fvis, ow.visible()[:nv])):
+                why = "frame block: visible list differs"; break
+            if not (fr.draws_emitted == len(ent) and fr.draws_in_buffer == nd and fr.draws_dropped == dropped
+                    and np.array_equal(fdraws[:, 0:4].copy().view(np.uint32).ravel(), ent[:nd])
+                    and np.array_equal(fdraws[:, 16:80].copy().view(np.float32).reshape(-1, 16), model[:nd])):
+                why = "frame block: draw items differ"; break
         if use_bp:
             mn, mx = ow.world_aabbs()
             want = oracle.broadphase_bruteforce(mn, mx, w.group, w.mask) if n <= 6000 else oracle.broadphase_grid(mn, mx, w.group, w.mask, 64.0)
