@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (vendor peak); the copy ceiling is measured below
+PROFILE_ROUND = "r03"          # profiles/<round>/pmc_traffic_<workload>.json: the PMC passes the `traffic` fields are read from
 TILE_SECTORS = 256
 PROPS = 15
 
@@ -70,15 +71,20 @@ def pmc_traffic(stages, entities_per_gpu, workload="config3", kernel="k_xform_cu
     """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_session.sh -> profiles/pmc_traffic.json):
     FETCH_SIZE and WRITE_SIZE collected in separate passes and calibrated on known-byte copy kernels of the same
     access widths (FETCH_SIZE under-counts 2x on gfx950).  None when no profile of this exact workload is committed."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-    except Exception:
-        return None
-    cfg = d.get("bench_config", {})
-    if sorted(cfg.get("stages", [])) != sorted(stages) or cfg.get("entities_per_gpu") != entities_per_gpu or cfg.get("workload", "config3") != workload:
-        return None
-    return d.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+    for path in (os.path.join(ROOT, "profiles", PROFILE_ROUND, f"pmc_traffic_{workload}.json"),
+                 os.path.join(ROOT, "profiles", "r02", f"pmc_traffic_{workload}.json"),
+                 os.path.join(ROOT, "profiles", "pmc_traffic.json")):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        cfg = d.get("bench_config", {})
+        if sorted(cfg.get("stages", [])) != sorted(stages) or cfg.get("entities_per_gpu") != entities_per_gpu or cfg.get("workload", "config3") != workload:
+            continue
+        v = d.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+        if v is not None:
+            return v
+    return None
 
 
 def copy_ceiling_gbs(torch, device):
@@ -203,6 +209,75 @@ class OracleLeg:
         self.ow.close()
 
 
+def end_of_tick_line(w, workload, SX, SZ, counts, kp_ms, stages, kind):
+    """achieved rate of the end-of-tick kernel from its algorithmic bytes (end_of_tick_bytes) and its dispatch timestamps"""
+    roots = int((w.parent < 0).sum())
+    sectors = (SX + 2) * (SZ + 2)
+    # records the pair role has to read: every record of a bin that holds an admissible pair partner (config 3: none)
+    per_sector = 32 if workload == "config5" else 16
+    records_read = 0 if workload == "config3" else int(round((per_sector + 3.0) / per_sector * w.n))   # + the ground slab's three extra copies
+    eot_ms = float(np.mean(kp_ms)) if len(kp_ms) else None
+    eot_bytes = end_of_tick_bytes(w.n, roots if kind == 1 else int((w.mover_kind > 0).sum()), int(counts.visible), sectors,
+                                  records_read, int(counts.pairs), stages, kind)
+    eot_achieved = (eot_bytes / (eot_ms * 1e-3) / 1e9) if eot_ms else None
+    return eot_ms, eot_bytes, eot_achieved
+
+
+def secondary_leg(args, workload, device, steps=20, warmup=5):
+    """The workloads whose pair search really searches, under the driver's clock: the same tick on a
+    config3dyn / config 5 world of the same size -- `steps` timed steps bracketed by synchronisation, then as many with every
+    launch timed by its dispatch timestamps, then the parity gate INCLUDING the pair set.  One GPU only."""
+    import torch
+    from sc_gameengine_amd import capi
+    from sc_gameengine_amd.tick import WorldTick, camera_view_proj
+    a2 = argparse.Namespace(**vars(args))
+    a2.workload = workload
+    w, SX, SZ = make_world(a2, 0, (1, 1))
+    stages = ["xform", "cull", "broadphase"]
+    t = WorldTick.from_world(w, device=device, broadphase=True)
+    vp = camera_view_proj(w.camera)
+    t.set_view_proj(vp)
+    kind, param = (2, 1.0 / 60.0) if workload == "config5" else (1, 0.01)
+    t.set_frame_producer(kind, param)
+    (t.advance_movers if kind == 2 else t.nudge_roots_x)(param)
+    flags = capi.FULL | capi.PRODUCE_NEXT
+    ticks = 0
+    for _ in range(warmup):
+        t.run(flags); ticks += 1
+    t.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t.run(flags); ticks += 1
+    t.sync(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t.set_profiling(1)
+    for _ in range(steps):
+        t.run(flags); ticks += 1
+    t.sync()
+    k1 = t.kernel_times_ms(capi.K_XFORM_CULL)
+    kp = t.kernel_times_ms(capi.K_PAIRS)
+    t.set_profiling(0)
+    counts = t.counts()
+    leg = OracleLeg(w)
+    parity = leg.parity(t, ticks, stages, vp)
+    leg.close()
+    eot_ms, eot_bytes, eot_achieved = end_of_tick_line(w, workload, SX, SZ, counts, kp, stages, kind)
+    dirty_frac = 0.5 if workload == "config5" else 1.0
+    bpe = algorithmic_bytes_per_entity(0.0 if workload == "config5" else float((w.parent >= 0).mean()), stages, dirty_frac)
+    k1_ms = float(np.mean(k1))
+    out = {"workload": workload, "entities": int(w.n), "steps": steps, "warmup": warmup,
+           "ms_per_step": elapsed / steps * 1e3, "value": w.n * steps / elapsed, "unit": "entities/s",
+           "pairs": int(counts.pairs), "visible": int(counts.visible), "border_lost": int(counts.border_lost),
+           "k_xform_cull": {"avg_launch_ms": k1_ms, "bytes_per_entity": bpe, "frac": w.n * bpe / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "traffic": pmc_traffic(stages, w.n, workload)},
+           "end_of_tick_kernel": {"avg_launch_ms": eot_ms, "algorithmic_bytes": eot_bytes, "achieved": eot_achieved,
+                                  "frac": (eot_achieved / HBM_PEAK_GBS) if eot_achieved else None,
+                                  "traffic": pmc_traffic(stages, w.n, workload, "k_compact_pairs")},
+           "parity_in_run": parity}
+    t.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,11 +293,17 @@ def main():
     ap.add_argument("--sample", type=int, default=0, help="record HIP events on every n-th step (0 = every step up to 64 steps, else every 8th)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity gate (profiling sessions only; the line then says so)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config3dyn / config 5 legs of the default line (N = 1, config 3)")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="rocprofv3 sessions: warm-up + the timed steps and nothing else -- no event timing, no every-launch pass, no end-to-end "
+                         "pass, no parity, no CPU leg -- so the profiler's per-kernel averages ARE the timed pass (profiles/README.md)")
     ap.add_argument("--pipeline", type=int, default=1, help="N>1: pair-search half of tick t on a second stream under the fused kernel of tick t+1")
     ap.add_argument("--control", default="nccl", help="torch.distributed backend of the CONTROL plane at N>1 (rendezvous of the RCCL id, barrier, "
                                                        "max-over-ranks timing); the data path is the library's own RCCL communicator either way")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on one GPU: every rank uses GPU 0 and the messages move by host staging (no RCCL)")
     args = ap.parse_args()
+    if args.profile_run:
+        args.no_parity = args.no_cpu_baseline = args.no_secondary = True
 
     import torch
     import torch.distributed as dist
@@ -334,7 +415,7 @@ def main():
     # same resident world, the next frames -- a second pass of the same length times EVERY launch.  Both averages are
     # reported; the roofline uses the every-launch pass.
     sample = args.sample if args.sample > 0 else (8 if args.steps > 32 else max(args.steps // 2, 1))
-    t.set_profiling(sample)
+    t.set_profiling(0 if args.profile_run else sample)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -342,8 +423,8 @@ def main():
     elapsed = time.perf_counter() - t0
     k1_region = t.kernel_times_ms(capi.K_XFORM_CULL)
     kp_region = t.kernel_times_ms(capi.K_PAIRS)
-    t.set_profiling(1)
-    for _ in range(min(args.steps, 64)):
+    t.set_profiling(0 if args.profile_run else 1)
+    for _ in range(0 if args.profile_run else min(args.steps, 64)):
         step()
     fence()
     k1 = t.kernel_times_ms(capi.K_XFORM_CULL)
@@ -357,7 +438,7 @@ def main():
     # 6000: src/sandbox/src/main.cpp:96) and reads back counts + visible list + draw items -- staged by a small kernel, ONE
     # device-to-host copy per frame on a copy stream under the next tick -- and the host consumes frame t-1 while tick t runs.
     end_to_end = None
-    if world_size == 1 and not args.graph:
+    if world_size == 1 and not args.graph and not args.profile_run:
         t.set_draw_budget(6000)
         t.set_frame_readback(8192, 6000)
         e2e_flags = flags | capi.DRAWS
@@ -415,16 +496,9 @@ def main():
         roots = int((w.parent < 0).sum())
         dirty_frac = 0.5 if args.workload == "config5" else 1.0      # config 5: only the movers (half the world, all roots) are rebuilt
         bpe = algorithmic_bytes_per_entity(0.0 if args.workload == "config5" else child_frac, stages, dirty_frac)
-        k1_ms = float(np.mean(k1)) if len(k1) else float("nan")
+        k1_ms = float(np.mean(k1)) if len(k1) else None
         achieved = (w.n * bpe) / (k1_ms * 1e-3) / 1e9 if len(k1) else None
-        sectors = (SX + 2) * (SZ + 2)
-        # records the pair role has to read: every record of a bin that holds an admissible pair partner (config 3: none)
-        per_sector = 32 if args.workload == "config5" else 16
-        records_read = 0 if args.workload == "config3" else int(round((per_sector + 3.0) / per_sector * w.n))   # + the ground slab's three extra copies
-        eot_ms = float(np.mean(kp)) if len(kp) else None
-        eot_bytes = end_of_tick_bytes(w.n, roots if kind == 1 else int((w.mover_kind > 0).sum()), int(counts.visible), sectors,
-                                      records_read, int(counts.pairs), stages, kind)
-        eot_achieved = (eot_bytes / (eot_ms * 1e-3) / 1e9) if eot_ms else None
+        eot_ms, eot_bytes, eot_achieved = end_of_tick_line(w, args.workload, SX, SZ, counts, kp, stages, kind)
         out = {
             "metric": "entities/sec world-tick (xform+broadphase+cull), 1M-entity world",
             "value": n_total * args.steps / elapsed,
@@ -501,6 +575,17 @@ def main():
             one = leg.baseline(ticks=5, warm=1, workers=0)
             out["cpu_baseline"]["single_thread_value"] = one["value"]
             out["cpu_baseline"]["single_thread_sample"] = one["sample"]
+        if world_size == 1 and args.workload == "config3" and args.sectors == TILE_SECTORS and not args.no_secondary and not args.graph:
+            # the pair search under the same clock: the headline world's pair pass is filter-skipped (all bodies static)
+            sec = []
+            for wl in ("config3dyn", "config5"):
+                leg2 = secondary_leg(args, wl, local_rank)
+                if not leg2["parity_in_run"]["ok"]:
+                    print(f"PARITY MISMATCH in the secondary leg {wl}: {json.dumps(leg2['parity_in_run'])}", file=sys.stderr)
+                    t.close()
+                    sys.exit(3)
+                sec.append(leg2)
+            out["secondary"] = sec
         print(json.dumps(out))
     if leg is not None:
         leg.close()

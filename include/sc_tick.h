@@ -201,10 +201,13 @@ int scTickRunPairs(ScTickContext* ctx);
  * was set: scTickBindBorderBuffersParity), then calls scTickRunPairs -- e.g. the pairs
  * stream is torch's current stream, where its RCCL operations go, and the tick runs on the context's own stream.
  * Read the results of tick t (pairs, ray hits, counts) after its scTickRunPairs and before the next scTickRun, as always.
- * Not combinable with graph replay.  Switching the pairs stream on or off synchronises and clears the per-parity broadphase
+ * With graph replay on (scTickSetGraphMode) each half of a pipelined step is a graph of its own, on its own stream.  Switching the pairs stream on or off synchronises and clears the per-parity broadphase
  * state (the two flows clear it differently): the previous tick's pairs / counts are no longer readable afterwards. */
 int scTickSetPairsStream(ScTickContext* ctx, void* hip_stream);
 int scTickBindBorderBuffersParity(ScTickContext* ctx, uint32_t parity, uint32_t direction, void* send_device_ptr, void* recv_device_ptr);
+/* the device buffer bound for (tick parity, direction): recv == 0 the outgoing message, != 0 the incoming one; NULL = none.
+ * Parity 0 is also the in-order flows' only set. */
+void* scTickGetBorderBuffer(ScTickContext* ctx, uint32_t parity, uint32_t direction, int recv);
 /* ---- the exchange itself, owned by the library (north_star: "Host code stays C++ ... RCCL over xGMI exchanging only
  * tile-border AABBs").  The reference has no counterpart: it is a single process ("Distributed
  * communication backend: none"); the tile sharding is this build's, its unit is the sector grid of

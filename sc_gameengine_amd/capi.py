@@ -110,6 +110,7 @@ SYMBOLS = {
     "scTickRunPairs": (C.c_int, [_CTX]),
     "scTickSetPairsStream": (C.c_int, [_CTX, C.c_void_p]),
     "scTickBindBorderBuffersParity": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "scTickGetBorderBuffer": (C.c_void_p, [_CTX, C.c_uint32, C.c_uint32, C.c_int]),
     "scTickSetStream": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
     "scTickCommGetUniqueId": (C.c_int, [U8P]),
     "scTickCommInit": (C.c_int, [_CTX, U8P, C.c_uint32, C.c_uint32]),

@@ -1134,7 +1134,7 @@ int scTickSetFreezeCulling(ScTickContext* c, int freeze)
   return 1;
 }
 
-static int exchangeBorders(ScTickContext* c, uint32_t parity, hipStream_t s);
+static int exchangeBorders(ScTickContext* c, uint32_t parity, hipStream_t s, bool inCapture);
 
 // merge what the neighbours sent, answer the ray queries, search the pairs: the half of a tile's step behind the exchange
 // `done` (may be null) rides on the half's last dispatch; false = it could not (nothing launched): record it on the stream
@@ -1171,6 +1171,13 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   TickParams p; uint32_t grid;
   fillParams(c, flags, p, grid);
   c->lastFlags = flags;
+  if ((flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_SPLIT_PAIRS) && c->neighbourMask) {
+    // every message of THIS tick parity needs its buffers: a missing one would make the pack skip that neighbour silently
+    const DeviceState ds = stateFor(c, c->parity);
+    for (uint32_t d = 0; d < 8; ++d)
+      if (((c->neighbourMask >> d) & 1u) && (!ds.borderSend[d] || !ds.borderRecv[d]))
+        return fail(c, "border buffers of this tick parity are not bound (scTickBindBorderBuffers / scTickBindBorderBuffersParity / scTickCommInit)");
+  }
   if (c->frustumStale && (flags & SC_TICK_CULL)) { launchSetFrustum(c->d, c->frustum, c->stream); c->frustumStale = false; }   // outside any graph
 
   const uint32_t q = (flags & SC_TICK_BROADPHASE) ? c->parity : 0u;
@@ -1190,10 +1197,11 @@ int scTickRun(ScTickContext* c, uint32_t flags)
       enqueueStages(c, p, grid, false);
       c->capturing = false;
       int okx = 1;
-      if (whole) { okx = exchangeBorders(c, p.parity, c->stream); if (okx) enqueuePairHalf(c, p, c->stream); }
+      if (whole) { okx = exchangeBorders(c, p.parity, c->stream, true); if (okx) enqueuePairHalf(c, p, c->stream); }
       const hipError_t ce = hipStreamEndCapture(c->stream, &c->graph[q]);
       if (!okx) { if (c->graph[q]) { hipGraphDestroy(c->graph[q]); c->graph[q] = nullptr; } return 0; }       // (the RCCL error text is already set)
       if (ce != hipSuccess) return fail(c, "hipStreamEndCapture", ce);
+      if (!c->graph[q]) return fail(c, "hipStreamEndCapture returned no graph (the capture was invalidated)");
       HIP_OK(c, hipGraphInstantiate(&c->graphExec[q], c->graph[q], nullptr, nullptr, 0));
       c->graphParams[q] = p; c->graphEpoch[q] = c->topoEpoch; c->graphWhole[q] = whole;
     }
@@ -1228,24 +1236,25 @@ static int runPendingPairs(ScTickContext* c, bool withExchange)
       if (stale) {
         dropPairGraph(c, (int)q);
         HIP_OK(c, hipStreamBeginCapture(ps, withExchange ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
-        const int okx = withExchange ? exchangeBorders(c, q, ps) : 1;
+        const int okx = withExchange ? exchangeBorders(c, q, ps, true) : 1;
         if (okx) enqueuePairHalf(c, pp, ps);
         const hipError_t ce = hipStreamEndCapture(ps, &c->pairGraph[q]);
         if (!okx) { if (c->pairGraph[q]) { hipGraphDestroy(c->pairGraph[q]); c->pairGraph[q] = nullptr; } return 0; }   // (the RCCL error text is already set)
         if (ce != hipSuccess) return fail(c, "hipStreamEndCapture (pair half)", ce);
+        if (!c->pairGraph[q]) return fail(c, "hipStreamEndCapture (pair half) returned no graph (the capture was invalidated)");
         HIP_OK(c, hipGraphInstantiate(&c->pairGraphExec[q], c->pairGraph[q], nullptr, nullptr, 0));
         c->pairGraphParams[q] = pp; c->pairGraphEpoch[q] = c->topoEpoch; c->pairGraphExchange[q] = withExchange;
       }
       HIP_OK(c, hipGraphLaunch(c->pairGraphExec[q], ps));
       HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
     } else {
-      if (withExchange && !exchangeBorders(c, q, ps)) return 0;
+      if (withExchange && !exchangeBorders(c, q, ps, false)) return 0;
       const bool rides = enqueuePairHalf(c, pp, ps, (c->variant & 4u) ? nullptr : c->pairsDone[q]);
       if (!rides || (c->variant & 4u)) HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
     }
     c->pairsInFlight[q] = true;
   } else {
-    if (withExchange && !exchangeBorders(c, q, ps)) return 0;
+    if (withExchange && !exchangeBorders(c, q, ps, false)) return 0;
     Scoped s(c, SC_TICK_K_PAIRS);
     enqueuePairHalf(c, c->pendingParams, ps);
   }
@@ -1313,6 +1322,13 @@ int scTickBindBorderBuffersParity(ScTickContext* c, uint32_t parity, uint32_t di
   return 1;
 }
 
+void* scTickGetBorderBuffer(ScTickContext* c, uint32_t parity, uint32_t dir, int recv)
+{
+  if (!c || dir > 7u || parity >= kMaxParity) return nullptr;
+  uint32_t* const* set = parity == 0 ? (recv ? c->d.borderRecv : c->d.borderSend) : (recv ? c->alt[parity - 1u].borderRecv : c->alt[parity - 1u].borderSend);
+  return set[dir];
+}
+
 int scTickSetPairsStream(ScTickContext* c, void* stream)
 {
   if (!c) return 0;
@@ -1353,8 +1369,9 @@ int scTickSetPairsStream(ScTickContext* c, void* stream)
     if (!a.bins && (!dalloc(c, a.binCount, c->sectors) || !dalloc(c, a.binLayers, c->sectors) ||
         !dalloc(c, a.bins, (size_t)c->sectors * kBinCap * 2u, false) || !dalloc(c, a.bigList, (N + 8u * kBorderBigCap) * 2u, false) ||
         !dalloc(c, a.spill, 2u * (size_t)ovfRecords(c), false) || !dalloc(c, a.spillSector, ovfRecords(c)) || !dalloc(c, a.ovfLo, c->sectors, false) || !dalloc(c, a.ovfHi, c->sectors))) return 0;
-    if (q > 1u && !a.borderSend[0] && !a.borderRecv[0])      // (buffers bound without a parity serve every copy)
-      for (int k = 0; k < 8; ++k) { a.borderSend[k] = c->alt[0].borderSend[k]; a.borderRecv[k] = c->alt[0].borderRecv[k]; }
+    // (border buffers: scTickBindBorderBuffers writes every copy's slots itself, scTickBindBorderBuffersParity and
+    //  scTickCommInit bind per parity -- nothing is inherited here.  Round 2 copied parity 1's pointers over a parity whose
+    //  direction 0 was unbound, which is every tile without a (-1,-1) neighbour: parities 1..3 then shared one message set.)
   }
   for (uint32_t k = 0; k < kMaxParity; ++k) {
     if (!c->packed[k]) HIP_OK(c, hipEventCreateWithFlags(&c->packed[k], hipEventDisableTiming | hipEventReleaseToDevice));
@@ -1989,6 +2006,8 @@ int scTickCommDestroy(ScTickContext* c)
   if (!bind(c)) return 0;
   sync(c);
   const RcclApi* r = needRccl(c);
+  // captured steps hold ncclSend / ncclRecv nodes bound to this communicator and to the peers' ranks
+  dropGraph(c); dropPairGraph(c); c->topoEpoch++;
   if (r) r->CommDestroy(c->comm);
   c->comm = nullptr; c->commSize = 0; c->commRank = 0;
   return 1;
@@ -1997,6 +2016,8 @@ int scTickCommDestroy(ScTickContext* c)
 int scTickCommSetPeers(ScTickContext* c, const int32_t peerRank[8])
 {
   if (!c || !peerRank) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !sync(c)) return 0;
+  dropGraph(c); dropPairGraph(c); c->topoEpoch++;       // a captured exchange names the old ranks
   for (int d = 0; d < 8; ++d) c->peer[d] = peerRank[d];
   c->peersSet = true;
   return 1;
@@ -2027,6 +2048,7 @@ int scTickCommInit(ScTickContext* c, const uint8_t id[SC_TICK_COMM_ID_BYTES], ui
   std::memcpy(&u, id, sizeof u);
   if (!ncclOk(c, r, r->CommInitRank(&c->comm, (int)worldSize, u, (int)rank), "ncclCommInitRank")) { c->comm = nullptr; return 0; }
   c->commSize = worldSize; c->commRank = rank;
+  dropGraph(c); dropPairGraph(c); c->topoEpoch++;       // (a graph captured against an earlier communicator must not be replayed)
   // the messages of both tick parities live in buffers of the library's own (a caller that runs its own transport binds
   // its buffers with scTickBindBorderBuffers instead and never comes here)
   for (uint32_t q = 0; q < kMaxParity; ++q)
@@ -2045,7 +2067,7 @@ int scTickSetPipelined(ScTickContext* c, int enable)
   if (!c) return 0;
   if (!bind(c)) return 0;
   if (!enable) return scTickSetPairsStream(c, nullptr);
-  if (enable > (int)kMaxParity) return fail(c, "pipeline depth must be 2..4 (1 = the default, 4)");
+  if (enable < 0 || enable > (int)kMaxParity) return fail(c, "pipeline depth must be 2..4 (1 = the default, 4; 0 = off)");
   // depth d: the pair half of a tick may take up to d - 2 ticks before it holds anything up (a tick's counters are cleared by
   // the tick before it, which therefore waits for the pair half d - 1 ticks back).  4 on the loop-back: 56 us per step
   // against 63 with 3; 2 leaves no overlap of the pair half with the next tick at all.
@@ -2064,10 +2086,20 @@ int scTickSetPipelined(ScTickContext* c, int enable)
 // neighbours on one rank (scTickCommSetPeers: a periodic world, the loop-back test), point-to-point operations between
 // two ranks match in posting order: sends go out by ascending direction, so the receives are posted by DESCENDING
 // direction -- what a peer sent as its direction d arrives here as direction 7-d.
-static int exchangeBorders(ScTickContext* c, uint32_t parity, hipStream_t s)
+// inCapture: what the caller believes about `s`.  The group is only opened when the stream's capture state is that one: an
+// RCCL group posted to a stream that is (or is not) being captured against the caller's expectation -- a capture that was
+// invalidated half way, a stream forked into somebody else's capture -- is refused here instead of being handed to RCCL.
+static int exchangeBorders(ScTickContext* c, uint32_t parity, hipStream_t s, bool inCapture)
 {
   const RcclApi* r = needRccl(c);
   if (!r) return 0;
+  if (!c->comm) return fail(c, "no communicator: scTickCommInit first");
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  const hipError_t qe = hipStreamIsCapturing(s, &st);
+  if (qe != hipSuccess) return fail(c, "hipStreamIsCapturing", qe);
+  if ((st == hipStreamCaptureStatusActive) != inCapture)
+    return fail(c, inCapture ? "border exchange: the stream is not being captured although a capture was begun (capture invalidated?)"
+                             : "border exchange: the stream is being captured by somebody else");
   const DeviceState ds = stateFor(c, parity);
   if (!ncclOk(c, r, r->GroupStart(), "ncclGroupStart")) return 0;
   ncclResult_t res = ncclSuccess;
@@ -2092,7 +2124,7 @@ int scTickExchangeBorders(ScTickContext* c)
   if (!c->pairsPending) return fail(c, "scTickExchangeBorders without a preceding scTickRun(... | SC_TICK_BROADPHASE | SC_TICK_SPLIT_PAIRS)");
   if (!c->neighbourMask) return 1;
   if (!c->comm) return fail(c, "no communicator: scTickCommInit first");
-  return exchangeBorders(c, c->pendingParams.parity, c->pairsStream ? c->pairsStream : c->stream);
+  return exchangeBorders(c, c->pendingParams.parity, c->pairsStream ? c->pairsStream : c->stream, false);
 }
 
 int scTickTileStep(ScTickContext* c, uint32_t flags)

@@ -355,6 +355,10 @@ class WorldTick:
         self._ok(self.lib.scTickBindBorderBuffersParity(self.ctx, parity, direction, C.c_void_p(send_ptr), C.c_void_p(recv_ptr)),
                  "scTickBindBorderBuffersParity")
 
+    def border_buffer(self, parity, direction, recv=False):
+        """device address of the message buffer bound for (tick parity, direction); 0 = none"""
+        return int(self.lib.scTickGetBorderBuffer(self.ctx, parity, direction, 1 if recv else 0) or 0)
+
     def run_pairs(self):
         self._ok(self.lib.scTickRunPairs(self.ctx), "scTickRunPairs")
 

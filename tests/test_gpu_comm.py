@@ -142,3 +142,70 @@ def test_a_lone_pipelined_tile_steps_without_a_communicator(oracle, graph):
             assert np.array_equal(keys(a), keys(b)) and len(keys(a)) > 50
             assert np.array_equal(a.visible(), b.visible())
     a.close(); b.close()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("depth", [3, 4])
+def test_pipelined_loopback_on_a_tile_without_a_corner_neighbour(depth):
+    """A tile of a 2x1 / 1x2 world has no (-1,-1) neighbour.  Round 2's scTickSetPairsStream took "direction 0 unbound" for
+    "bound without a parity" and overwrote parities 2 and 3 with parity 1's buffers there -- three ticks in flight shared one
+    message set.  Here: neighbours in directions 3 and 4 only (both the rank itself), comm first and pipelining second as
+    tiles.setup_tile does, many steps against the device-copy twin, and the parities' buffers must all differ."""
+    import torch
+    w = centre_tile_world(seed=11)
+    vp = camera_view_proj(w.camera)
+    flags = capi.FULL | capi.PRODUCE_NEXT
+    MASK = (1 << 3) | (1 << 4)
+    peers = [-1, -1, -1, 0, 0, -1, -1, -1]
+
+    a = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 17)
+    a.set_view_proj(vp)
+    a.set_tile_grid(1, 0, 3, 1)                       # the middle tile of a 3x1 world: mask = directions 3 and 4
+    a.comm_init(capi.comm_unique_id(), 1, 0, peers=peers)
+    a.set_pipelined(depth)
+    for d in (3, 4):
+        for recv in (False, True):
+            ptrs = [a.border_buffer(q, d, recv) for q in range(depth)]
+            assert all(ptrs) and len(set(ptrs)) == depth, f"direction {d}: parities share a buffer: {ptrs}"
+    for d in (0, 1, 2, 5, 6, 7):
+        assert a.border_buffer(1, d) == 0
+
+    b = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 17)
+    b.set_view_proj(vp)
+    b.set_tile_grid(1, 0, 3, 1)
+    s2 = torch.cuda.Stream()
+    b.set_pairs_stream(s2.cuda_stream)
+    words = {d: b.border_bytes(d) // 4 for d in (3, 4)}
+    sets = []
+    for q in range(3):                                # the caller-run twin rotates through the default three copies
+        send = {d: torch.zeros(words[d], dtype=torch.int32, device="cuda") for d in (3, 4)}
+        recv = {d: torch.zeros(words[d], dtype=torch.int32, device="cuda") for d in (3, 4)}
+        for d in (3, 4):
+            b.bind_border_parity(q, d, send[d].data_ptr(), recv[d].data_ptr())
+        sets.append((send, recv))
+    for t in (a, b):
+        t.set_frame_producer(1, 0.05)
+        t.nudge_roots_x(0.05)
+    steps = 40
+    for step in range(steps):
+        a.tile_step(flags)
+        b.run(flags | capi.SPLIT_PAIRS)
+        send, recv = sets[step % 3]
+        with torch.cuda.stream(s2):
+            for d in (3, 4):
+                recv[7 - d].copy_(send[d], non_blocking=True)
+        b.run_pairs()
+        if step % 8 == 7 or step >= steps - 2:
+            ka, kb = keys(a), keys(b)
+            assert np.array_equal(ka, kb), f"step {step}: {len(ka)} vs {len(kb)} pairs"
+            assert len(ka) > 50
+    a.close(); b.close()
+
+
+def test_pipeline_depth_is_validated():
+    w = sw.generate(4, 4, 15)
+    t = WorldTick.from_world(w, broadphase=True)
+    for bad in (-1, -7, 5):
+        with pytest.raises(capi.ScTickError, match="pipeline depth"):
+            t.set_pipelined(bad)
+    t.close()

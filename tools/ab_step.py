@@ -40,7 +40,12 @@ flags = capi.FULL | capi.PRODUCE_NEXT
 ctxs = {}
 for path in args.libs:
     lib_path, _, variant = path.partition("@")            # "lib.so@48": SC_TICK_VARIANT for this context (tuning knobs)
+    variant, _, spans = variant.partition(":")            # "lib.so@0:4096": SC_TICK_SPANS too (workgroups of the fused kernel)
     os.environ["SC_TICK_VARIANT"] = variant or "0"
+    if spans:
+        os.environ["SC_TICK_SPANS"] = spans
+    else:
+        os.environ.pop("SC_TICK_SPANS", None)
     capi._LIB = None
     capi.LIB_PATH = os.path.abspath(lib_path)
     t = WorldTick.from_world(w, broadphase=True)
@@ -73,7 +78,7 @@ vis = {p: int(t.counts().visible) for p, t in ctxs.items()}
 prs = {p: int(t.counts().pairs) for p, t in ctxs.items()}
 for path in args.libs:
     r = res[path]
-    print(json.dumps({"lib": os.path.basename(path), "workload": args.workload,
+    print(json.dumps({"lib": os.path.basename(path.partition("@")[0]) + ("@" + path.partition("@")[2] if "@" in path else ""), "workload": args.workload,
                       "step_us_median": round(float(np.median(r["step_us"])), 2), "step_us_min": round(float(np.min(r["step_us"])), 2),
                       "k_xform_cull_us": round(float(np.median(r["k1_us"])), 2), "end_of_tick_us": round(float(np.median(r["eot_us"])), 2) if r["eot_us"] else None,
                       "gap_us": round(float(np.median(r["step_us"])) - float(np.median(r["k1_us"])) - (float(np.median(r["eot_us"])) if r["eot_us"] else 0.0), 2),
