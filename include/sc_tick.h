@@ -92,8 +92,8 @@ typedef struct ScTickCounts    /* CullingStats (sc_world_partition.h:334-339) + 
   uint32_t bin_overflow;       /* bin records that found their sector's bin (64 records) full: they sit in the sector overflow list */
   uint32_t big_boxes;          /* boxes in the big list: larger than 2x2 sectors or outside the tile rectangle */
   uint32_t draws_sorted;       /* with SC_TICK_SORT_DRAWS: draws left after the renderer's mesh / material handle checks */
-  uint32_t border_lost;        /* records the fixed capacities could not carry: border messages that ran out of room, a ring sector
-                                  with more than 64 boxes, big boxes reaching beyond the eight neighbouring tiles, a sector with more
+  uint32_t border_lost;        /* records the fixed capacities could not carry: border messages that ran out of room
+                                  (scTickSetBorderCapacity), big boxes reaching beyond the eight neighbouring tiles, a sector with more
                                   than 64 + 1024 boxes; non-zero means pairs may be missing */
   uint32_t relinks;            /* whole-world hierarchy re-links (O(entities) on the host) this context has done so far */
 } ScTickCounts;
@@ -184,6 +184,14 @@ int scTickSetTile(ScTickContext* ctx, uint32_t rank, uint32_t neighbour_mask);
  * nearest tile).  A big box may reach its own tile and the eight around it; one that reaches further, or a message
  * that runs out of room, is counted in ScTickCounts::border_lost. */
 int scTickSetTileGrid(ScTickContext* ctx, uint32_t tile_x, uint32_t tile_z, uint32_t tiles_x, uint32_t tiles_z);
+/* Capacity of the border messages: `records_per_ring_sector` records per sector of a ring side ON AVERAGE (the side's
+ * sectors share the message: a crowded ring sector may take more than its share), never less than one full sector (its
+ * 64-record bin + 1024 overflow records).  Default 16 -- SynthWorld's ring sectors hold 0-2.  A world authored at the engine's
+ * streaming budget (200 entities per sector, src/sandbox/src/main.cpp:92-99) with districts on tile edges wants more; what a
+ * message cannot hold is counted in ScTickCounts::border_lost, never dropped silently.  Every tile of a world must use the
+ * same value (the two sides of an edge agree on the message size).  Call before scTickCommInit / before binding buffers:
+ * bound buffers are unbound, scTickBorderBytes changes. */
+int scTickSetBorderCapacity(ScTickContext* ctx, uint32_t records_per_ring_sector);
 /* size in bytes of the fixed-capacity border message of direction d (same on both sides of an edge) */
 uint32_t scTickBorderBytes(ScTickContext* ctx, uint32_t direction);
 /* caller-owned device buffers (e.g. torch tensors) of at least scTickBorderBytes(d) bytes each */
@@ -261,15 +269,17 @@ int scTickSetFrameProducer(ScTickContext* ctx, uint32_t kind, float param);
  * lane's speed limit (smoothExp, :58-62, response 2.5), the agent advances targetSpeed * dt along its lane
  * (TrafficLaneGraph::advanceAlongLane, src/engine/traffic/sc_traffic_lanes.cpp:291-352, crossing into the best-aligned
  * connected segment, :137-156, parking on a dead end), localPos.x/z follow the lane, localRot = (0, atan2(dir.x, dir.z), 0),
- * dirty = true.  Without a PhysicsWorld there is no obstacle ray (obstacleBrake = 0), as in the reference when
- * TrafficAIState::physics is null.  The Physics / Kinematic tiers are Bullet's (absent): agents in those modes are left
+ * dirty = true.  An agent without a lane (lane id 0xFFFFFFFF) first takes the nearest active one (:264-272,
+ * TrafficLaneGraph::queryNearestLane, sc_traffic_lanes.cpp:240-279).  The obstacle ray and its brake (:300-345) are
+ * scTickSetTrafficSensors below; without it obstacleBrake = 0, as in the reference when TrafficAIState::physics is null.
+ * The Physics / Kinematic tiers are Bullet's (absent): agents in those modes are left
  * alone, their transforms arrive through the upload calls like any physics-synced body's.
  * The lane graph is handed over flat: per segment the start node's position, the direction, length, end node, active flag
  * and the speed limit of its start node (laneSpeedLimit, sc_traffic_lanes.cpp:392-400); per node its position and the
  * segments that start there (LaneNode::connections, CSR).  sin / cos of each segment's yaw are taken here with the host
  * libm, so an agent's world matrix equals the host's bit for bit: the device never evaluates a trigonometric function.
  * scTickUploadTrafficAgents gives entities a TrafficAgent + TrafficVehicle (sc_traffic_common.h:26-44): lane id
- * (0xFFFFFFFF = none: the spawner always assigns one, sc_traffic_spawner.cpp:315-318), laneS, targetSpeed, mode 0 Physics /
+ * (0xFFFFFFFF = none: the next step looks for the nearest lane), laneS, targetSpeed, mode 0 Physics /
  * 1 Kinematic / 2 OnRails, lookAheadDist (NULL = 12).  Agents then move with scTickAdvanceMovers(dt) or as the frame
  * producer kind 2, next to SynthWorld's straight-line movers. */
 typedef struct ScTickLaneGraph
@@ -292,6 +302,21 @@ int scTickUploadTrafficAgents(ScTickContext* ctx, uint32_t first, uint32_t count
                               const float* lane_s, const float* target_speed, const uint8_t* mode, const float* look_ahead_dist);
 int scTickReadTrafficAgents(ScTickContext* ctx, uint32_t first, uint32_t count, uint32_t* lane_id, float* lane_s,
                             float* target_speed, uint8_t* mode);
+/* The traffic AI's obstacle ray (sc_traffic_ai.cpp:300-345, the branch the reference takes when TrafficAIState::physics is
+ * set).  With sensors enabled every scTickRun that includes SC_TICK_BROADPHASE casts, right after the boxes of the tick are
+ * binned, one ray per OnRails agent: from 1.7 m ahead of the agent's origin and 0.6 m above it, along
+ * normalize(sin(yaw), 0, cos(yaw)) with the yaw's sin / cos as the entity holds them, front_ray_length long (TrafficSensors::
+ * frontRayLength, 20 m), mask 1; a hit other than the agent's own box closer than safe_distance (TrafficSensors::safeDistance,
+ * 10 m) leaves obstacleBrake = clamp01((safe - d) / safe) for the agent, and the next on-rails step -- scTickAdvanceMovers or
+ * the frame producer, SC_TICK_PRODUCE_NEXT included -- scales its desired speed by 1 - obstacleBrake (:436).  As for the ray
+ * queries below the candidates are the WORLD AABBS of the broadphase with the collision layers as uploaded (own spec: Bullet
+ * is absent; an agent's own box never answers).  Order in a frame: rays from the poses of frame t against the boxes of frame
+ * t, then the step to frame t+1 -- what the reference does (the ray sees Bullet's world as the last physics step left it).
+ * On a tiled world the rays see the tile's own boxes only (they are cast before the border exchange); the brake of a run
+ * without SC_TICK_BROADPHASE is the last one computed.  One pair of values per context (the reference's per-entity
+ * TrafficSensors component falls back to exactly these defaults).  Needs agents (scTickUploadTrafficAgents) and a tile rectangle. */
+int scTickSetTrafficSensors(ScTickContext* ctx, int enable, float front_ray_length, float safe_distance);
+int scTickReadTrafficBrakes(ScTickContext* ctx, uint32_t first, uint32_t count, float* obstacle_brake);
 /* TrafficDebugState::speedMultiplier (sc_traffic_ai.cpp:297-298); 1 by default */
 int scTickSetTrafficSpeedMultiplier(ScTickContext* ctx, float multiplier);
 /* TrafficLODSystem's tier selection (src/engine/traffic/sc_traffic_lod.cpp:269-274 threshold repair, :303-307 xz distance to

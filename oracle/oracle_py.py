@@ -125,6 +125,10 @@ def lib():
     L.orc_lanes_export.argtypes = [vp, F32P, F32P, F32P, U8P, U32P, F32P, F32P, U32P, U32P]
     L.orc_lanes_advance.argtypes = [vp, U32P, F32P, C.c_float, F32P, F32P]
     L.orc_traffic_ai_onrails.argtypes = [vp, vp, U8P, U32P, F32P, F32P, U8P, F32P, C.c_float, C.c_float]
+    L.orc_traffic_ai_onrails_braked.argtypes = [vp, vp, U8P, U32P, F32P, F32P, U8P, F32P, F32P, C.c_float, C.c_float]
+    L.orc_traffic_front_ray_brakes.argtypes = [vp, F32P, F32P, U32P, U32P, U8P, U8P, C.c_float, C.c_float, F32P]
+    L.orc_lanes_query_nearest.argtypes = [vp, F32P, U32P, F32P]
+    L.orc_lanes_query_nearest.restype = C.c_int
     L.orc_traffic_lod_tiers.argtypes = [vp, U8P, U8P, F32P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, U8P, U32P]
     _LIB = L
     return L
@@ -398,6 +402,25 @@ class OracleWorld:
         assert lane_id.dtype == np.uint32 and lane_s.dtype == np.float32 and target_speed.dtype == np.float32
         self.L.orc_traffic_ai_onrails(self.w, lanes.g, ia.ctypes.data_as(U8P), _u(lane_id), _f(lane_s), _f(target_speed),
                                       md.ctypes.data_as(U8P), _f(la), float(speed_multiplier), float(dt))
+
+    def traffic_front_ray_brakes(self, mn, mx, group, mask, is_agent, mode, ray_len=20.0, safe=10.0):
+        """obstacleBrake of every OnRails agent from its front ray against the given world AABBs (sc_traffic_ai.cpp:300-345, own spec)"""
+        ia, md = np.ascontiguousarray(is_agent, np.uint8), np.ascontiguousarray(mode, np.uint8)
+        a, b = _c32(mn), _c32(mx)
+        g, m = np.ascontiguousarray(group, np.uint32), np.ascontiguousarray(mask, np.uint32)
+        out = np.zeros(len(ia), np.float32)
+        self.L.orc_traffic_front_ray_brakes(self.w, _f(a), _f(b), _u(g), _u(m), ia.ctypes.data_as(U8P), md.ctypes.data_as(U8P),
+                                            float(ray_len), float(safe), _f(out))
+        return out
+
+    def traffic_ai_onrails_braked(self, lanes, is_agent, lane_id, lane_s, target_speed, mode, look_ahead, brake, dt, speed_multiplier=1.0):
+        """as traffic_ai_onrails, with the agents' obstacle brakes (None = 0); agents without a lane take the nearest one first"""
+        ia, md = np.ascontiguousarray(is_agent, np.uint8), np.ascontiguousarray(mode, np.uint8)
+        la = _c32(look_ahead)
+        br = None if brake is None else _c32(brake)
+        assert lane_id.dtype == np.uint32 and lane_s.dtype == np.float32 and target_speed.dtype == np.float32
+        self.L.orc_traffic_ai_onrails_braked(self.w, lanes.g, ia.ctypes.data_as(U8P), _u(lane_id), _f(lane_s), _f(target_speed),
+                                             md.ctypes.data_as(U8P), _f(la), None if br is None else _f(br), float(speed_multiplier), float(dt))
 
     def traffic_lod_tiers(self, is_agent, mode, player_pos, a_enter=50.0, a_exit=70.0, b_enter=110.0, b_exit=150.0, max_physics=24, max_kinematic=64):
         ia, md = np.ascontiguousarray(is_agent, np.uint8), np.ascontiguousarray(mode, np.uint8)

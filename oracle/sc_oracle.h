@@ -201,6 +201,16 @@ int      orc_lanes_advance(const OrcLaneGraph* g, uint32_t* laneId, float* s, fl
 /* dense-order arrays; laneId / laneS / targetSpeed are updated in place (sc_traffic_ai.cpp:264-299, :434-460) */
 void     orc_traffic_ai_onrails(OrcWorld* w, const OrcLaneGraph* g, const uint8_t* isAgent, uint32_t* laneId, float* laneS,
                                 float* targetSpeed, const uint8_t* mode, const float* lookAheadDist, float speedMultiplier, float dt);
+/* the same with the obstacle brake of every agent (sc_traffic_ai.cpp:300-345, :436; NULL = none) */
+void     orc_traffic_ai_onrails_braked(OrcWorld* w, const OrcLaneGraph* g, const uint8_t* isAgent, uint32_t* laneId, float* laneS,
+                                       float* targetSpeed, const uint8_t* mode, const float* lookAheadDist, const float* obstacleBrake,
+                                       float speedMultiplier, float dt);
+int      orc_lanes_query_nearest(const OrcLaneGraph* g, const float pos[3], uint32_t* laneOut, float* sOut);   /* sc_traffic_lanes.cpp:240-279 */
+/* one agent's front ray against the world AABBs (own spec) and the brake it yields, sc_traffic_ai.cpp:300-345 */
+float    orc_traffic_front_ray_brake(uint32_t n, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
+                                     uint32_t self, const float pos[3], float sinYaw, float cosYaw, float rayLen, float safe);
+void     orc_traffic_front_ray_brakes(OrcWorld* w, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
+                                      const uint8_t* isAgent, const uint8_t* mode, float rayLen, float safe, float* brakeOut);
 /* mode / desired: 0 Physics, 1 Kinematic, 2 OnRails (sc_traffic_common.h:11-16); counts[3] after the caps (sc_traffic_lod.cpp:323-417) */
 void     orc_traffic_lod_tiers(OrcWorld* w, const uint8_t* isAgent, const uint8_t* mode, const float playerPos[3],
                                float tierAEnter, float tierAExit, float tierBEnter, float tierBExit,

@@ -6,9 +6,10 @@
  *   src/engine/traffic/sc_traffic_lanes.cpp   :33-43 quantPos/quantDir, :65-91 addNode, :93-135 addSegment,
  *                                             :137-156 chooseNextSegment, :158-225 buildProceduralForSector,
  *                                             :291-352 advanceAlongLane, :392-400 laneSpeedLimit
+ *   src/engine/traffic/sc_traffic_lanes.cpp   :240-279 queryNearestLane
  *   src/engine/traffic/sc_traffic_ai.cpp      :58-62 smoothExp, :72-75 yawFromDir, :264-299 the per-agent preamble
- *                                             (lane validity, look-ahead point, the 1e-4 early-out, desired speed),
- *                                             :434-460 the on-rails branch
+ *                                             (lane re-acquisition, lane validity, look-ahead point, the 1e-4 early-out,
+ *                                             desired speed), :300-345 the obstacle ray and its brake, :434-460 the on-rails branch
  *   src/engine/traffic/sc_traffic_lod.cpp     :269-274 threshold repair, :303-307 distances, :323-353 hysteresis,
  *                                             :355-417 the physics / kinematic caps
  * PARITY UNPINNED: the reference holds no test or fixture for these, and the translation units need
@@ -235,19 +236,140 @@ static float smoothExp(float current, float target, float response, float dt)   
   return current + (target - current) * t;
 }
 
-/* TrafficAISystem for agents whose tier is OnRails (mode 2), without a PhysicsWorld (state->physics == nullptr: no
- * obstacle ray, obstacleBrake = 0) and without a debug state unless speedMultiplier says otherwise:
- * sc_traffic_ai.cpp:264-299 preamble + :434-460.  Arrays are in Transform-pool dense order; isAgent[i] marks the
- * entities that carry TrafficAgent + TrafficVehicle.  Physics / Kinematic agents are left alone here (their transforms
- * come from the physics sync, :351-433 / TrafficPhysicsSyncSystem). */
-void orc_traffic_ai_onrails(OrcWorld* w, const OrcLaneGraph* g, const uint8_t* isAgent, uint32_t* laneId, float* laneS,
-                            float* targetSpeed, const uint8_t* mode, const float* lookAheadDist, float speedMultiplier, float dt)
+/* TrafficLaneGraph::queryNearestLane, sc_traffic_lanes.cpp:240-279: the closest point of every active segment, the first
+ * segment wins among equals (strict <). */
+int orc_lanes_query_nearest(const OrcLaneGraph* g, const float pos[3], uint32_t* laneOut, float* sOut)
+{
+  uint32_t best = ORC_INVALID_LANE; float bestS = 0.0f, bestDist = 0.0f; int hasBest = 0;
+  for (uint32_t i = 0; i < g->segLen; ++i) {
+    const OrcLaneSegment* seg = &g->segs[i];
+    if (!seg->active || seg->length <= 1e-5f) continue;
+    const OrcLaneNode* a = &g->nodes[seg->startNode];
+    const float toP[3] = { pos[0] - a->pos[0], pos[1] - a->pos[1], pos[2] - a->pos[2] };
+    const float proj = toP[0] * seg->dir[0] + toP[1] * seg->dir[1] + toP[2] * seg->dir[2];
+    const float mn = (proj < seg->length) ? proj : seg->length;            /* std::min(seg.length, proj) */
+    const float sv = (0.0f < mn) ? mn : 0.0f;                               /* std::max(0.0f, ...) */
+    const float closest[3] = { a->pos[0] + seg->dir[0] * sv, a->pos[1] + seg->dir[1] * sv, a->pos[2] + seg->dir[2] * sv };
+    const float dx = pos[0] - closest[0], dy = pos[1] - closest[1], dz = pos[2] - closest[2];
+    const float distSq = dx * dx + dy * dy + dz * dz;
+    if (!hasBest || distSq < bestDist) { hasBest = 1; bestDist = distSq; best = i; bestS = sv; }
+  }
+  *laneOut = best; *sOut = bestS;
+  return best != ORC_INVALID_LANE;
+}
+
+static float clampf(float v, float lo, float hi)          /* std::max(lo, std::min(v, hi)), sc_traffic_ai.cpp:16-19 */
+{
+  const float m = (hi < v) ? hi : v;
+  return (lo < m) ? m : lo;
+}
+
+/* The obstacle ray of one agent, sc_traffic_ai.cpp:300-345, against the world AABBs of the broadphase (own spec, as the ray
+ * queries: Bullet is absent).  forward = normalize(sin(yaw), 0, cos(yaw)) with the yaw's sin / cos as the Transform holds them
+ * (host libm), origin 1.7 m ahead and 0.6 m up, PhysicsWorld::raycast(origin, forward, rayLen, 1u).  The agent's own box
+ * never answers (Bullet does not report a convex shape the ray starts inside, and the reference ignores a self hit anyway,
+ * :322-325, :336).  brake = clamp01((safe - d) / safe) for a hit closer than `safe` (:336-339). */
+float orc_traffic_front_ray_brake(uint32_t n, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
+                                  uint32_t self, const float pos[3], float sinYaw, float cosYaw, float rayLen, float safe)
+{
+  float forward[3] = { sinYaw, 0.0f, cosYaw };
+  normalize3(forward);
+  const float origin[3] = { pos[0] + forward[0] * 1.7f, pos[1] + 0.6f, pos[2] + forward[2] * 1.7f };
+  /* one ray through orc_raycast_boxes' arithmetic, the agent's own box left out */
+  const float lenSq = forward[0] * forward[0] + forward[1] * forward[1] + forward[2] * forward[2];
+  if (!(lenSq > 1e-6f) || !(rayLen >= 0.0f)) return 0.0f;
+  const float invLen = 1.0f / sqrtf(lenSq);
+  const float dir[3] = { forward[0] * invLen, forward[1] * invLen, forward[2] * invLen };
+  float best = INFINITY; int hit = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (i == self) continue;
+    if (!(min3[3 * i] <= max3[3 * i])) continue;
+    const uint32_t gq = group[i] & 0xFFFFu, mq = mask[i] & 0xFFFFu;
+    if (!(gq & 1u) || !mq) continue;
+    float tmin = 0.0f, tmax = rayLen; int ok = 1;
+    for (int k = 0; k < 3 && ok; ++k) {                                     /* intersectRayAABB, editor_core.cpp:438-470 */
+      if (fabsf(dir[k]) < 1e-6f) { if (origin[k] < min3[3 * i + k] || origin[k] > max3[3 * i + k]) ok = 0; }
+      else {
+        const float ood = 1.0f / dir[k];
+        float t1 = (min3[3 * i + k] - origin[k]) * ood, t2 = (max3[3 * i + k] - origin[k]) * ood;
+        if (t1 > t2) { const float q = t1; t1 = t2; t2 = q; }
+        if (t1 > tmin) tmin = t1;
+        tmax = tmax < t2 ? tmax : t2;
+        if (tmin > tmax) ok = 0;
+      }
+    }
+    if (ok && tmin < best) { best = tmin; hit = 1; }
+  }
+  if (hit && safe > 1e-3f && best < safe) return clampf((safe - best) / safe, 0.0f, 1.0f);
+  return 0.0f;
+}
+
+/* Every OnRails agent's brake for one step (the rays of sc_traffic_ai.cpp:300-345 against the world as it stands): sin / cos of
+ * Transform::localRot[1] with the float libm, as the reference's std::sin(currentYaw) / std::cos(currentYaw).  A box whose
+ * AABB misses the ray segment's own bounding box (grown by a centimetre) cannot be hit and is skipped before the slab test. */
+void orc_traffic_front_ray_brakes(OrcWorld* w, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
+                                  const uint8_t* isAgent, const uint8_t* mode, float rayLen, float safe, float* brakeOut)
+{
+  const OrcTransform* d = orc_transform_dense_data(w);
+  const uint32_t n = orc_transform_count(w);
+  for (uint32_t i = 0; i < n; ++i) {
+    brakeOut[i] = 0.0f;
+    if (!isAgent[i] || mode[i] != 2u) continue;
+    const float sy = sinf(d[i].localRot[1]), cy = cosf(d[i].localRot[1]);
+    float f[3] = { sy, 0.0f, cy };
+    normalize3(f);
+    const float o[3] = { d[i].localPos[0] + f[0] * 1.7f, d[i].localPos[1] + 0.6f, d[i].localPos[2] + f[2] * 1.7f };
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) { const float e = o[k] + f[k] * (rayLen * 1.001f); lo[k] = (o[k] < e ? o[k] : e) - 0.01f; hi[k] = (o[k] < e ? e : o[k]) + 0.01f; }
+    /* gather the candidates, then the exact routine on them (indices kept: `self` must stay recognisable) */
+    float best = 0.0f;
+    {
+      float brake = 0.0f;
+      /* the exact test on the boxes that can be hit at all */
+      static uint32_t* cand = NULL; static uint32_t candCap = 0;
+      uint32_t m = 0;
+      for (uint32_t j = 0; j < n; ++j) {
+        if (max3[3 * j] < lo[0] || min3[3 * j] > hi[0] || max3[3 * j + 2] < lo[2] || min3[3 * j + 2] > hi[2] || max3[3 * j + 1] < lo[1] || min3[3 * j + 1] > hi[1]) continue;
+        if (m == candCap) { candCap = candCap ? candCap * 2u : 256u; cand = xr(cand, (size_t)candCap * 4u); }
+        cand[m++] = j;
+      }
+      if (m) {
+        float* cmn = xr(NULL, (size_t)m * 12u); float* cmx = xr(NULL, (size_t)m * 12u); uint32_t* cg = xr(NULL, (size_t)m * 4u); uint32_t* cm = xr(NULL, (size_t)m * 4u);
+        uint32_t self = 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < m; ++k) {
+          const uint32_t j = cand[k];
+          memcpy(cmn + 3 * k, min3 + 3 * j, 12); memcpy(cmx + 3 * k, max3 + 3 * j, 12); cg[k] = group[j]; cm[k] = mask[j];
+          if (j == i) self = k;
+        }
+        brake = orc_traffic_front_ray_brake(m, cmn, cmx, cg, cm, self, d[i].localPos, sy, cy, rayLen, safe);
+        free(cmn); free(cmx); free(cg); free(cm);
+      }
+      best = brake;
+    }
+    brakeOut[i] = best;
+  }
+}
+
+/* TrafficAISystem for the agents of the OnRails tier (mode 2): sc_traffic_ai.cpp:264-299 preamble + :434-460.  Every agent
+ * without a lane first takes the nearest active one (:264-272, whatever its tier).  obstacleBrake[i] (may be NULL: no
+ * PhysicsWorld, brake 0) is the agent's brake from its front ray, :300-345 -- cast by the caller against the world as it
+ * stood BEFORE this step, which is what Bullet's world is while TrafficAISystem walks the agents.  Arrays are in
+ * Transform-pool dense order; isAgent[i] marks the entities that carry TrafficAgent + TrafficVehicle.  Physics / Kinematic
+ * agents are not moved here (their transforms come from the physics sync, :351-433 / TrafficPhysicsSyncSystem). */
+void orc_traffic_ai_onrails_braked(OrcWorld* w, const OrcLaneGraph* g, const uint8_t* isAgent, uint32_t* laneId, float* laneS,
+                                   float* targetSpeed, const uint8_t* mode, const float* lookAheadDist, const float* obstacleBrakeIn,
+                                   float speedMultiplier, float dt)
 {
   OrcTransform* d = orc_transform_dense_data(w);
   const uint32_t n = orc_transform_count(w);
   for (uint32_t i = 0; i < n; ++i) {
-    if (!isAgent[i] || mode[i] != 2u) continue;
+    if (!isAgent[i]) continue;
     OrcTransform* tr = &d[i];
+    if (laneId[i] == ORC_INVALID_LANE) {                                           /* :264-272 */
+      uint32_t q; float qs;
+      if (orc_lanes_query_nearest(g, tr->localPos, &q, &qs)) { laneId[i] = q; laneS[i] = qs; }
+    }
+    if (mode[i] != 2u) continue;
     if (laneId[i] == ORC_INVALID_LANE || laneId[i] >= g->segLen) continue;         /* getLane() == nullptr, :274-276 */
     if (!g->segs[laneId[i]].active) continue;
     float target[3] = { 0, 0, 0 }, tmpDir[3];
@@ -258,7 +380,7 @@ void orc_traffic_ai_onrails(OrcWorld* w, const OrcLaneGraph* g, const uint8_t* i
     float desiredSpeed = g->nodes[g->segs[laneId[i]].startNode].speedLimit;        /* laneSpeedLimit, :296 */
     desiredSpeed *= speedMultiplier;                                               /* :297-298 (dbg->speedMultiplier, 1 by default) */
     desiredSpeed = (0.0f < desiredSpeed) ? desiredSpeed : 0.0f;                    /* std::max(0.0f, desiredSpeed), :299 */
-    const float obstacleBrake = 0.0f;
+    const float obstacleBrake = obstacleBrakeIn ? obstacleBrakeIn[i] : 0.0f;       /* :300-345 */
     const float desired = desiredSpeed * (1.0f - obstacleBrake);                   /* :436 */
     targetSpeed[i] = smoothExp(targetSpeed[i], desired, 2.5f, dt);                 /* :437 */
     const float travel = targetSpeed[i] * dt;                                      /* :439 */
@@ -271,6 +393,12 @@ void orc_traffic_ai_onrails(OrcWorld* w, const OrcLaneGraph* g, const uint8_t* i
       tr->dirty = 1;
     }
   }
+}
+
+void orc_traffic_ai_onrails(OrcWorld* w, const OrcLaneGraph* g, const uint8_t* isAgent, uint32_t* laneId, float* laneS,
+                            float* targetSpeed, const uint8_t* mode, const float* lookAheadDist, float speedMultiplier, float dt)
+{
+  orc_traffic_ai_onrails_braked(w, g, isAgent, laneId, laneS, targetSpeed, mode, lookAheadDist, NULL, speedMultiplier, dt);
 }
 
 /* TrafficLODSystem's tier selection (sc_traffic_lod.cpp:269-274, :303-307, :323-417): desired tier per vehicle from its

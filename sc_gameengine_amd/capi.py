@@ -105,6 +105,7 @@ SYMBOLS = {
     "scTickSetDrawSortTable": (C.c_int, [_CTX, U8P, C.c_uint32, C.c_uint32]),
     "scTickSetTile": (C.c_int, [_CTX, C.c_uint32, C.c_uint32]),
     "scTickSetTileGrid": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "scTickSetBorderCapacity": (C.c_int, [_CTX, C.c_uint32]),
     "scTickBorderBytes": (C.c_uint32, [_CTX, C.c_uint32]),
     "scTickBindBorderBuffers": (C.c_int, [_CTX, C.c_uint32, C.c_void_p, C.c_void_p]),
     "scTickRunPairs": (C.c_int, [_CTX]),
@@ -130,6 +131,8 @@ SYMBOLS = {
     "scTickUploadTrafficAgents": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P, U32P, F32P, F32P, U8P, F32P]),
     "scTickReadTrafficAgents": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U32P, F32P, F32P, U8P]),
     "scTickSetTrafficSpeedMultiplier": (C.c_int, [_CTX, C.c_float]),
+    "scTickSetTrafficSensors": (C.c_int, [_CTX, C.c_int, C.c_float, C.c_float]),
+    "scTickReadTrafficBrakes": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
     "scTickSelectTrafficTiers": (C.c_int, [_CTX, F32P, C.POINTER(TierParams), C.POINTER(TierCounts)]),
     "scTickSetViewProj": (C.c_int, [_CTX, F32P]),
     "scTickSetFrustumPlanes": (C.c_int, [_CTX, F32P, C.c_int]),

@@ -105,6 +105,7 @@ struct ScTickContext
   uint32_t tileX = 0, tileZ = 0, tilesX = 0, tilesZ = 0;
   uint32_t producerKind = 0; float producerParam = 0.0f;      // part of the frame when set (scTickSetFrameProducer)
   float trafficMult = 1.0f;                                   // TrafficDebugState::speedMultiplier (sc_traffic_common.h:63)
+  bool sensors = false; float sensorRay = 20.0f, sensorSafe = 10.0f;   // TrafficSensors defaults (sc_traffic_ai.cpp:307-309)
   void* laneAllocs[6] = {};                                   // device copies of the lane graph (scTickSetLaneGraph)
   uint2* dTierPatch = nullptr;                                // tier selection: the few modes the caps changed
   bool pairsPending = false;
@@ -118,6 +119,7 @@ struct ScTickContext
                   uint32_t* borderSend[8] = {}; uint32_t* borderRecv[8] = {}; };
   AltSet alt[kMaxParity - 1];          // parity q > 0 works on alt[q - 1]
   uint32_t pipeDepth = 3;              // copies a pipelined tile rotates through (scTickSetPipelined)
+  uint32_t borderRecs = kBorderRecsPerBin;   // border messages: records per ring sector of a side on average (scTickSetBorderCapacity)
   hipEvent_t packed[kMaxParity] = {}, pairsDone[kMaxParity] = {};
   bool pairsInFlight[kMaxParity] = {};
   // library-owned exchange (scTickCommInit): one RCCL communicator per context, the border messages of both tick
@@ -404,7 +406,7 @@ uint32_t ovfRecords(const ScTickContext* c)
 {
   const uint64_t own = 4ull * c->cap;
   uint64_t border = 0;
-  for (uint32_t d = 0; d < 8; ++d) border += borderRecCap(borderLen(d, c->desc.tile_sectors_x, c->desc.tile_sectors_z));
+  for (uint32_t d = 0; d < 8; ++d) border += borderRecCap(borderLen(d, c->desc.tile_sectors_x, c->desc.tile_sectors_z), c->borderRecs);
   return (uint32_t)std::min<uint64_t>(own + border, 0xFFFFFF00ull);
 }
 
@@ -437,6 +439,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.trafficMult = c->trafficMult;
   p.bigCap = c->cap + 8u * kBorderBigCap;
   p.pairRunLog2 = pairRunLog2(p.binSX * p.binSZ);
+  p.borderRecs = c->borderRecs;
   p.tileX = c->tileX; p.tileZ = c->tileZ; p.tilesX = c->tilesX; p.tilesZ = c->tilesZ;
 }
 
@@ -492,6 +495,8 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
       launchDeepLevel(ds, p, c->dLevelList + b, e - b, c->stream);
     }
   }
+  // the traffic AI's obstacle rays (scTickSetTrafficSensors): against this tick's boxes, before the frame producer moves the agents
+  if ((flags & SC_TICK_BROADPHASE) && c->sensors && ds.aLane) launchAgentFrontRays(ds, p, c->sensorRay, c->sensorSafe, c->stream);
   if ((flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_DENSE_AABBS)) launchDenseAabbs(ds, c->n, c->stream);   // read-back aid, off the hot path
   const bool needCompact = (flags & (SC_TICK_XFORM | SC_TICK_CULL)) != 0;
   const bool pairsNow = (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS);
@@ -1301,7 +1306,38 @@ int scTickSetTileGrid(ScTickContext* c, uint32_t tileX, uint32_t tileZ, uint32_t
 uint32_t scTickBorderBytes(ScTickContext* c, uint32_t dir)
 {
   if (!c || dir > 7u || !c->desc.tile_sectors_x) return 0;
-  return borderWords(dir, c->desc.tile_sectors_x, c->desc.tile_sectors_z) * 4u;
+  return borderWords(dir, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs) * 4u;
+}
+
+int scTickSetBorderCapacity(ScTickContext* c, uint32_t recordsPerRingSector)
+{
+  if (!c) return 0;
+  if (!c->sectors) return fail(c, "the context has no broadphase");
+  if (recordsPerRingSector < 1u || recordsPerRingSector > kSectorRecMax) return fail(c, "border capacity: 1..1088 records per ring sector (a sector holds at most 64 + 1024)");
+  if (c->comm) return fail(c, "scTickSetBorderCapacity must precede scTickCommInit (the library's message buffers are sized there)");
+  if (c->pairsPending) return fail(c, "scTickRunPairs is pending");
+  if (recordsPerRingSector == c->borderRecs) return 1;
+  if (!bind(c) || !sync(c)) return 0;
+  const uint32_t before = ovfRecords(c);
+  c->borderRecs = recordsPerRingSector;
+  // the sector overflow list has room for every border record that finds its landing bin full: grow it with the messages
+  if (ovfRecords(c) > before) {
+    auto regrow = [&](float4*& spill, uint32_t*& tags) -> bool {
+      if (!spill) return true;
+      dfree(c, spill); dfree(c, tags); spill = nullptr; tags = nullptr;
+      return dalloc(c, spill, 2u * (size_t)ovfRecords(c), false) && dalloc(c, tags, ovfRecords(c));
+    };
+    if (!regrow(c->d.spill, c->d.spillSector)) return 0;
+    for (auto& a : c->alt) if (!regrow(a.spill, a.spillSector)) return 0;
+  }
+  // library-owned message buffers are allocated by scTickCommInit; caller-owned ones must be re-bound at the new scTickBorderBytes
+  for (uint32_t d = 0; d < 8; ++d) {
+    c->d.borderSend[d] = c->d.borderRecv[d] = nullptr;
+    for (auto& a : c->alt) a.borderSend[d] = a.borderRecv[d] = nullptr;
+    for (uint32_t q = 0; q < kMaxParity; ++q) for (int k = 0; k < 2; ++k) if (c->ownBorder[q][d][k]) { dfree(c, c->ownBorder[q][d][k]); c->ownBorder[q][d][k] = nullptr; }
+  }
+  dropGraph(c); dropPairGraph(c); c->topoEpoch++;
+  return 1;
 }
 
 int scTickBindBorderBuffers(ScTickContext* c, uint32_t dir, void* send, void* recv)
@@ -1896,6 +1932,34 @@ int scTickUploadTrafficAgents(ScTickContext* c, uint32_t first, uint32_t count, 
   return ok && sync(c) ? 1 : 0;
 }
 
+int scTickSetTrafficSensors(ScTickContext* c, int enable, float frontRayLength, float safeDistance)
+{
+  if (!c) return 0;
+  if (!bind(c) || !sync(c)) return 0;
+  if (enable) {
+    if (!c->d.aLane) return fail(c, "no traffic agents uploaded");
+    if (!c->sectors) return fail(c, "the obstacle rays read the broadphase bins: the context has no tile rectangle");
+    if (!(frontRayLength >= 0.0f) || !(safeDistance >= 0.0f)) return fail(c, "ray length and safe distance must be >= 0");
+    if (!c->d.aBrake && (!dalloc(c, c->d.aBrake, c->cap) || !dalloc(c, c->d.agentList, c->cap, false) || !dalloc(c, c->d.agentCount, 4))) return 0;
+    c->sensorRay = frontRayLength; c->sensorSafe = safeDistance;
+  } else if (c->d.aBrake) {
+    HIP_OK(c, hipMemsetAsync(c->d.aBrake, 0, (size_t)c->cap * sizeof(float), c->stream));      // no sensors: brake 0 from here on
+    if (!sync(c)) return 0;
+  }
+  c->sensors = enable != 0;
+  dropGraph(c); dropPairGraph(c); c->topoEpoch++;
+  return 1;
+}
+
+int scTickReadTrafficBrakes(ScTickContext* c, uint32_t first, uint32_t count, float* brake)
+{
+  if (!c || !brake) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!c->d.aBrake) return fail(c, "scTickSetTrafficSensors first");
+  if (!count) return 1;
+  return d2h(c, brake, c->d.aBrake + first, (size_t)count * 4u) && sync(c) ? 1 : 0;
+}
+
 int scTickReadTrafficAgents(ScTickContext* c, uint32_t first, uint32_t count, uint32_t* laneId, float* laneS, float* targetSpeed, uint8_t* mode)
 {
   if (!c) return 0;
@@ -2054,7 +2118,7 @@ int scTickCommInit(ScTickContext* c, const uint8_t id[SC_TICK_COMM_ID_BYTES], ui
   for (uint32_t q = 0; q < kMaxParity; ++q)
     for (uint32_t d = 0; d < 8; ++d) {
       if (!((c->neighbourMask >> d) & 1u)) continue;
-      const size_t words = borderWords(d, c->desc.tile_sectors_x, c->desc.tile_sectors_z);
+      const size_t words = borderWords(d, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs);
       for (int k = 0; k < 2; ++k) if (!c->ownBorder[q][d][k] && !dalloc(c, c->ownBorder[q][d][k], words)) return 0;
       if (q == 0) { c->d.borderSend[d] = c->ownBorder[0][d][0]; c->d.borderRecv[d] = c->ownBorder[0][d][1]; }
       else { c->alt[q - 1u].borderSend[d] = c->ownBorder[q][d][0]; c->alt[q - 1u].borderRecv[d] = c->ownBorder[q][d][1]; }
@@ -2106,11 +2170,11 @@ static int exchangeBorders(ScTickContext* c, uint32_t parity, hipStream_t s, boo
   for (int d = 0; d < 8 && res == ncclSuccess; ++d) {
     if (!((c->neighbourMask >> d) & 1u)) continue;
     if (!ds.borderSend[d] || !ds.borderRecv[d]) { r->GroupEnd(); return fail(c, "border buffers are not bound"); }
-    res = r->Send(ds.borderSend[d], (size_t)borderWords((uint32_t)d, c->desc.tile_sectors_x, c->desc.tile_sectors_z), ncclUint32, c->peer[d], c->comm, s);
+    res = r->Send(ds.borderSend[d], (size_t)borderWords((uint32_t)d, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs), ncclUint32, c->peer[d], c->comm, s);
   }
   for (int d = 7; d >= 0 && res == ncclSuccess; --d) {
     if (!((c->neighbourMask >> d) & 1u)) continue;
-    res = r->Recv(ds.borderRecv[d], (size_t)borderWords((uint32_t)d, c->desc.tile_sectors_x, c->desc.tile_sectors_z), ncclUint32, c->peer[d], c->comm, s);
+    res = r->Recv(ds.borderRecv[d], (size_t)borderWords((uint32_t)d, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs), ncclUint32, c->peer[d], c->comm, s);
   }
   const ncclResult_t end = r->GroupEnd();
   if (!ncclOk(c, r, res, "ncclSend/ncclRecv")) return 0;

@@ -113,6 +113,9 @@ struct DeviceState {
   // traffic agents (TrafficAgent + TrafficVehicle, sc_traffic_common.h:26-44; allocated on first scTickUploadTrafficAgents)
   LaneGraphDev lanes;
   uint32_t* aLane; float* aS; float* aSpeed; uint32_t* aMode; float* aLook; uint32_t* aDesired;
+  float* aBrake;               // obstacleBrake per agent from its front ray (sc_traffic_ai.cpp:300-345); nullptr = no sensors: brake 0
+  uint32_t* agentList;         // dense indices of the OnRails agents, rebuilt every tick that casts their rays
+  uint32_t* agentCount;
   uint32_t* tierCounts;        // [0..2] desired tiers, [3] entries in tierNear
   uint2* tierNear;             // (dense index, bits of the distance) of agents whose desired tier is Physics or Kinematic
   // multi-GPU border exchange: one message per neighbour direction (caller-owned device buffers)
@@ -124,7 +127,8 @@ struct DeviceState {
 // then records (8 words each) packed bin after bin, then the big-box section: [0] boxes, [1] overflow flag,
 // boxes (8 words each).  L = sectors on that ring side.
 constexpr uint32_t kBorderHeader = 2;
-constexpr uint32_t kBorderRecsPerBin = 16;    // capacity = L * kBorderRecsPerBin records per message, at least one full bin
+constexpr uint32_t kBorderRecsPerBin = 16;    // default: a message holds L * 16 records (shared by the side's sectors: a crowded ring sector
+                                              // may take more than its share), at least one full sector; scTickSetBorderCapacity raises it
 constexpr uint32_t kOvfPerSector = 1024;      // overflow records one sector can hold besides its bin (what lies beyond is counted, never silent)
 constexpr uint32_t kOvfWaves = 2048u * 4u;    // pair-role waves that can own an ovfIdx scratch row (the launcher's workgroup cap x 4)
 constexpr uint32_t kBorderBigCap = 128;       // big boxes (wider than 2x2 sectors, outside the rectangle, bin full) per message
@@ -168,6 +172,7 @@ struct TickParams {
   uint32_t bigCap;          // entries the big list can hold (capacity + room for the neighbours' boxes): every index into it is held below this
   uint32_t ovfCap;          // entries the sector overflow list can hold
   uint32_t pairRunLog2;     // pair role: a wave takes its sectors in runs of 2^pairRunLog2 consecutive ones (pairRunLog2())
+  uint32_t borderRecs;      // border messages: records per ring sector of a side, on average (scTickSetBorderCapacity; kBorderRecsPerBin)
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d
 __host__ __device__ inline void borderDir(uint32_t d, int& dx, int& dz) { const uint32_t k = d < 4 ? d : d + 1; dx = (int)(k % 3) - 1; dz = (int)(k / 3) - 1; }
@@ -176,9 +181,11 @@ __host__ __device__ inline uint32_t borderLen(uint32_t d, uint32_t coreSX, uint3
 __host__ __device__ inline uint32_t borderDirOf(int dx, int dz) { const uint32_t k9 = (uint32_t)((dz + 1) * 3 + (dx + 1)); return k9 < 4 ? k9 : k9 - 1u; }
 // hasNb(p, dx, dz): a tile exists one step in that direction
 __host__ __device__ inline bool hasNb(const TickParams& p, int dx, int dz) { return (p.neighbourMask >> borderDirOf(dx, dz)) & 1u; }
-__host__ __device__ inline uint32_t borderRecCap(uint32_t L) { return L * kBorderRecsPerBin > 64u ? L * kBorderRecsPerBin : 64u; }     // 64 = kBinCap
-__host__ __device__ inline uint32_t borderBinWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { const uint32_t L = borderLen(d, coreSX, coreSZ); return kBorderHeader + L + borderRecCap(L) * 8u; }
-__host__ __device__ inline uint32_t borderWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { return borderBinWords(d, coreSX, coreSZ) + kBorderBigWords; }
+// records one border message can carry: `recs` per ring sector of the side on average, at least one sector's bin and overflow list
+constexpr uint32_t kSectorRecMax = 64u + kOvfPerSector;      // what one sector can hold at all: its bin + its share of the overflow list
+__host__ __device__ inline uint32_t borderRecCap(uint32_t L, uint32_t recs) { return L * recs > kSectorRecMax ? L * recs : kSectorRecMax; }
+__host__ __device__ inline uint32_t borderBinWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ, uint32_t recs) { const uint32_t L = borderLen(d, coreSX, coreSZ); return kBorderHeader + L + borderRecCap(L, recs) * 8u; }
+__host__ __device__ inline uint32_t borderWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ, uint32_t recs) { return borderBinWords(d, coreSX, coreSZ, recs) + kBorderBigWords; }
 constexpr uint32_t kFlagHasDeep = 1u << 16;   // write recomp bits for the level kernels
 constexpr uint32_t kFlagDeferredReset = 1u << 17;   // pipelined tiles: a pair kernel never clears the other parity's counters / big bits; a small kernel
                                                     // behind it on the pairs stream snapshots the results and clears its OWN parity
@@ -207,6 +214,7 @@ struct RayQueryState {
   uint32_t count;
 };
 void launchRayQueries(const DeviceState& d, const TickParams& p, const RayQueryState& q, hipStream_t s);
+void launchAgentFrontRays(const DeviceState& d, const TickParams& p, float rayLen, float safe, hipStream_t s);
 constexpr uint32_t kMaxOccupancyQueries = 256;
 void launchOccupancy(const DeviceState& d, uint32_t n, const float4* q, uint32_t count, uint32_t* blocked, hipStream_t s);
 

@@ -12,6 +12,18 @@
 #include <hip/hip_ext.h>
 #include "../../include/sc_tick.h"
 
+#ifdef SC_NO_DEFER
+constexpr bool kNoDefer = true;       // A/B: world-matrix stores in place (round 2) instead of behind the bin reservations
+#else
+constexpr bool kNoDefer = false;
+#endif
+#ifndef SC_BINV
+#define SC_BINV 3         // order of the bin reservations / stores inside binEntityWave (A/B)
+#endif
+#ifndef SC_ABL
+#define SC_ABL 0          // timing ablations of the fused kernel (tools only: results are wrong with any bit set)
+#endif
+
 namespace sctick {
 
 // The pair role is bound by instruction issue and LDS latency: five waves per SIMD hide it measurably better than four
@@ -235,61 +247,6 @@ __device__ __forceinline__ void appendBig(const DeviceState& d, const TickParams
   d.bigList[2u * (size_t)slot + 1u] = rmax;
 }
 
-// One insertion round for the whole wave (must be called by all 64 lanes).  Consecutive lanes that
-// target the same sector form a run; the run's first lane reserves the slots with ONE atomic.
-__device__ __forceinline__ void binInsertWave(const DeviceState& d, const TickParams& p, bool want, uint32_t sector,
-                                              const float4& rmin, const float4& rmax)
-{
-  const unsigned long long act = ballot64(want);
-  if (!act) return;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t key = want ? sector : 0xFFFFFFFFu;
-  const uint32_t prev = __shfl_up(key, 1, 64);
-  const bool head = want && (lane == 0 || prev != key);
-  const unsigned long long heads = ballot64(head);
-  const unsigned long long upto = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
-  const uint32_t myHead = (63u - (uint32_t)__clzll(heads & upto)) & 63u;
-  const unsigned long long above = (myHead == 63u) ? 0ull : ~((2ull << myHead) - 1ull);
-  const unsigned long long ends = (heads | ~act) & above;
-  const uint32_t runEnd = ends ? (uint32_t)__ffsll((long long)ends) - 1u : 64u;
-  // OR of the run's collision layers for the head lane.  Runs are almost always uniform (one layer
-  // word): one cross-lane read decides; only a wave with a mixed run pays the segmented OR.
-  uint32_t lay = want ? __float_as_uint(rmin.w) : 0u;
-  const uint32_t headLay = (uint32_t)__shfl((int)lay, (int)myHead, 64);
-  if (ballot64(want && headLay != lay)) {
-#pragma unroll
-    for (uint32_t o = 1; o < 64u; o <<= 1) {
-      const uint32_t other = (uint32_t)__shfl_down((int)lay, o, 64);
-      if (want && lane + o < runEnd) lay |= other;
-    }
-  }
-  uint32_t base = 0;
-  if (head) { base = atomicAdd(&d.binCount[sector], runEnd - lane); atomicOr(&d.binLayers[sector], lay); }
-  base = __shfl(base, myHead, 64);
-  const uint32_t slot = base + (lane - myHead);
-  if (want && slot < kBinCap) {
-    float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
-    r[0] = rmin; r[1] = rmax;
-  }
-  // bin full: the record joins the sector overflow list (one reservation per wave)
-  const bool over = want && slot >= kBinCap;
-  const unsigned long long mo = ballot64(over);
-  if (mo) {
-    const uint32_t ctr = kCtrPar + 8u * p.parity;
-    const uint32_t first = (uint32_t)__ffsll((long long)mo) - 1u;
-    uint32_t at = 0;
-    if (lane == first) at = atomicAdd(&d.counters[ctr + kCtrSpill], (uint32_t)__popcll(mo));     // (every wave of the chip meets on this word: one atomic, not two)
-    at = __shfl(at, (int)first, 64) + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
-    if (over && at < p.ovfCap) {
-      d.spill[2u * (size_t)at] = rmin; d.spill[2u * (size_t)at + 1u] = rmax; d.spillSector[at] = sector;
-      // the overflowing lanes of a run are its tail and their list indices ascend with the lane: the first one lowers the
-      // sector's slice bound, the last one raises it (two atomics per run, not per record)
-      if (slot == kBinCap || lane == myHead) atomicMin(&d.ovfLo[sector], at);
-      if (lane + 1u == runEnd) atomicMax(&d.ovfHi[sector], at + 1u);
-    } else if (over) atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);      // (cannot happen with the list sized by ovfRecords(): never silent anyway)
-  }
-}
-
 // One record into one sector's bin by the lane itself (or into the sector overflow list when the bin is full).
 __device__ __forceinline__ void binInsertLane(const DeviceState& d, const TickParams& p, uint32_t sector, const float4& rmin, const float4& rm)
 {
@@ -309,8 +266,30 @@ __device__ __forceinline__ void binInsertLane(const DeviceState& d, const TickPa
 }
 
 // Whole-wave broadphase step for one entity per lane: world AABB -> bins / big list.
+//
+// Round 3: ONE reservation round trip per tile.  Ablations of the round-2 form (profiles/r03/ab_ablation_binning.log) showed
+// that binning was 15 of the fused kernel's 36 us, and that its cost was not bytes: the copies of a box in the sectors next to
+// its own -- every ground slab has three, a straddling prop one -- each reserved their slot with a returning atomic of their
+// own, one AFTER the other behind the primary copy's (four dependent round trips to L2 at the end of every tile: 5.8 us);
+// the primary's returning atomic another 2.9.  Now every returning atomic of the tile -- the run heads' for the primary
+// copies, up to three per straddling lane for the others -- is issued before any result is used, the layer summaries'
+// atomicOr (nothing returns) behind them, and the stores follow one wait.
+__device__ __forceinline__ void spillLane(const DeviceState& d, const TickParams& p, uint32_t sector, const float4& rmin, const float4& rm)
+{
+  // one record that found its sector's bin full: it joins the sector overflow list
+  const uint32_t ctr = kCtrPar + 8u * p.parity;
+  const uint32_t at = atomicAdd(&d.counters[ctr + kCtrSpill], 1u);
+  if (at < p.ovfCap) {
+    d.spill[2u * (size_t)at] = rmin; d.spill[2u * (size_t)at + 1u] = rm; d.spillSector[at] = sector;
+    atomicMin(&d.ovfLo[sector], at); atomicMax(&d.ovfHi[sector], at + 1u);
+  } else atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);               // (cannot happen with the list sized by ovfRecords(): never silent anyway)
+}
+
+// storeM: the lane's freshly built world matrix is stored HERE, behind the reservations (they do not depend on it): the wait
+// for the reservations then does not include the stores' way to memory (vmcnt retires in order), and the bounds loads in
+// front of this call are not held behind the stores either.
 __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickParams& p, uint32_t i, bool collider,
-                                              const Aff& M, const BoundsCE& b)
+                                              const Aff& M, const BoundsCE& b, bool storeM)
 {
   float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
   BinPlan plan; plan.collide = false; plan.big = false; plan.x0 = plan.z0 = 0.0f; plan.nx = plan.nz = 0;
@@ -321,25 +300,121 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
     rmin = make_float4(mn[0], mn[1], mn[2], __uint_as_float(ldU(d, kLAYERS, i)));
     rmax = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i | p.rankBits));
   }
-  const bool binned = plan.collide && !plan.big;
-  const uint32_t sx = (uint32_t)plan.x0, sz = (uint32_t)plan.z0;
-  // the primary copy (every box has exactly one): consecutive lanes mostly share the sector -- one reservation per run
-  {
+  const bool want = plan.collide && !plan.big;
+  const uint32_t sector = (uint32_t)plan.z0 * p.binSX + (uint32_t)plan.x0;
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long act = ballot64(want);
+  if (act) {
+    // ---- the primary copies (every box has exactly one): consecutive lanes that target the same sector form a run, whose
+    // first lane reserves the slots of the whole run
+    const uint32_t key = want ? sector : 0xFFFFFFFFu;
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    const bool head = want && (lane == 0 || prev != key);
+    const unsigned long long heads = ballot64(head);
+    const unsigned long long upto = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
+    const uint32_t myHead = (63u - (uint32_t)__clzll(heads & upto)) & 63u;
+    const unsigned long long above = (myHead == 63u) ? 0ull : ~((2ull << myHead) - 1ull);
+    const unsigned long long ends = (heads | ~act) & above;
+    const uint32_t runEnd = ends ? (uint32_t)__ffsll((long long)ends) - 1u : 64u;
+    // OR of the run's collision layers for the head lane.  Runs are almost always uniform (one layer
+    // word): one cross-lane read decides; only a wave with a mixed run pays the segmented OR.
+    const uint32_t myLay = want ? __float_as_uint(rmin.w) : 0u;
+    uint32_t lay = myLay;
+    const uint32_t headLay = (uint32_t)__shfl((int)lay, (int)myHead, 64);
+    if (ballot64(want && headLay != lay)) {
+#pragma unroll
+      for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t other = (uint32_t)__shfl_down((int)lay, o, 64);
+        if (want && lane + o < runEnd) lay |= other;
+      }
+    }
+    // ---- the copies in the neighbouring sectors of a box that straddles a sector edge (a few lanes per wave; every ground
+    // slab): the lanes concerned reserve their slots themselves
+    const bool c1 = want && plan.nx > 1u, c2 = want && plan.nz > 1u, c3 = c1 && c2;
+    const uint32_t sec1 = sector + 1u, sec2 = sector + p.binSX, sec3 = sec2 + 1u;
+    uint32_t base = 0, q1 = 0, q2 = 0, q3 = 0;
     float4 rm = rmax;
     rm.w = __uint_as_float(i | p.rankBits | kPrimary);
-    binInsertWave(d, p, binned, sz * p.binSX + sx, rmin, rm);
-  }
-  // the copies in the neighbouring sectors of a box that straddles a sector edge: a few lanes per wave (a prop is a few
-  // metres wide in a 64 m sector), almost never two of them for one sector -- a whole-wave insertion round per direction
-  // (ballots, run detection, cross-lane reads: ~40 instructions each, and nearly every wave has SOME straddler) cost
-  // more than the lanes concerned reserving their slot themselves
-  if (binned && (plan.nx > 1u || plan.nz > 1u)) {
-#pragma unroll
-    for (uint32_t k = 1; k < 4; ++k) {
-      const uint32_t dx = k & 1u, dz = k >> 1;
-      if (dx < plan.nx && dz < plan.nz) binInsertLane(d, p, (sz + dz) * p.binSX + (sx + dx), rmin, rmax);
+#if SC_BINV == 0
+    // ---- every reservation of the tile, back to back: one round trip
+    if (head) base = atomicAdd(&d.binCount[sector], runEnd - lane);
+    if (c1) q1 = atomicAdd(&d.binCount[sec1], 1u);
+    if (c2) q2 = atomicAdd(&d.binCount[sec2], 1u);
+    if (c3) q3 = atomicAdd(&d.binCount[sec3], 1u);
+    if (head) atomicOr(&d.binLayers[sector], lay);
+    if (c1) atomicOr(&d.binLayers[sec1], myLay);
+    if (c2) atomicOr(&d.binLayers[sec2], myLay);
+    if (c3) atomicOr(&d.binLayers[sec3], myLay);
+    if (storeM) storeRows(d, i, M);
+    base = __shfl(base, myHead, 64);
+#elif SC_BINV == 1
+    // reservations back to back, the layer summaries behind the record stores (off the wait)
+    if (head) base = atomicAdd(&d.binCount[sector], runEnd - lane);
+    if (c1) q1 = atomicAdd(&d.binCount[sec1], 1u);
+    if (c2) q2 = atomicAdd(&d.binCount[sec2], 1u);
+    if (c3) q3 = atomicAdd(&d.binCount[sec3], 1u);
+    if (storeM) storeRows(d, i, M);
+    base = __shfl(base, myHead, 64);
+#elif SC_BINV == 2
+    // round 2's order: primary reservation, its store; then each neighbour copy on its own
+    if (head) { base = atomicAdd(&d.binCount[sector], runEnd - lane); atomicOr(&d.binLayers[sector], lay); }
+    if (storeM) storeRows(d, i, M);
+    base = __shfl(base, myHead, 64);
+#elif SC_BINV == 3
+    if (head) { base = atomicAdd(&d.binCount[sector], runEnd - lane); atomicOr(&d.binLayers[sector], lay); }
+    if (storeM) storeRows(d, i, M);
+    base = __shfl(base, myHead, 64);
+#endif
+    const uint32_t slot = base + (lane - myHead);
+    if (want && slot < kBinCap) {
+      float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
+      r[0] = rmin; r[1] = rm;
     }
-  }
+#if SC_BINV == 2
+    if (c1) { q1 = atomicAdd(&d.binCount[sec1], 1u); atomicOr(&d.binLayers[sec1], myLay); if (q1 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec1 * kBinCap + q1); r[0] = rmin; r[1] = rmax; } }
+    if (c2) { q2 = atomicAdd(&d.binCount[sec2], 1u); atomicOr(&d.binLayers[sec2], myLay); if (q2 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec2 * kBinCap + q2); r[0] = rmin; r[1] = rmax; } }
+    if (c3) { q3 = atomicAdd(&d.binCount[sec3], 1u); atomicOr(&d.binLayers[sec3], myLay); if (q3 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec3 * kBinCap + q3); r[0] = rmin; r[1] = rmax; } }
+#else
+#if SC_BINV == 3
+    if (c1) q1 = atomicAdd(&d.binCount[sec1], 1u);
+    if (c2) q2 = atomicAdd(&d.binCount[sec2], 1u);
+    if (c3) q3 = atomicAdd(&d.binCount[sec3], 1u);
+#endif
+    if (c1 && q1 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec1 * kBinCap + q1); r[0] = rmin; r[1] = rmax; }
+    if (c2 && q2 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec2 * kBinCap + q2); r[0] = rmin; r[1] = rmax; }
+    if (c3 && q3 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec3 * kBinCap + q3); r[0] = rmin; r[1] = rmax; }
+#if SC_BINV == 1
+    if (head) atomicOr(&d.binLayers[sector], lay);
+#endif
+#if SC_BINV == 1 || SC_BINV == 3
+    if (c1) atomicOr(&d.binLayers[sec1], myLay);
+    if (c2) atomicOr(&d.binLayers[sec2], myLay);
+    if (c3) atomicOr(&d.binLayers[sec3], myLay);
+#endif
+#endif
+    // bin full: the record joins the sector overflow list (primary copies: one reservation per wave)
+    const bool over = want && slot >= kBinCap;
+    const unsigned long long mo = ballot64(over);
+    if (mo) {
+      const uint32_t ctr = kCtrPar + 8u * p.parity;
+      const uint32_t first = (uint32_t)__ffsll((long long)mo) - 1u;
+      uint32_t at = 0;
+      if (lane == first) at = atomicAdd(&d.counters[ctr + kCtrSpill], (uint32_t)__popcll(mo));     // (every wave of the chip meets on this word: one atomic, not two)
+      at = __shfl(at, (int)first, 64) + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
+      if (over && at < p.ovfCap) {
+        d.spill[2u * (size_t)at] = rmin; d.spill[2u * (size_t)at + 1u] = rm; d.spillSector[at] = sector;
+        // the overflowing lanes of a run are its tail and their list indices ascend with the lane: the first one lowers the
+        // sector's slice bound, the last one raises it (two atomics per run, not per record)
+        if (slot == kBinCap || lane == myHead) atomicMin(&d.ovfLo[sector], at);
+        if (lane + 1u == runEnd) atomicMax(&d.ovfHi[sector], at + 1u);
+      } else if (over) atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);      // (cannot happen with the list sized by ovfRecords(): never silent anyway)
+    }
+    if (ballot64((c1 && q1 >= kBinCap) || (c2 && q2 >= kBinCap) || (c3 && q3 >= kBinCap))) {
+      if (c1 && q1 >= kBinCap) spillLane(d, p, sec1, rmin, rmax);
+      if (c2 && q2 >= kBinCap) spillLane(d, p, sec2, rmin, rmax);
+      if (c3 && q3 >= kBinCap) spillLane(d, p, sec3, rmin, rmax);
+    }
+  } else if (storeM) storeRows(d, i, M);
   if (plan.collide && plan.big) appendBig(d, p, rmin, rmax);
 }
 
@@ -432,11 +507,18 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
 #pragma unroll
       for (uint32_t k = 1; k <= kChain; ++k) a[k] = i;
     }
+#if SC_ABL & 4
+    if (top > 0) top = 0;
+#endif
     const bool recompute = top >= 0;
 
     Aff M;
     if (recompute) {
+#if SC_ABL & 4
+      const bool fromRoot = true;
+#else
       const bool fromRoot = (uint32_t)top == depth;       // the chain's root itself is rebuilt: world = local
+#endif
       uint32_t seed = i;
 #pragma unroll
       for (uint32_t k = 0; k < kChain; ++k) if ((uint32_t)top == k) seed = a[k + 1];
@@ -450,7 +532,11 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
           else M = mulAff(M, L);
         }
       }
-      storeRows(d, i, M);
+#if SC_ABL & 1
+      if (M.r0[0] == 12345.678f) storeRows(d, i, M);
+#else
+      if (!kAabb || kNoDefer) storeRows(d, i, M);        // (with binning the store rides behind the bin reservations: binEntityWave)
+#endif
     } else if ((kCull || kAabb) && active) {
       M = loadRows(d, i);
     }
@@ -466,6 +552,194 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
       BoundsCE b = {0, 0, 0, 0, 0, 0};
       if (hb) b = loadBounds(d, i);
 
+      if (kCull) {
+        bool visible = cand;
+        if (cand && hb && !p.freeze && p.frustumValid) {
+          const float* fr = d.frustum;
+          asm volatile("" : "+s"(fr));                 // opaque: keeps the plane loads inside the loop, at their use
+#if SC_ABL & 8
+          visible = M.r0[3] + b.cx > -1e30f;
+#else
+          visible = sphereVisibleAt(M, b, (ConstF)fr);
+#endif
+        }
+        // deeper entities get their matrix (and their bit) from the level kernels
+        if (doXform && depth > kChain && depth != kUnreachable) visible = false;
+        const unsigned long long vm = ballot64(visible);
+        const unsigned long long cm = ballot64(cand);
+        if (lane == 0 && (base + wave * 64u) < p.n) {
+          d.vis[(base >> 6) + wave] = vm;
+          if (wantCand) d.cand[(base >> 6) + wave] = cm;
+        }
+        visCount += (uint32_t)__popcll(vm);
+        candCount += (uint32_t)__popcll(cm);
+      }
+      if (kAabb) {
+        // deeper entities are binned by the level kernels once their matrix is final
+        const bool collider = hb && !(doXform && depth > kChain && depth != kUnreachable);
+#if SC_ABL & 2
+        if (M.r1[3] + b.cy == 12345.678f) binEntityWave(d, p, i, collider, M, b, false);
+        if (recompute) storeRows(d, i, M);
+#else
+        binEntityWave(d, p, i, collider, M, b, recompute && !(SC_ABL & 1) && !kNoDefer);
+#endif
+      }
+    }
+  }
+
+  if (kCull) {
+    __shared__ uint32_t sVis[kTile / 64], sCand[kTile / 64];
+    if (lane == 0) { sVis[wave] = visCount; sCand[wave] = candCount; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      d.blockVis[blockIdx.x] = sVis[0] + sVis[1] + sVis[2] + sVis[3];
+      d.blockCand[blockIdx.x] = sCand[0] + sCand[1] + sCand[2] + sCand[3];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1, LDS form (round 3).  The chain walk above is a string of DEPENDENT memory round trips per 64-entity tile -- own link
+// and dirty word, one trip per ancestor for its link / dirty words, one per chain level for its locals, then bounds, then
+// the bin reservation: about eight, ~14 us per tile and wave, and that -- not bytes, not instruction issue (an FMA-contracted
+// build and an SLP-vectorised one run at the same speed: profiles/r03/ab_diag_fma_slp_spans.log) -- is what the kernel's
+// duration was made of.  Here a workgroup's tile (256 consecutive entities) shares what the walk needs through LDS:
+//   trip 1   link word of every entity of the tile + the tile's eight dirty words          -> LDS, barrier
+//   walk     ancestors' link words and dirty bits come from LDS (an ancestor outside the tile: from memory, as before)
+//   trip 2   an entity that rebuilds loads its OWN locals once and leaves its local matrix in LDS; a clean one loads its
+//            stored rows; bounds are requested in the same trip                             -> barrier
+//   products world = world'(parent(top)) * local(top) * ... * local(self), left to right as the DFS does (sc_ecs.cpp:178-209),
+//            the ancestors' local matrices read from LDS (every ancestor at or below `top` rebuilds too, so its lane wrote one)
+//   trip 3   the bin reservation
+// Same arithmetic on the same values in the same order: bit-identical results.  LDS: 12 KiB of local matrices + 1 KiB of
+// link words per workgroup, seven workgroups per CU.
+// ------------------------------------------------------------------------------------------
+#ifndef SC_LDS_WAVES
+#define SC_LDS_WAVES 6
+#endif
+#if SC_LDS_WAVES
+#define SC_LDS_OCC __attribute__((amdgpu_waves_per_eu(SC_LDS_WAVES, SC_LDS_WAVES)))
+#else
+#define SC_LDS_OCC
+#endif
+#ifndef SC_EARLY_BOUNDS
+#define SC_EARLY_BOUNDS 0
+#endif
+constexpr bool kEarlyBounds = SC_EARLY_BOUNDS != 0;     // bounds requested in trip 2 (six more VGPRs across the products) or behind them
+template <bool kCull, bool kAabb, uint32_t kChain>
+__device__ __forceinline__ void xformCullLdsBody(const DeviceState& d, const TickParams& p, float (*sL)[kTile], uint32_t* sLink, uint32_t* sDirty);
+
+template <bool kCull, bool kAabb, uint32_t kChain>
+__global__ __launch_bounds__(kTile) SC_LDS_OCC void k_xform_cull_lds(const DeviceState d, const TickParams p)
+{
+  __shared__ float sL[12][kTile];
+  __shared__ uint32_t sLink[kTile];
+  __shared__ uint32_t sDirty[kTile / 32];
+  xformCullLdsBody<kCull, kAabb, kChain>(d, p, sL, sLink, sDirty);
+}
+
+template <bool kCull, bool kAabb, uint32_t kChain>
+__device__ __forceinline__ void xformCullLdsBody(const DeviceState& d, const TickParams& p, float (*sL)[kTile], uint32_t* sLink, uint32_t* sDirty)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t begin = blockIdx.x * p.span;
+  const uint32_t end = (begin + p.span < p.n) ? begin + p.span : p.n;
+  const bool doXform = (p.flags & SC_TICK_XFORM) != 0;
+  const bool wantCand = (p.flags & SC_TICK_CULLED_LIST) != 0;
+  const bool hasDeep = (p.flags & kFlagHasDeep) != 0;
+  const uint32_t dirtyWords = (p.n + 31u) >> 5;
+
+  uint32_t visCount = 0, candCount = 0;      // wave-uniform running sums
+
+  for (uint32_t base = begin; base < end; base += kTile) {
+    const uint32_t i = base + threadIdx.x;
+    const bool active = i < p.n;
+    // ---- trip 1: the tile's link and dirty words
+    const uint32_t lk = active ? ldU(d, kLINK, i) : ((kUnreachable << kDepthShift) | kNoParent);
+    if (doXform) {
+      sLink[threadIdx.x] = lk;
+      if (threadIdx.x < kTile / 32u) { const uint32_t w = (base >> 5) + threadIdx.x; sDirty[threadIdx.x] = w < dirtyWords ? d.dirty[w] : 0u; }
+    }
+    __syncthreads();
+    const uint32_t depth = linkDepth(lk);
+    const bool chain = depth <= kChain;
+    // ---- walk up: ancestors a[1..depth], top = dirty level nearest the root
+    uint32_t a[kChain + 1];
+    uint32_t rotFlags = lk >> 29;                      // 3 rotation-triviality bits per level (used for ancestors outside the tile)
+    a[0] = i;
+    int top = -1;
+#pragma unroll
+    for (uint32_t k = 1; k <= kChain; ++k) a[k] = i;
+    if (doXform && chain) {
+      if ((sDirty[threadIdx.x >> 5] >> (threadIdx.x & 31u)) & 1u) top = 0;
+      uint32_t cur = lk;
+#pragma unroll
+      for (uint32_t k = 1; k <= kChain; ++k) {
+        if (k <= depth) {
+          a[k] = cur & kParentMask;
+          const uint32_t r = a[k] - base;
+          bool ad;
+          if (r < kTile) { cur = sLink[r]; ad = (sDirty[r >> 5] >> (r & 31u)) & 1u; }
+          else { cur = ldU(d, kLINK, a[k]); ad = dirtyBit(d.dirty, a[k]); }
+          rotFlags |= (cur >> 29) << (3u * k);
+          if (ad) top = (int)k;
+        }
+      }
+    }
+    const bool recompute = top >= 0;
+    const bool fromRoot = recompute && (uint32_t)top == depth;       // the chain's root itself is rebuilt: world = local
+
+    // ---- trip 2: own locals (-> LDS) or own stored rows; the seed; bounds
+    Aff M;
+    if (recompute) {
+      {
+        const Aff Lown = loadLocal(d, i, lk);
+        sL[0][threadIdx.x] = Lown.r0[0]; sL[1][threadIdx.x] = Lown.r0[1]; sL[2][threadIdx.x] = Lown.r0[2]; sL[3][threadIdx.x] = Lown.r0[3];
+        sL[4][threadIdx.x] = Lown.r1[0]; sL[5][threadIdx.x] = Lown.r1[1]; sL[6][threadIdx.x] = Lown.r1[2]; sL[7][threadIdx.x] = Lown.r1[3];
+        sL[8][threadIdx.x] = Lown.r2[0]; sL[9][threadIdx.x] = Lown.r2[1]; sL[10][threadIdx.x] = Lown.r2[2]; sL[11][threadIdx.x] = Lown.r2[3];
+      }
+      if (!fromRoot) {
+        uint32_t seed = i;
+#pragma unroll
+        for (uint32_t k = 0; k < kChain; ++k) if ((uint32_t)top == k) seed = a[k + 1];
+        M = loadRows(d, seed);                           // clean parent of the top dirty ancestor: its stored (possibly stale) matrix
+      }
+    } else if ((kCull || kAabb) && active) {
+      M = loadRows(d, i);
+    }
+    const bool hb = active && (lk & kHasBounds);
+    BoundsCE b = {0, 0, 0, 0, 0, 0};
+    if (kEarlyBounds && (kCull || kAabb) && hb) b = loadBounds(d, i);
+    if (doXform) __syncthreads();
+
+    if (recompute) {
+      // the chain's local matrices come back from LDS, the entity's own included (level 0)
+#pragma unroll
+      for (int lev = (int)kChain; lev >= 0; --lev) {
+        if (lev <= top) {
+          Aff L;
+          const uint32_t r = a[lev] - base;
+          if (lev == 0 || r < kTile) {
+            L.r0[0] = sL[0][r]; L.r0[1] = sL[1][r]; L.r0[2] = sL[2][r]; L.r0[3] = sL[3][r];
+            L.r1[0] = sL[4][r]; L.r1[1] = sL[5][r]; L.r1[2] = sL[6][r]; L.r1[3] = sL[7][r];
+            L.r2[0] = sL[8][r]; L.r2[1] = sL[9][r]; L.r2[2] = sL[10][r]; L.r2[3] = sL[11][r];
+          } else L = loadLocal(d, a[lev], (rotFlags >> (3 * lev)) << 29);
+          if (lev == top && fromRoot) M = L;
+          else M = mulAff(M, L);
+        }
+      }
+      if (!kAabb) storeRows(d, i, M);                    // (with binning the store rides behind the bin reservations: binEntityWave)
+    }
+    if (!kEarlyBounds && (kCull || kAabb) && hb) b = loadBounds(d, i);
+
+    if (hasDeep) {
+      const unsigned long long rm = ballot64(recompute);
+      if (lane == 0 && (base + wave * 64u) < p.n) d.recomp[(base >> 6) + wave] = rm;
+    }
+
+    if (kCull || kAabb) {
+      const bool cand = active && (lk & kHasMesh);
       if (kCull) {
         bool visible = cand;
         if (cand && hb && !p.freeze && p.frustumValid) {
@@ -487,7 +761,7 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
       if (kAabb) {
         // deeper entities are binned by the level kernels once their matrix is final
         const bool collider = hb && !(doXform && depth > kChain && depth != kUnreachable);
-        binEntityWave(d, p, i, collider, M, b);
+        binEntityWave(d, p, i, collider, M, b, recompute);
       }
     }
   }
@@ -617,25 +891,60 @@ __device__ __forceinline__ LaneStep advanceAlongLane(const LaneGraphDev& g, uint
   return r;
 }
 
-// TrafficAISystem for one agent of the OnRails tier, without a PhysicsWorld (no obstacle ray: obstacleBrake = 0):
-// the per-agent preamble src/engine/traffic/sc_traffic_ai.cpp:264-299 (valid active lane, look-ahead point, the 1e-4 early
-// out, desired speed) and the on-rails branch :434-460.  Returns true when the transform was written (Transform::dirty).
+// TrafficLaneGraph::queryNearestLane (sc_traffic_lanes.cpp:240-279) for ONE position, by a whole wave (every lane must call):
+// lanes take the segments 64 at a time; each keeps its closest (strict <, so the lowest index among equals within the lane),
+// and one 64-bit min over (bits of the squared distance, index) elects the winner -- squared distances are >= 0, so their
+// bit patterns order like the values, and equal distances go to the lower index as in the reference's ascending scan.
+// Returns the lane id (kInvalidLane: no active segment) and its s, wave-uniform.
+__device__ __forceinline__ uint32_t queryNearestLaneWave(const LaneGraphDev& g, float x, float y, float z, float& sOut)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  float bestD = INFINITY, bestS = 0.0f; uint32_t best = kInvalidLane;
+  for (uint32_t i = lane; i < g.segments; i += 64u) {
+    const uint4 C = g.segC[i];
+    const float4 A = g.segA[i], B = g.segB[i];
+    if (!C.y || A.w <= 1e-5f) continue;                              // !seg.active || seg.length <= 1e-5f
+    const float tx = x - A.x, ty = y - A.y, tz = z - A.z;
+    const float proj = tx * B.x + ty * B.y + tz * B.z;
+    const float mn = (proj < A.w) ? proj : A.w;                      // std::min(seg.length, proj)
+    const float sv = (0.0f < mn) ? mn : 0.0f;                        // std::max(0.0f, ...)
+    const float cx = A.x + B.x * sv, cy = A.y + B.y * sv, cz = A.z + B.z * sv;
+    const float dx = x - cx, dy = y - cy, dz = z - cz;
+    const float distSq = dx * dx + dy * dy + dz * dz;
+    if (best == kInvalidLane || distSq < bestD) { bestD = distSq; best = i; bestS = sv; }
+  }
+  unsigned long long key = ((unsigned long long)__float_as_uint(bestD) << 32) | best;
+  unsigned long long low = key;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(low, o, 64); low = other < low ? other : low; }
+  const unsigned long long winners = ballot64(best != kInvalidLane && key == low);
+  sOut = 0.0f;
+  if (!winners) return kInvalidLane;
+  const int win = __ffsll((long long)winners) - 1;
+  sOut = __shfl(bestS, win, 64);
+  return (uint32_t)__shfl((int)best, win, 64);
+}
+
+// TrafficAISystem for one agent of the OnRails tier: the per-agent preamble src/engine/traffic/sc_traffic_ai.cpp:274-299 (valid
+// active lane, look-ahead point, the 1e-4 early out, desired speed), the obstacle brake of :300-345 as the agent's front ray
+// left it in aBrake[] (k_agent_front_rays; 0 without sensors, as the reference without a PhysicsWorld), and the on-rails branch
+// :434-460.  (lane, s0) are the agent's lane state after the re-acquisition of :264-272, which the caller performs.
+// Returns true when the transform was written (Transform::dirty).
 // `smooth` = 1 - exp(-2.5 dt) from the host (smoothExp :58-62); the yaw's sin / cos come from the segment table.
-__device__ __forceinline__ bool trafficAgentStep(const DeviceState& d, uint32_t i, float dt, float smooth, float mult)
+__device__ __forceinline__ bool trafficAgentStep(const DeviceState& d, uint32_t i, uint32_t lane, float s0, float dt, float smooth, float mult)
 {
   if (d.aMode[i] != kTierOnRails) return false;               // Physics / Kinematic tiers: moved by the physics sync, not here
   const LaneGraphDev& g = d.lanes;
-  const uint32_t lane = d.aLane[i];
   if (lane == kInvalidLane || lane >= g.segments) return false;
   if (!g.segC[lane].y) return false;
-  const float s0 = d.aS[i];
   const LaneStep look = advanceAlongLane(g, lane, s0, d.aLook[i]);   // getLookAheadPoint, sc_traffic_lanes.cpp:281-289
   if (!look.ok) return false;
   const float tx = look.pos[0] - d.px[i], tz = look.pos[2] - d.pz[i];
   if (sqrtf(tx * tx + 0.0f * 0.0f + tz * tz) < 1e-4f) return false;
   float desiredSpeed = g.segB[lane].w * mult;
   desiredSpeed = (0.0f < desiredSpeed) ? desiredSpeed : 0.0f;         // std::max(0.0f, desiredSpeed)
-  const float desired = desiredSpeed * (1.0f - 0.0f);
+  const float obstacleBrake = d.aBrake ? d.aBrake[i] : 0.0f;          // :300-345
+  const float desired = desiredSpeed * (1.0f - obstacleBrake);        // :436
   const float cur = d.aSpeed[i];
   const float speed = cur + (desired - cur) * smooth;
   d.aSpeed[i] = speed;
@@ -648,6 +957,7 @@ __device__ __forceinline__ bool trafficAgentStep(const DeviceState& d, uint32_t 
   return true;
 }
 
+// One entity per lane; every lane of the wave must call (the lane re-acquisition is a whole-wave step).
 __device__ __forceinline__ bool moverPosition(const DeviceState& d, uint32_t i, uint32_t n, float dt, float smooth, float mult)
 {
   const bool in = i < n;
@@ -655,7 +965,23 @@ __device__ __forceinline__ bool moverPosition(const DeviceState& d, uint32_t i, 
   const uint32_t kind = in ? d.moverKind[i] : 0u;
   float vx = 0, vz = 0, lox = 0, loz = 0, hix = 0, hiz = 0, x = 0, z = 0;
   if (in) { vx = d.mvx[i]; vz = d.mvz[i]; lox = d.mlox[i]; loz = d.mloz[i]; hix = d.mhix[i]; hiz = d.mhiz[i]; x = d.px[i]; z = d.pz[i]; }
-  if (kind == kMoverTraffic) return trafficAgentStep(d, i, dt, smooth, mult);      // (behind the loads: they must not wait for `kind`)
+  // An agent without a lane takes the nearest active one first, whatever its tier (sc_traffic_ai.cpp:264-272): rare -- a lane
+  // id is lost when its sector's lanes go (sc_traffic_lanes.cpp:227-237) -- so the wave serves such lanes one after the other.
+  uint32_t aLane = kInvalidLane; float aS = 0.0f;
+  if (d.aLane) {
+    const bool agent = kind == kMoverTraffic;
+    if (agent) { aLane = d.aLane[i]; aS = d.aS[i]; }
+    unsigned long long lost = ballot64(agent && aLane == kInvalidLane);
+    while (lost) {
+      const int src = __ffsll((long long)lost) - 1;
+      lost &= lost - 1ull;
+      const uint32_t who = (uint32_t)__shfl((int)i, src, 64);
+      float qs;
+      const uint32_t q = queryNearestLaneWave(d.lanes, __shfl(x, src, 64), d.py[who], __shfl(z, src, 64), qs);
+      if ((int)(threadIdx.x & 63u) == src && q != kInvalidLane) { aLane = q; aS = qs; d.aLane[i] = q; d.aS[i] = qs; }
+    }
+  }
+  if (kind == kMoverTraffic) return trafficAgentStep(d, i, aLane, aS, dt, smooth, mult);      // (behind the loads: they must not wait for `kind`)
   if (kind) {
     x = x + vx * dt; z = z + vz * dt;
     if (kind == 1u) {
@@ -1462,55 +1788,95 @@ __device__ __forceinline__ uint32_t blockScanExclusive(uint32_t v, uint32_t carr
   return before + incl - v;
 }
 
+// a record that overlaps nothing and passes no filter: padding where a count was promised and the record could not be found
+__device__ __forceinline__ void nullRecord(float4& lo, float4& hi)
+{
+  lo = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0u));
+  hi = make_float4(-INFINITY, -INFINITY, -INFINITY, __uint_as_float(0x00FFFFFFu));
+}
+
 __device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickParams& p, uint32_t dir)
 {
   __shared__ uint32_t sWave[4];
   if (!((p.neighbourMask >> dir) & 1u) || !d.borderSend[dir]) return;
   int dx, dz; borderDir(dir, dx, dz);
+  const uint32_t lane = threadIdx.x & 63u;
   const uint32_t L = borderLen(dir, p.binSX - 2u, p.binSZ - 2u);
   uint32_t* msg = d.borderSend[dir];
-  const uint32_t cap = borderRecCap(L);
+  const uint32_t cap = borderRecCap(L, p.borderRecs);
   float4* records = reinterpret_cast<float4*>(msg + kBorderHeader + L);
   // 2 * kTile ring bins at a time (one pass for a 256-sector side): a thread takes two neighbouring bins, finds their
   // offsets (parallel scan, carry across chunks) and copies their records.  Ring bins are sparse, and 512 bins in flight
   // hide the latency that a wave-per-bin walk would serialise (measured: 59 us against 14).
   // (the kernel is a chain of dependent memory round trips, nothing else: a bin's FIRST record is requested together with its
   //  count -- its address does not depend on the count, most ring bins hold none or one -- and so is the big-box count below)
+  // A ring sector that holds more than its bin (round 3): the sector's counter kept counting and the rest of its records sit in
+  // the sector overflow list, tagged with the sector.  They cross the border like the bin's records -- the message reserves
+  // room for the sector's whole count, the thread copies the bin part, and the WAVE then sweeps the sector's slice of the
+  // overflow list for the rest (the pair search gathers a sector's overflow the same way).  What a message cannot hold, and
+  // what lies beyond a sector's 64 + 1024 records, is counted in border_lost.
   const uint32_t ctr = kCtrPar + 8u * p.parity;
   const uint32_t nLocal = min(d.counters[ctr + kCtrBig], p.bigCap);          // the merge has not run yet: only this tile's boxes
+  const uint32_t novf = min(d.counters[ctr + kCtrSpill], p.ovfCap);
   auto copyBin = [&](uint32_t cell, uint32_t off, uint32_t take, const float4& lo0, const float4& hi0) {
     const float4* src = d.bins + 2u * ((size_t)cell * kBinCap);
     float4* dst = records + 2u * (size_t)off;
     dst[0] = lo0; dst[1] = hi0;
     for (uint32_t r = 1; r < take; ++r) { dst[2u * r] = src[2u * r]; dst[2u * r + 1u] = src[2u * r + 1u]; }
   };
+  // the overflow part of the bins a wave's lanes hold: one bin after the other, all 64 lanes on its slice of the list
+  auto sweepOverflow = [&](uint32_t cell, uint32_t off, uint32_t take) {
+    unsigned long long todo = ballot64(take > kBinCap);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      const uint32_t wCell = __shfl(cell, src, 64), wOff = __shfl(off, src, 64), wTake = __shfl(take, src, 64);
+      const uint32_t want = wTake - kBinCap;                 // records to find in the list
+      uint32_t eLo = d.ovfLo[wCell], eHi = d.ovfHi[wCell];
+      if (eHi > novf) eHi = novf;
+      float4* dst = records + 2u * ((size_t)wOff + kBinCap);
+      uint32_t found = 0;
+      for (uint32_t e0 = eLo; e0 < eHi && found < want; e0 += 64u) {
+        const uint32_t e = e0 + lane;
+        const bool match = e < eHi && d.spillSector[e] == wCell;
+        const unsigned long long mm = ballot64(match);
+        const uint32_t at = found + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+        if (match && at < want) { dst[2u * at] = d.spill[2u * (size_t)e]; dst[2u * at + 1u] = d.spill[2u * (size_t)e + 1u]; }
+        found += (uint32_t)__popcll(mm);
+      }
+      // (the counter promised more than the list holds -- only when the list itself ran out: keep the count, pad with nothing)
+      for (uint32_t q = (found < want ? found : want) + lane; q < want; q += 64u) { float4 lo, hi; nullRecord(lo, hi); dst[2u * q] = lo; dst[2u * q + 1u] = hi; }
+    }
+  };
   uint32_t carry = 0;
   for (uint32_t base = 0; base < L; base += 2u * kTile) {
     const uint32_t l0 = base + 2u * threadIdx.x, l1 = l0 + 1u;
     uint32_t c0 = 0, c1 = 0, cell0 = 0, cell1 = 0;
     float4 a0 = make_float4(0, 0, 0, 0), b0 = a0, a1 = a0, b1 = a0;
-    // (a ring sector carries at most one bin's worth of boxes across the border: what overflowed there is counted as lost)
     uint32_t over = 0;
     if (l0 < L) { bool send = false; cell0 = ringCell(p, dx, dz, l0, &send); if (send) { c0 = d.binCount[cell0]; const float4* r = d.bins + 2u * ((size_t)cell0 * kBinCap); a0 = r[0]; b0 = r[1]; } }
     if (l1 < L) { bool send = false; cell1 = ringCell(p, dx, dz, l1, &send); if (send) { c1 = d.binCount[cell1]; const float4* r = d.bins + 2u * ((size_t)cell1 * kBinCap); a1 = r[0]; b1 = r[1]; } }
-    if (c0 > kBinCap) { over += c0 - kBinCap; c0 = kBinCap; }
-    if (c1 > kBinCap) { over += c1 - kBinCap; c1 = kBinCap; }
-    if (over) atomicAdd(&d.counters[ctr + kCtrBorderLost], over);
+    if (c0 > kSectorRecMax) { over += c0 - kSectorRecMax; c0 = kSectorRecMax; }
+    if (c1 > kSectorRecMax) { over += c1 - kSectorRecMax; c1 = kSectorRecMax; }
     uint32_t total;
     const uint32_t off0 = blockScanExclusive(c0 + c1, carry, sWave, &total), off1 = off0 + c0;
     const uint32_t take0 = (off0 + c0 <= cap) ? c0 : (off0 < cap ? cap - off0 : 0u);
     const uint32_t take1 = (off1 + c1 <= cap) ? c1 : (off1 < cap ? cap - off1 : 0u);
+    over += (c0 - take0) + (c1 - take1);                      // the message is full
+    if (over) atomicAdd(&d.counters[ctr + kCtrBorderLost], over);
     if (l0 < L) msg[kBorderHeader + l0] = take0;
     if (l1 < L) msg[kBorderHeader + l1] = take1;
-    if (take0) copyBin(cell0, off0, take0, a0, b0);
-    if (take1) copyBin(cell1, off1, take1, a1, b1);
+    if (take0) copyBin(cell0, off0, take0 < kBinCap ? take0 : kBinCap, a0, b0);
+    if (take1) copyBin(cell1, off1, take1 < kBinCap ? take1 : kBinCap, a1, b1);
+    sweepOverflow(cell0, off0, take0);
+    sweepOverflow(cell1, off1, take1);
     carry = total;
   }
   if (threadIdx.x == 0) { msg[0] = carry < cap ? carry : cap; msg[1] = carry > cap ? 1u : 0u; }
 
   // ---- big-box section: this tile's big boxes that reach the neighbour's owned region (its core, unbounded on
   // the sides where the world ends) within kBigReach sectors
-  uint32_t* big = msg + borderBinWords(dir, p.binSX - 2u, p.binSZ - 2u);
+  uint32_t* big = msg + borderBinWords(dir, p.binSX - 2u, p.binSZ - 2u, p.borderRecs);
   __shared__ uint32_t bigCount, bigLost;
   if (threadIdx.x == 0) { bigCount = 0u; bigLost = 0u; }
   __syncthreads();
@@ -1581,42 +1947,84 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
   if (threadIdx.x == 0 && msg[1]) atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);   // sender ran out of message space
   const float4* records = reinterpret_cast<const float4*>(msg + kBorderHeader + L);
   // (requested up front, used at the end: the kernel is a chain of dependent round trips)
-  const uint32_t* big = msg + borderBinWords(dir, p.binSX - 2u, p.binSZ - 2u);
+  const uint32_t* big = msg + borderBinWords(dir, p.binSX - 2u, p.binSZ - 2u, p.borderRecs);
   const uint32_t bigHead0 = big[0], bigHead1 = big[1];
+  const uint32_t lane = threadIdx.x & 63u;
+  // One record to its place: slot `slot` of the sector's bin, or entry q of the sector overflow list when the bin is full.
+  auto place = [&](uint32_t sector, uint32_t slot, uint32_t q, const float4& lo, const float4& hi) {
+    if (slot < kBinCap) {
+      float4* dst = d.bins + 2u * ((size_t)sector * kBinCap + slot);
+      dst[0] = lo; dst[1] = hi;
+    } else if (q < p.ovfCap) {
+      d.spill[2u * (size_t)q] = lo; d.spill[2u * (size_t)q + 1u] = hi; d.spillSector[q] = sector;
+    } else atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);
+  };
+  // reserve room for c records of one landing sector: bin slots first, the rest in the sector overflow list (ONE reservation
+  // each, and the sector's slice bounds follow: two atomics per sector, not per record)
+  auto reserve = [&](uint32_t sector, uint32_t c, uint32_t& slot0, uint32_t& q0) {
+    slot0 = atomicAdd(&d.binCount[sector], c);
+    const uint32_t inBin = slot0 < kBinCap ? (c < kBinCap - slot0 ? c : kBinCap - slot0) : 0u;
+    const uint32_t nOver = c - inBin;
+    q0 = 0;
+    if (nOver) {
+      q0 = atomicAdd(&d.counters[ctr + kCtrSpill], nOver);
+      if (q0 < p.ovfCap) { atomicMin(&d.ovfLo[sector], q0); atomicMax(&d.ovfHi[sector], (q0 + nOver < p.ovfCap) ? q0 + nOver : p.ovfCap); }
+    }
+    // (record r goes to slot0 + r while that is below the bin's capacity, else to list entry q0 + (slot0 + r - max(slot0, 64)))
+  };
+  constexpr uint32_t kSerial = 4;                          // a sector's records up to this many are landed by its own thread
   auto landBin = [&](uint32_t l, uint32_t off, uint32_t c) {
     // the sender's ring cell l on its side (-dx,-dz) is this tile's cell l along its own side (dx,dz)
     const uint32_t sector = landingCell(p, dx, dz, l);
     const float4* src = records + 2u * (size_t)off;
     const float4 lo0 = src[0], hi0 = src[1];                      // in flight together with the slot reservation
-    const uint32_t slot0 = atomicAdd(&d.binCount[sector], c);
+    uint32_t slot0, q0; reserve(sector, c, slot0, q0);
+    const uint32_t firstOver = slot0 < kBinCap ? kBinCap : slot0;
     uint32_t lay = 0;
     for (uint32_t r = 0; r < c; ++r) {
       const float4 lo = r ? src[2u * r] : lo0, hi = r ? src[2u * r + 1u] : hi0;
       lay |= __float_as_uint(lo.w);
-      if (slot0 + r < kBinCap) {
-        float4* dst = d.bins + 2u * ((size_t)sector * kBinCap + slot0 + r);
-        dst[0] = lo; dst[1] = hi;
-      } else {
-        // the landing bin is full: the record joins the sector overflow list; the pair search gathers it back
-        const uint32_t q = atomicAdd(&d.counters[ctr + kCtrSpill], 1u);
-        if (q < p.ovfCap) {
-          d.spill[2u * (size_t)q] = lo; d.spill[2u * (size_t)q + 1u] = hi; d.spillSector[q] = sector;
-          atomicMin(&d.ovfLo[sector], q); atomicMax(&d.ovfHi[sector], q + 1u);
-        } else atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);
-      }
+      place(sector, slot0 + r, q0 + (slot0 + r - firstOver), lo, hi);
     }
     if (lay) atomicOr(&d.binLayers[sector], lay);
+  };
+  // crowded landing sectors: the wave lands them one after the other, a record per lane and round
+  auto landCrowded = [&](uint32_t l, uint32_t off, uint32_t c, bool mine) {
+    unsigned long long todo = ballot64(mine);
+    while (todo) {
+      const int srcLane = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      const uint32_t wl = __shfl(l, srcLane, 64), wOff = __shfl(off, srcLane, 64), wc = __shfl(c, srcLane, 64);
+      const uint32_t sector = landingCell(p, dx, dz, wl);
+      uint32_t slot0 = 0, q0 = 0;
+      if (lane == 0) reserve(sector, wc, slot0, q0);
+      slot0 = __shfl(slot0, 0, 64); q0 = __shfl(q0, 0, 64);
+      const uint32_t firstOver = slot0 < kBinCap ? kBinCap : slot0;
+      const float4* src = records + 2u * (size_t)wOff;
+      uint32_t lay = 0;
+      for (uint32_t r = lane; r < wc; r += 64u) {
+        const float4 lo = src[2u * r], hi = src[2u * r + 1u];
+        lay |= __float_as_uint(lo.w);
+        place(sector, slot0 + r, q0 + (slot0 + r - firstOver), lo, hi);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) lay |= (uint32_t)__shfl_xor((int)lay, o, 64);
+      if (lane == 0 && lay) atomicOr(&d.binLayers[sector], lay);
+    }
   };
   uint32_t carry = 0;
   for (uint32_t base = 0; base < L; base += 2u * kTile) {
     const uint32_t l0 = base + 2u * threadIdx.x, l1 = l0 + 1u;
-    // (counts are what a neighbour wrote: held to what a message can carry whatever arrives)
-    const uint32_t c0 = l0 < L ? min(msg[kBorderHeader + l0], kBinCap) : 0u, c1 = l1 < L ? min(msg[kBorderHeader + l1], kBinCap) : 0u;
+    // (counts are what a neighbour wrote: held to what a sector can hold whatever arrives)
+    const uint32_t c0 = l0 < L ? min(msg[kBorderHeader + l0], kSectorRecMax) : 0u, c1 = l1 < L ? min(msg[kBorderHeader + l1], kSectorRecMax) : 0u;
     uint32_t total;
     const uint32_t off0 = blockScanExclusive(c0 + c1, carry, sWave, &total);
-    const uint32_t recCap = borderRecCap(L);
-    if (c0 && off0 + c0 <= recCap) landBin(l0, off0, c0);
-    if (c1 && off0 + c0 + c1 <= recCap) landBin(l1, off0 + c0, c1);
+    const uint32_t recCap = borderRecCap(L, p.borderRecs);
+    const bool ok0 = c0 && off0 + c0 <= recCap, ok1 = c1 && off0 + c0 + c1 <= recCap;
+    if (ok0 && c0 <= kSerial) landBin(l0, off0, c0);
+    if (ok1 && c1 <= kSerial) landBin(l1, off0 + c0, c1);
+    landCrowded(l0, off0, c0, ok0 && c0 > kSerial);
+    landCrowded(l1, off0 + c0, c1, ok1 && c1 > kSerial);
     carry = total;
   }
   // the neighbour's big boxes that reach this tile join the big list behind this tile's own
@@ -1895,8 +2303,13 @@ void launchStageFrame(const DeviceState& d, uint32_t* block, uint32_t maxVisible
 template <bool kCull, bool kAabb, uint32_t kChain>
 static void launchOne(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA, hipEvent_t evB)
 {
-  if (evA) hipExtLaunchKernelGGL((k_xform_cull<kCull, kAabb, kChain>), dim3(grid), dim3(kTile), 0, s, evA, evB, 0, d, p);
-  else hipLaunchKernelGGL((k_xform_cull<kCull, kAabb, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
+  if (p.variant & 1u) {                                    // SC_TICK_VARIANT bit 0: round 2's chain walk through memory (A/B)
+    if (evA) hipExtLaunchKernelGGL((k_xform_cull<kCull, kAabb, kChain>), dim3(grid), dim3(kTile), 0, s, evA, evB, 0, d, p);
+    else hipLaunchKernelGGL((k_xform_cull<kCull, kAabb, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
+    return;
+  }
+  if (evA) hipExtLaunchKernelGGL((k_xform_cull_lds<kCull, kAabb, kChain>), dim3(grid), dim3(kTile), 0, s, evA, evB, 0, d, p);
+  else hipLaunchKernelGGL((k_xform_cull_lds<kCull, kAabb, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
 }
 template <uint32_t kChain>
 static void launchXformCullChain(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA, hipEvent_t evB)

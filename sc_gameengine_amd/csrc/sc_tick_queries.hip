@@ -42,26 +42,22 @@ __device__ __forceinline__ Slab rayBox(const float o[3], const float dir[3], flo
   return s;
 }
 
-__global__ __launch_bounds__(kTile) void k_ray_queries(const DeviceState d, const TickParams p, const RayQueryState q)
+// One ray, cast by a whole wave (every lane must call): `valid` false = no segment (|dir|^2 <= 1e-6 or a negative length).
+// The result is wave-uniform.  skipId: a box that never answers (0xFFFFFFFF = none) -- an agent's own box for its front ray.
+struct WaveRay { bool valid, hit; float t; uint32_t id, axis, layer; float dir[3]; };
+
+__device__ __forceinline__ WaveRay castRayWave(const DeviceState& d, const TickParams& p, const float o[3], const float dm[3], float maxDist,
+                                               uint32_t rayMask, uint32_t skipId)
 {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t r = blockIdx.x * (kTile / 64u) + (threadIdx.x >> 6);
-  if (r >= q.count) return;
-  const float4 od = q.origin[r], dm = q.dir[r];
-  const float o[3] = { od.x, od.y, od.z };
-  const float maxDist = od.w;
-  const uint32_t rayMask = __float_as_uint(dm.w);
-  RayHit48 out;
-  out.hit = 0u; out.id = 0xFFFFFFFFu; out.distance = 0.0f;
-  out.position[0] = out.position[1] = out.position[2] = 0.0f;
-  out.normal[0] = 0.0f; out.normal[1] = 1.0f; out.normal[2] = 0.0f;           // RaycastHit{} (sc_physics.h:106-114)
-  out.layer = 0u; out.pad = 0u; out.pad2 = 0u;
-
-  const float lenSq = dm.x * dm.x + dm.y * dm.y + dm.z * dm.z;
+  WaveRay w; w.valid = false; w.hit = false; w.t = 0.0f; w.id = 0xFFFFFFFFu; w.axis = 3u; w.layer = 0u; w.dir[0] = w.dir[1] = w.dir[2] = 0.0f;
+  const float lenSq = dm[0] * dm[0] + dm[1] * dm[1] + dm[2] * dm[2];
   // (a NaN or non-positive length is no segment either)
-  if (!(lenSq > 1e-6f) || !(maxDist >= 0.0f)) { if (lane == 0) q.hits[r] = out; return; }
+  if (!(lenSq > 1e-6f) || !(maxDist >= 0.0f)) return w;
+  w.valid = true;
   const float invLen = 1.0f / sqrtf(lenSq);
-  const float dir[3] = { dm.x * invLen, dm.y * invLen, dm.z * invLen };
+  const float dir[3] = { dm[0] * invLen, dm[1] * invLen, dm[2] * invLen };
+  w.dir[0] = dir[0]; w.dir[1] = dir[1]; w.dir[2] = dir[2];
   const float ex = o[0] + dir[0] * maxDist, ez = o[2] + dir[2] * maxDist;
 
   // this lane's best so far
@@ -70,9 +66,10 @@ __global__ __launch_bounds__(kTile) void k_ray_queries(const DeviceState d, cons
     const uint32_t lay = __float_as_uint(lo.w);
     // Bullet's needsCollision with the callback's group 0xFFFF: (proxy.group & mask) && (0xFFFF & proxy.mask)
     if (!((lay & 0xFFFFu) & rayMask) || !(lay >> 16)) return;
+    const uint32_t id = __float_as_uint(hi.w) & ~kPrimary;
+    if (id == skipId) return;
     const Slab s = rayBox(o, dir, maxDist, lo, hi);
     if (!s.hit) return;
-    const uint32_t id = __float_as_uint(hi.w) & ~kPrimary;
     if (s.t < bt || (s.t == bt && id < bid)) { bt = s.t; bid = id; baxis = s.axis; blayer = lay & 0xFFFFu; }
   };
 
@@ -80,6 +77,7 @@ __global__ __launch_bounds__(kTile) void k_ray_queries(const DeviceState d, cons
   const float fx0 = floorf((o[0] < ex ? o[0] : ex) * p.invSector) - p.binOx, fx1 = floorf((o[0] < ex ? ex : o[0]) * p.invSector) - p.binOx;
   const float fz0 = floorf((o[2] < ez ? o[2] : ez) * p.invSector) - p.binOz, fz1 = floorf((o[2] < ez ? ez : o[2]) * p.invSector) - p.binOz;
   const float gridX = (float)p.binSX - 1.0f, gridZ = (float)p.binSZ - 1.0f;
+  bool anyOverflow = false;
   if (p.binSX && fx1 >= 0.0f && fz1 >= 0.0f && fx0 <= gridX && fz0 <= gridZ) {
     const uint32_t gx0 = (uint32_t)(fx0 < 0.0f ? 0.0f : fx0), gx1 = (uint32_t)(fx1 > gridX ? gridX : fx1);
     const uint32_t gz0 = (uint32_t)(fz0 < 0.0f ? 0.0f : fz0), gz1 = (uint32_t)(fz1 > gridZ ? gridZ : fz1);
@@ -94,7 +92,7 @@ __global__ __launch_bounds__(kTile) void k_ray_queries(const DeviceState d, cons
         }
         const uint32_t s = gz * p.binSX + gx;
         uint32_t n = d.binCount[s];
-        if (n > kBinCap) n = kBinCap;
+        if (n > kBinCap) { n = kBinCap; anyOverflow = true; }
         if (lane < n) {
           const float4* rec = d.bins + 2u * ((size_t)s * kBinCap + lane);
           consider(rec[0], rec[1]);
@@ -106,8 +104,12 @@ __global__ __launch_bounds__(kTile) void k_ray_queries(const DeviceState d, cons
   // records that found their sector's bin full -- this tile's own boxes and a neighbour's border records (k_border_merge)
   // -- live only in the sector overflow list; they are this tile's to answer for like the records in the bins.  Duplicates
   // of a box that is also binned elsewhere are harmless: the same box gives the same distance and the id breaks the tie.
-  const uint32_t nspill = min(d.counters[kCtrPar + 8u * p.parity + kCtrSpill], p.ovfCap);
-  for (uint32_t e = lane; e < nspill; e += 64u) consider(d.spill[2u * (size_t)e], d.spill[2u * (size_t)e + 1u]);
+  // (Only a ray that crossed a sector holding more than its bin can meet one of them: a record of the list belongs to a
+  //  sector whose counter passed 64.)
+  if (anyOverflow) {
+    const uint32_t nspill = min(d.counters[kCtrPar + 8u * p.parity + kCtrSpill], p.ovfCap);
+    for (uint32_t e = lane; e < nspill; e += 64u) consider(d.spill[2u * (size_t)e], d.spill[2u * (size_t)e + 1u]);
+  }
 
   // closest hit of the wave: distances are >= 0, so their bit patterns order like the values
   unsigned long long key = ((unsigned long long)__float_as_uint(bt) << 32) | bid;
@@ -119,15 +121,78 @@ __global__ __launch_bounds__(kTile) void k_ray_queries(const DeviceState d, cons
   }
   const bool found = bid != 0xFFFFFFFFu && key == best;
   const unsigned long long winners = ballot64(found);
-  if (!winners) { if (lane == 0) q.hits[r] = out; return; }
-  if (lane == (uint32_t)__ffsll((long long)winners) - 1u) {
-    out.hit = 1u; out.id = bid; out.distance = bt; out.layer = blayer;
-    out.position[0] = o[0] + dir[0] * bt; out.position[1] = o[1] + dir[1] * bt; out.position[2] = o[2] + dir[2] * bt;
-    if (baxis < 3u) {                                   // the face the ray entered through; a ray starting inside keeps (0,1,0)
+  if (!winners) return w;
+  const int win = __ffsll((long long)winners) - 1;
+  w.hit = true;
+  w.t = __shfl(bt, win, 64); w.id = __shfl(bid, win, 64); w.axis = __shfl(baxis, win, 64); w.layer = __shfl(blayer, win, 64);
+  return w;
+}
+
+__global__ __launch_bounds__(kTile) void k_ray_queries(const DeviceState d, const TickParams p, const RayQueryState q)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t r = blockIdx.x * (kTile / 64u) + (threadIdx.x >> 6);
+  if (r >= q.count) return;
+  const float4 od = q.origin[r], dm = q.dir[r];
+  const float o[3] = { od.x, od.y, od.z };
+  const float dv[3] = { dm.x, dm.y, dm.z };
+  RayHit48 out;
+  out.hit = 0u; out.id = 0xFFFFFFFFu; out.distance = 0.0f;
+  out.position[0] = out.position[1] = out.position[2] = 0.0f;
+  out.normal[0] = 0.0f; out.normal[1] = 1.0f; out.normal[2] = 0.0f;           // RaycastHit{} (sc_physics.h:106-114)
+  out.layer = 0u; out.pad = 0u; out.pad2 = 0u;
+  const WaveRay w = castRayWave(d, p, o, dv, od.w, __float_as_uint(dm.w), 0xFFFFFFFFu);
+  if (w.hit) {
+    out.hit = 1u; out.id = w.id; out.distance = w.t; out.layer = w.layer;
+    out.position[0] = o[0] + w.dir[0] * w.t; out.position[1] = o[1] + w.dir[1] * w.t; out.position[2] = o[2] + w.dir[2] * w.t;
+    if (w.axis < 3u) {                                  // the face the ray entered through; a ray starting inside keeps (0,1,0)
       out.normal[0] = out.normal[1] = out.normal[2] = 0.0f;
-      out.normal[baxis] = dir[baxis] > 0.0f ? -1.0f : 1.0f;
+      out.normal[w.axis] = w.dir[w.axis] > 0.0f ? -1.0f : 1.0f;
     }
-    q.hits[r] = out;
+  }
+  if (lane == 0) q.hits[r] = out;
+}
+
+// ---- the traffic AI's obstacle ray (src/engine/traffic/sc_traffic_ai.cpp:300-345) --------------------------------------------
+// Every agent of the OnRails tier casts one ray per step from 1.7 m ahead of its origin (0.6 m up) along its heading --
+// forward = normalize(sin(yaw), 0, cos(yaw)) with the yaw's sin / cos as the entity's rotation streams hold them (host libm) --
+// of TrafficSensors::frontRayLength (20 m) with mask 1, and brakes by clamp01((safe - d) / safe) when something other than
+// itself is closer than TrafficSensors::safeDistance (10 m).  As for the ray queries above the candidates are the world AABBs
+// of this tick's bins (own spec: Bullet is absent); the agent's own box never answers (Bullet does not report a convex shape a
+// ray starts inside, and the reference discards a self hit: :322-325, :336).  The brake waits in aBrake[] for the on-rails
+// step that produces the next frame.
+__global__ __launch_bounds__(kTile) void k_list_onrails_agents(const DeviceState d, uint32_t n)
+{
+  const uint32_t i = blockIdx.x * kTile + threadIdx.x;
+  const bool agent = i < n && d.moverKind[i] == kMoverTraffic && d.aMode[i] == kTierOnRails;
+  const unsigned long long m = ballot64(agent);
+  if (!m) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(d.agentCount, (uint32_t)__popcll(m));
+  base = __shfl(base, 0, 64);
+  if (agent) d.agentList[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+__global__ __launch_bounds__(kTile) void k_agent_front_rays(const DeviceState d, const TickParams p, float rayLen, float safe)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t count = *d.agentCount;
+  const uint32_t waves = gridDim.x * (kTile / 64u);
+  for (uint32_t k = blockIdx.x * (kTile / 64u) + (threadIdx.x >> 6); k < count; k += waves) {
+    const uint32_t i = d.agentList[k];
+    float forward[3] = { d.rsy[i], 0.0f, d.rcy[i] };                 // { sin(currentYaw), 0, cos(currentYaw) }, :304
+    const float len = sqrtf(forward[0] * forward[0] + forward[1] * forward[1] + forward[2] * forward[2]);      // normalize3, :38-48
+    if (len > 1e-6f) { const float inv = 1.0f / len; forward[0] *= inv; forward[1] *= inv; forward[2] *= inv; }
+    const float origin[3] = { d.px[i] + forward[0] * 1.7f, d.py[i] + 0.6f, d.pz[i] + forward[2] * 1.7f };       // :311-315
+    const WaveRay w = castRayWave(d, p, origin, forward, rayLen, 1u, i | p.rankBits);
+    float brake = 0.0f;
+    if (w.hit && safe > 1e-3f && w.t < safe) {
+      const float v = (safe - w.t) / safe;                            // clamp01 = std::max(0, std::min(v, 1)), :16-24
+      const float m = (1.0f < v) ? 1.0f : v;
+      brake = (0.0f < m) ? m : 0.0f;
+    }
+    if (lane == 0) d.aBrake[i] = brake;
   }
 }
 
@@ -160,6 +225,15 @@ void launchOccupancy(const DeviceState& d, uint32_t n, const float4* q, uint32_t
 {
   if (!n || !count) return;
   hipLaunchKernelGGL(k_occupancy, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, q, count, blocked);
+}
+
+void launchAgentFrontRays(const DeviceState& d, const TickParams& p, float rayLen, float safe, hipStream_t s)
+{
+  if (!p.n || !d.aLane || !d.aBrake) return;
+  hipMemsetAsync(d.agentCount, 0, sizeof(uint32_t), s);
+  hipLaunchKernelGGL(k_list_onrails_agents, dim3((p.n + kTile - 1) / kTile), dim3(kTile), 0, s, d, p.n);
+  const uint32_t blocks = std::min((p.n + 3u) / 4u, 8192u);          // (a wave per agent, wave-strided over the list the kernel above wrote)
+  hipLaunchKernelGGL(k_agent_front_rays, dim3(std::max(blocks, 1u)), dim3(kTile), 0, s, d, p, rayLen, safe);
 }
 
 void launchRayQueries(const DeviceState& d, const TickParams& p, const RayQueryState& q, hipStream_t s)

@@ -314,6 +314,15 @@ class WorldTick:
         self._ok(self.lib.scTickReadTrafficAgents(self.ctx, 0, self.n, _u(ln), _f(ls), _f(sp), md.ctypes.data_as(capi.U8P)), "scTickReadTrafficAgents")
         return ln, ls, sp, md
 
+    def set_traffic_sensors(self, on=True, front_ray_length=20.0, safe_distance=10.0):
+        """the traffic AI's obstacle ray per OnRails agent, cast in every run with BROADPHASE; its brake scales the next on-rails step"""
+        self._ok(self.lib.scTickSetTrafficSensors(self.ctx, 1 if on else 0, float(front_ray_length), float(safe_distance)), "scTickSetTrafficSensors")
+
+    def traffic_brakes(self):
+        out = np.zeros(self.n, np.float32)
+        self._ok(self.lib.scTickReadTrafficBrakes(self.ctx, 0, self.n, _f(out)), "scTickReadTrafficBrakes")
+        return out
+
     def set_traffic_speed_multiplier(self, m):
         self._ok(self.lib.scTickSetTrafficSpeedMultiplier(self.ctx, float(m)), "scTickSetTrafficSpeedMultiplier")
 
@@ -340,6 +349,10 @@ class WorldTick:
 
     def set_tile_grid(self, tile_x, tile_z, tiles_x, tiles_z):
         self._ok(self.lib.scTickSetTileGrid(self.ctx, tile_x, tile_z, tiles_x, tiles_z), "scTickSetTileGrid")
+
+    def set_border_capacity(self, records_per_ring_sector):
+        """records per ring sector of a side (on average) a border message can carry; every tile of a world alike, before comm_init / binding"""
+        self._ok(self.lib.scTickSetBorderCapacity(self.ctx, int(records_per_ring_sector)), "scTickSetBorderCapacity")
 
     def border_bytes(self, direction):
         return int(self.lib.scTickBorderBytes(self.ctx, direction))

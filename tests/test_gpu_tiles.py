@@ -107,12 +107,15 @@ def test_context_runs_on_an_external_stream(oracle):
     ow.close()
 
 
-def run_tiles(oracle, w, grid, S, steps=2, nudge=0.9):
+def run_tiles(oracle, w, grid, S, steps=2, nudge=0.9, border_capacity=None, max_pairs=1 << 16):
     """Whole-world pair set from the oracle vs the union of the tiles' pair lists; returns the tiles' counts."""
     import torch
     parts, n = split_world(w, grid, S)
     ow = worlds.oracle_world(oracle, w, camera=False)
-    ticks = [WorldTick.from_world(p, broadphase=True, max_pairs=1 << 16) for p in parts]
+    ticks = [WorldTick.from_world(p, broadphase=True, max_pairs=max_pairs) for p in parts]
+    if border_capacity:
+        for t in ticks:
+            t.set_border_capacity(border_capacity)
     bufs = [tiles.BorderBuffers(t, r, grid, "cuda") for r, t in enumerate(ticks)]
     flags = capi.XFORM | capi.BROADPHASE | capi.SPLIT_PAIRS
     counts = []
@@ -197,6 +200,42 @@ def test_big_boxes_cross_tile_borders(oracle, grid):
     involved = np.isin(want[:, 0], wide) | np.isin(want[:, 1], wide)
     crossing = (want[:, 0] // n) != (want[:, 1] // n)
     assert (involved & crossing).sum() > 20                     # big boxes really pair across tiles
+
+
+@pytest.mark.parametrize("grid,K", [((2, 1), 95), ((2, 2), 199)])
+def test_crowded_sectors_on_tile_edges_lose_nothing(oracle, grid, K):
+    """The engine's own density (200 entities per sector, src/sandbox/src/main.cpp:92-99) on tile edges: every bin overflows,
+    ring sectors hold far more than a bin.  Since round 3 a ring sector's overflow records cross the border with its bin
+    (round 2 counted them in border_lost and the pairs were missing): with the messages sized for the world
+    (scTickSetBorderCapacity) the tiled pair set equals the whole world's and nothing is reported lost."""
+    S = (3, 3)
+    w = sw.generate(S[0] * grid[0], S[1] * grid[1], K, tiles=grid)
+    rng = np.random.default_rng(31 + K)
+    dyn = rng.random(w.n) < 0.3
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    roots = np.flatnonzero((w.parent < 0) & (np.arange(w.n) % (K + 1) != 0))
+    TW, TH = 64.0 * S[0], 64.0 * S[1]
+    e = rng.choice(roots, len(roots) // 3, replace=False)
+    w.pos[e, 0] = (np.round(w.pos[e, 0] / TW) * TW + rng.uniform(-1.5, 1.5, len(e))).astype(np.float32)
+    e = rng.choice(roots, len(roots) // 3, replace=False)
+    w.pos[e, 2] = (np.round(w.pos[e, 2] / TH) * TH + rng.uniform(-1.5, 1.5, len(e))).astype(np.float32)
+    counts, want, n = run_tiles(oracle, w, grid, S, steps=3, nudge=0.4, border_capacity=384, max_pairs=1 << 21)
+    assert all(c.border_lost == 0 and c.pairs_truncated == 0 for c in counts)
+    assert sum(c.bin_overflow for c in counts) > 500                 # the overflow lists really carry records
+    crossing = (want[:, 0] // n) != (want[:, 1] // n)
+    assert crossing.sum() > 200
+
+
+def test_border_capacity_is_validated():
+    w = sw.generate(4, 4, 15)
+    t = WorldTick.from_world(w, broadphase=True)
+    for bad in (0, 1089):
+        with pytest.raises(capi.ScTickError, match="border capacity"):
+            t.set_border_capacity(bad)
+    before = t.border_bytes(3)
+    t.set_border_capacity(256)
+    assert t.border_bytes(3) > before
+    t.close()
 
 
 def test_big_box_reaching_past_the_neighbours_is_counted(oracle):

@@ -117,7 +117,7 @@ def test_traffic_as_fused_frame_producer_and_graph_replay(oracle):
 def test_inactive_lanes_speed_multiplier_and_invalid_lane(oracle):
     w = laned_world(12, 12, seed=7)
     agents = np.flatnonzero(w.is_agent)
-    w.agent_lane[agents[:20]] = lanes.INVALID_LANE           # getLane() == nullptr: the agent is skipped
+    w.agent_lane[agents[:20]] = lanes.INVALID_LANE           # no lane: the agent takes the nearest active one first (sc_traffic_ai.cpp:264-272)
     ow, ol, st = oracle_side(oracle, w)
     t = WorldTick.from_world(w, broadphase=False)
     off = np.arange(40, 120, dtype=np.uint32)                # removeSector: these segments go inactive
@@ -138,6 +138,73 @@ def test_inactive_lanes_speed_multiplier_and_invalid_lane(oracle):
     assert np.array_equal(t.world_matrices(), ow.world_matrices()[:w.n])
     a = w.is_agent.astype(bool)
     assert st["speed"][a].max() > 12.0                       # the multiplier raised the target speed above the limit
+    assert (st["lane"][agents[:20]] != lanes.INVALID_LANE).all()          # queryNearestLane found every lost agent a lane ...
+    assert (t.traffic_agents()[0][agents[:20]] != lanes.INVALID_LANE).all()   # ... on the device too (the same one: compared above)
+    t.close(); ow.close(); ol.close()
+
+
+def test_lost_agents_with_no_active_lane_stay_lost(oracle):
+    """queryNearestLane over a graph without an active segment returns nothing: the agent keeps kInvalidLaneId and is skipped."""
+    w = laned_world(8, 8, seed=13)
+    agents = np.flatnonzero(w.is_agent)
+    w.agent_lane[agents[::3]] = lanes.INVALID_LANE
+    ow, ol, st = oracle_side(oracle, w)
+    t = WorldTick.from_world(w, broadphase=False)
+    every = np.arange(len(w.lane_graph.seg_length), dtype=np.uint32)
+    for s in every:
+        ol.set_active(int(s), False)
+    t.set_lane_active(every, False)
+    for k in range(3):
+        oracle_advance(ow, ol, w, st, DT)
+        t.advance_movers(DT)
+    assert_agents_equal(t, w, st, ow)
+    assert (t.traffic_agents()[0][agents[::3]] == lanes.INVALID_LANE).all()
+    t.close(); ow.close(); ol.close()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_on_rails_agents_brake_for_what_their_front_ray_meets_60_ticks(oracle, fused):
+    """The obstacle ray of TrafficAISystem (sc_traffic_ai.cpp:300-345) wired to the on-rails step (:436): every tick casts one
+    ray per OnRails agent against the tick's boxes (own spec: world AABBs, the agent's own box excluded), the brake scales the
+    desired speed of the step that follows.  The oracle does the same with a brute-force ray over every box.  Vehicles carry
+    group 1 / mask all, so they brake for each other where the lanes bunch them up; brakes, lane state and positions are
+    compared as bit patterns, matrices and visible lists as always.  fused: the step rides on the end-of-tick kernel."""
+    w = laned_world(16, 12, seed=21)
+    w.scale[w.is_agent.astype(bool), 1] = np.float32(2.0)    # SynthWorld's vehicles are 0.7 m tall at y = 0.35: the ray (0.6 m above the origin) would pass over them
+    ow, ol, st = oracle_side(oracle, w)
+    vp = camera_view_proj(w.camera)
+    t = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 20)
+    t.set_view_proj(vp)
+    t.set_traffic_sensors(True)                              # TrafficSensors defaults: 20 m ray, 10 m safe distance
+    if fused:
+        t.set_frame_producer(2, DT)
+    a = w.is_agent.astype(bool)
+    braked_ticks, slowest = 0, 1e9
+    for k in range(60):
+        ow.transform_system(); ow.culling_system(view_proj=vp)
+        mn, mx = ow.world_aabbs()
+        brake = ow.traffic_front_ray_brakes(mn[:w.n], mx[:w.n], w.group, w.mask, w.is_agent, st["mode"])
+        ow.traffic_ai_onrails_braked(ol, w.is_agent, st["lane"], st["s"], st["speed"], st["mode"], st["look"], brake, DT)
+        ow.advance_movers(w.mover_kind, st["vel"], w.mover_lo, w.mover_hi, DT)
+        if fused:
+            t.run(capi.FULL | capi.PRODUCE_NEXT)             # tick, rays, and the next frame's step in the end-of-tick kernel
+        else:
+            t.run(capi.FULL)                                 # tick + rays ...
+        if k % 10 == 9 or k < 2:
+            assert np.array_equal(t.visible(), ow.visible()), f"tick {k}"
+            got = t.traffic_brakes()
+            assert np.array_equal(bits(got[a]), bits(brake[a])), f"tick {k}: {(got[a] != brake[a]).sum()} brakes differ"
+        if not fused:
+            t.advance_movers(DT)                             # ... then the step that uses them
+        braked_ticks += int((brake[a] > 0).sum() > 20)
+        slowest = min(slowest, float(st["speed"][a & (st["mode"] == 2) & (brake > 0.5)].min(initial=1e9)))
+        if k % 10 == 9:
+            assert_agents_equal(t, w, st, ow)
+    assert braked_ticks > 30 and slowest < 6.0               # agents really braked, hard enough to fall well below the 12 m/s limit
+    ow.transform_system()
+    t.set_frame_producer(0)
+    t.run(capi.XFORM)
+    assert np.array_equal(t.world_matrices(), ow.world_matrices()[:w.n])
     t.close(); ow.close(); ol.close()
 
 

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Random tiled worlds on ONE GPU (contexts as tiles, device copies as the network) against the whole-world pair set of the
 oracle: tile grids, sector fills (bins that overflow included), dynamic shares, props pushed onto tile edges and corners, wide
-slabs.  A mismatch counts only when no tile reported a loss (border_lost / pairs_truncated are the documented capacities).
+slabs -- up to the engine's own streaming budget of 200 entities per sector (src/sandbox/src/main.cpp:92-99), with the border
+messages sized for it (scTickSetBorderCapacity).  Every world must come out EQUAL with border_lost == 0: ring sectors carry
+their overflow across the border since round 3, so a reported loss is a failure here too (--allow-losses restores round 2's
+reading, where a mismatch counted only when no tile had reported a loss).
     python tools/stress_tiles.py [--seeds 40]"""
 import argparse
 import os
@@ -18,6 +21,7 @@ from tests.test_gpu_tiles import split_world                       # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, default=40)
+ap.add_argument("--allow-losses", action="store_true")
 args = ap.parse_args()
 oracle_py.build(); oracle = oracle_py
 import torch                                                        # noqa: E402
@@ -28,8 +32,13 @@ for seed in range(args.seeds):
     rng = np.random.default_rng(5000 + seed)
     grid = [(2, 1), (2, 2), (4, 2), (3, 3), (1, 2)][int(rng.integers(0, 5))]
     S = (int(rng.integers(2, 6)), int(rng.integers(2, 6)))
-    K = int(rng.choice([7, 15, 31, 63, 95]))
+    K = int(rng.choice([7, 15, 31, 63, 95, 199]))
     pipelined = bool(rng.integers(0, 2))
+    # wide slabs (up to 190 m, centred within 40 m of a tile edge) must not come within two sectors of a tile BEYOND the
+    # neighbouring one -- that is the documented reach of a big box (border_lost counts it): tiles of five sectors hold them
+    wide_world = bool(np.random.default_rng(9000 + seed).integers(0, 2))
+    if wide_world:
+        S = (max(S[0], 5) if grid[0] > 2 else S[0], max(S[1], 5) if grid[1] > 2 else S[1])
     w = sw.generate(S[0] * grid[0], S[1] * grid[1], K, tiles=grid)
     dyn = rng.random(w.n) < float(rng.choice([0.05, 0.3, 1.0]))
     w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
@@ -43,6 +52,8 @@ for seed in range(args.seeds):
         e = rng.choice(roots, len(roots) // share, replace=False)
         w.pos[e, 2] = (np.round(w.pos[e, 2] / TH) * TH + rng.uniform(-1.5, 1.5, len(e))).astype(np.float32)
     nwide = int(rng.choice([0, 0, 10, 60]))
+    if not wide_world:
+        nwide = 0
     if nwide:
         sel = rng.choice(len(roots), min(nwide, len(roots)), replace=False)
         wide = roots[sel]
@@ -54,7 +65,10 @@ for seed in range(args.seeds):
         w.group[wide], w.mask[wide] = sw.GROUP_DYNAMIC, sw.MASK_ALL
     parts, n = split_world(w, grid, S)
     ow = worlds.oracle_world(oracle, w, camera=False)
-    ticks = [WorldTick.from_world(p, broadphase=True, max_pairs=1 << 20) for p in parts]
+    ticks = [WorldTick.from_world(p, broadphase=True, max_pairs=1 << 21) for p in parts]
+    if K >= 63:                                  # crowded sectors on tile edges: messages sized for them, the same on every tile
+        for t in ticks:
+            t.set_border_capacity(384)
     streams = [torch.cuda.Stream() for _ in ticks] if pipelined else None
     if pipelined:
         for t, s in zip(ticks, streams):
@@ -98,6 +112,10 @@ for seed in range(args.seeds):
             state = "LOSSY (reported)" if lost and not dup and not extra else "MISMATCH"
             print(f"seed {seed} step {step}: grid {grid} S {S} K {K} pipelined {pipelined} wide {nwide} edge share {share}: want {len(wkey)} missing {missing} extra {extra} twice {dup} lost {lost}", flush=True)
             break
+        if lost and not args.allow_losses:
+            state = "LOSSY (reported)"
+            print(f"seed {seed} step {step}: grid {grid} S {S} K {K} pipelined {pipelined} wide {nwide} edge share {share}: pairs equal but lost {lost}", flush=True)
+            break
     if state == "MISMATCH":
         bad += 1
     elif state != "equal":
@@ -106,4 +124,4 @@ for seed in range(args.seeds):
         t.close()
     ow.close()
 print(f"{args.seeds - bad - lossy} of {args.seeds} worlds equal, {lossy} with reported losses, {bad} MISMATCHES")
-sys.exit(1 if bad else 0)
+sys.exit(1 if bad or (lossy and not args.allow_losses) else 0)
