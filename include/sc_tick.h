@@ -237,6 +237,24 @@ int scTickCommInit(ScTickContext* ctx, const uint8_t id[SC_TICK_COMM_ID_BYTES], 
 int scTickCommSetPeers(ScTickContext* ctx, const int32_t peer_rank[8]);
 int scTickCommDestroy(ScTickContext* ctx);
 int scTickSetPipelined(ScTickContext* ctx, int enable);
+/* What a multi-GPU run needs in order to be read afterwards: the communicator as ncclCommInitRank saw it, the exchange's
+ * shape, and the host time scTickTileStep spends issuing each half of a step (averages since the last reset; an in-order
+ * captured step counts as one tick half).  Valid without a communicator too (a 1x1 grid: zeros). */
+typedef struct ScTickCommInfo
+{
+  uint32_t has_communicator, world_size, rank;
+  uint32_t rccl_version;               /* ncclGetVersion of the library the context bound at run time */
+  uint32_t neighbour_mask;
+  int32_t  peer_rank[8];               /* -1 = no neighbour in that direction */
+  uint32_t operations_per_group;       /* ncclSend + ncclRecv calls inside the one group of a step */
+  uint32_t pipeline_depth;             /* 0 = in order */
+  uint32_t border_records_per_sector;  /* scTickSetBorderCapacity */
+  uint64_t bytes_sent_per_step;        /* fixed-size messages: what the group moves out of this rank per step */
+  uint64_t host_steps;
+  double   host_tick_half_us, host_pair_half_us;
+} ScTickCommInfo;
+int scTickGetCommInfo(ScTickContext* ctx, ScTickCommInfo* out);
+int scTickResetHostTimes(ScTickContext* ctx);
 int scTickTileStep(ScTickContext* ctx, uint32_t flags);
 /* the middle third of scTickTileStep on its own, for hosts that interleave other work: after scTickRun(... | SC_TICK_SPLIT_PAIRS) */
 int scTickExchangeBorders(ScTickContext* ctx);

@@ -70,6 +70,13 @@ class TierCounts(C.Structure):
     _fields_ = [("physics", C.c_uint32), ("kinematic", C.c_uint32), ("on_rails", C.c_uint32), ("total", C.c_uint32)]
 
 
+class CommInfo(C.Structure):
+    _fields_ = [("has_communicator", C.c_uint32), ("world_size", C.c_uint32), ("rank", C.c_uint32), ("rccl_version", C.c_uint32),
+                ("neighbour_mask", C.c_uint32), ("peer_rank", C.c_int32 * 8), ("operations_per_group", C.c_uint32),
+                ("pipeline_depth", C.c_uint32), ("border_records_per_sector", C.c_uint32), ("bytes_sent_per_step", C.c_uint64),
+                ("host_steps", C.c_uint64), ("host_tick_half_us", C.c_double), ("host_pair_half_us", C.c_double)]
+
+
 class SectorInfo(C.Structure):
     _fields_ = [("version", C.c_uint32), ("sector_x", C.c_int32), ("sector_z", C.c_int32), ("instances", C.c_uint32),
                 ("lanes", C.c_uint32), ("lane_points", C.c_uint32), ("spawners", C.c_uint32), ("colliders", C.c_uint32),
@@ -118,6 +125,8 @@ SYMBOLS = {
     "scTickCommSetPeers": (C.c_int, [_CTX, I32P]),
     "scTickCommDestroy": (C.c_int, [_CTX]),
     "scTickSetPipelined": (C.c_int, [_CTX, C.c_int]),
+    "scTickGetCommInfo": (C.c_int, [_CTX, C.POINTER(CommInfo)]),
+    "scTickResetHostTimes": (C.c_int, [_CTX]),
     "scTickTileStep": (C.c_int, [_CTX, C.c_uint32]),
     "scTickExchangeBorders": (C.c_int, [_CTX]),
     "scTickUploadMovers": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, U8P, F32P, F32P, F32P]),

@@ -136,6 +136,7 @@ struct ScTickContext
   int32_t peer[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };
   bool peersSet = false;
   uint32_t* ownBorder[kMaxParity][8][2] = {};   // [parity][direction][send, recv]
+  double hostAcc[2] = { 0.0, 0.0 }; uint64_t hostSteps = 0;     // scTickTileStep: host time issuing the tick half / the exchange + pair half
   hipStream_t ownPairsStream = nullptr;
 };
 
@@ -1253,9 +1254,13 @@ static int runPendingPairs(ScTickContext* c, bool withExchange)
       HIP_OK(c, hipGraphLaunch(c->pairGraphExec[q], ps));
       HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
     } else {
+      // a sampled tick times its pair chain too (exchange + merge + queries + pair search, on the pairs stream): SC_TICK_K_PAIRS
+      EventPair ev; const bool timed = c->profiling && c->lastTickSampled;
+      if (timed) { ev = takeEvents(c); hipEventRecord(ev.a, ps); }
       if (withExchange && !exchangeBorders(c, q, ps, false)) return 0;
       const bool rides = enqueuePairHalf(c, pp, ps, (c->variant & 4u) ? nullptr : c->pairsDone[q]);
       if (!rides || (c->variant & 4u)) HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
+      if (timed) { hipEventRecord(ev.b, ps); c->times[SC_TICK_K_PAIRS].push_back(ev); }
     }
     c->pairsInFlight[q] = true;
   } else {
@@ -2126,6 +2131,34 @@ int scTickCommInit(ScTickContext* c, const uint8_t id[SC_TICK_COMM_ID_BYTES], ui
   return sync(c) ? 1 : 0;
 }
 
+int scTickGetCommInfo(ScTickContext* c, ScTickCommInfo* out)
+{
+  if (!c || !out) return c ? fail(c, "null argument") : 0;
+  std::memset(out, 0, sizeof *out);
+  out->world_size = c->commSize; out->rank = c->commRank; out->has_communicator = c->comm ? 1u : 0u;
+  out->neighbour_mask = c->neighbourMask;
+  out->pipeline_depth = c->pairsStream ? c->pipeDepth : 0u;
+  out->border_records_per_sector = c->borderRecs;
+  for (uint32_t d = 0; d < 8; ++d) {
+    out->peer_rank[d] = ((c->neighbourMask >> d) & 1u) ? c->peer[d] : -1;
+    if (!((c->neighbourMask >> d) & 1u) || !c->sectors) continue;
+    out->operations_per_group += 2u;                                   // one ncclSend + one ncclRecv per neighbour
+    out->bytes_sent_per_step += (uint64_t)borderWords(d, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs) * 4u;
+  }
+  if (c->comm) { std::string why; if (const RcclApi* r = rccl(&why)) { int v = 0; if (r->GetVersion(&v) == ncclSuccess) out->rccl_version = (uint32_t)v; } }
+  out->host_steps = c->hostSteps;
+  out->host_tick_half_us = c->hostSteps ? c->hostAcc[0] / (double)c->hostSteps : 0.0;
+  out->host_pair_half_us = c->hostSteps ? c->hostAcc[1] / (double)c->hostSteps : 0.0;
+  return 1;
+}
+
+int scTickResetHostTimes(ScTickContext* c)
+{
+  if (!c) return 0;
+  c->hostAcc[0] = c->hostAcc[1] = 0.0; c->hostSteps = 0;
+  return 1;
+}
+
 int scTickSetPipelined(ScTickContext* c, int enable)
 {
   if (!c) return 0;
@@ -2200,29 +2233,26 @@ int scTickTileStep(ScTickContext* c, uint32_t flags)
     return runPendingPairs(c, false);
   }
   if (!c->comm) return fail(c, "no communicator: scTickCommInit first (a tile with neighbours cannot skip the exchange)");
-  static const bool prof = std::getenv("SC_TICK_HOSTPROF") != nullptr;
-  static double acc[2] = { 0, 0 }; static uint64_t calls = 0;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   if (c->graphMode && !c->pairsStream) {
     // in-order tile, graph replay: the whole step -- producer, fused kernel, compaction + pack, the RCCL group, merge, pair
     // search -- is captured once per tick parity and replayed with one hipGraphLaunch
+    const double g0 = now();
     c->captureWholeStep = true;
     const int okr = scTickRun(c, flags | SC_TICK_SPLIT_PAIRS);
     c->captureWholeStep = false;
     if (!okr) return 0;
-    if (c->pairsPending) return runPendingPairs(c, true);          // a sampled (profiled) tick ran eagerly: finish it the eager way
-    return 1;
+    const int okp = c->pairsPending ? runPendingPairs(c, true) : 1;     // a sampled (profiled) tick ran eagerly: finish it the eager way
+    c->hostAcc[0] += now() - g0; c->hostSteps++;
+    return okp;
   }
   // eager, or a pipelined tile: the tick on its stream, then exchange + pair half on theirs (with graph replay on, each
   // half of a pipelined step is one hipGraphLaunch; the events that order them are recorded between the two)
-  const double t0 = prof ? now() : 0.0;
+  const double t0 = now();
   if (!scTickRun(c, flags | SC_TICK_SPLIT_PAIRS)) return 0;
-  const double t1 = prof ? now() : 0.0;
+  const double t1 = now();
   const int ok = runPendingPairs(c, true);
-  if (prof) {
-    acc[0] += t1 - t0; acc[1] += now() - t1;
-    if (++calls % 200 == 0) { std::fprintf(stderr, "[sc_tick hostprof] per step over 200: tick half %.1f us, exchange + pair half %.1f us\n", acc[0] / 200, acc[1] / 200); acc[0] = acc[1] = 0; }
-  }
+  c->hostAcc[0] += t1 - t0; c->hostAcc[1] += now() - t1; c->hostSteps++;
   return ok;
 }
 

@@ -361,7 +361,11 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
     if (storeM) storeRows(d, i, M);
     base = __shfl(base, myHead, 64);
 #elif SC_BINV == 3
-    if (head) { base = atomicAdd(&d.binCount[sector], runEnd - lane); atomicOr(&d.binLayers[sector], lay); }
+#if SC_ABL & 128
+    if (head && !(SC_ABL & 32)) atomicOr(&d.binLayers[sector], lay);
+#else
+    if (head) { base = atomicAdd(&d.binCount[sector], runEnd - lane); if (!(SC_ABL & 32)) atomicOr(&d.binLayers[sector], lay); }
+#endif
     if (storeM) storeRows(d, i, M);
     base = __shfl(base, myHead, 64);
 #endif
@@ -376,9 +380,13 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
     if (c3) { q3 = atomicAdd(&d.binCount[sec3], 1u); atomicOr(&d.binLayers[sec3], myLay); if (q3 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec3 * kBinCap + q3); r[0] = rmin; r[1] = rmax; } }
 #else
 #if SC_BINV == 3
+#if SC_ABL & 256
+    q1 = 17u; q2 = 18u; q3 = 19u;                          // (timing only: no reservation, fixed slots)
+#else
     if (c1) q1 = atomicAdd(&d.binCount[sec1], 1u);
     if (c2) q2 = atomicAdd(&d.binCount[sec2], 1u);
     if (c3) q3 = atomicAdd(&d.binCount[sec3], 1u);
+#endif
 #endif
     if (c1 && q1 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec1 * kBinCap + q1); r[0] = rmin; r[1] = rmax; }
     if (c2 && q2 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec2 * kBinCap + q2); r[0] = rmin; r[1] = rmax; }
@@ -386,7 +394,7 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
 #if SC_BINV == 1
     if (head) atomicOr(&d.binLayers[sector], lay);
 #endif
-#if SC_BINV == 1 || SC_BINV == 3
+#if (SC_BINV == 1 || SC_BINV == 3) && !(SC_ABL & 32)
     if (c1) atomicOr(&d.binLayers[sec1], myLay);
     if (c2) atomicOr(&d.binLayers[sec2], myLay);
     if (c3) atomicOr(&d.binLayers[sec3], myLay);

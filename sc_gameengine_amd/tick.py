@@ -394,6 +394,15 @@ class WorldTick:
         """False / 0 = off, True / 1 = on (default depth 4), 2..4 = on with that many copies of the per-tick broadphase state"""
         self._ok(self.lib.scTickSetPipelined(self.ctx, int(on)), "scTickSetPipelined")
 
+    def comm_info(self):
+        """the exchange as the library sees it (communicator, peers, operations per group, host time per half of a step) as a dict"""
+        ci = capi.CommInfo()
+        self._ok(self.lib.scTickGetCommInfo(self.ctx, C.byref(ci)), "scTickGetCommInfo")
+        return {k: (list(getattr(ci, k)) if k == "peer_rank" else getattr(ci, k)) for k, _ in capi.CommInfo._fields_}
+
+    def reset_host_times(self):
+        self._ok(self.lib.scTickResetHostTimes(self.ctx), "scTickResetHostTimes")
+
     def tile_step(self, flags):
         """One whole step of a tile: tick + pack, RCCL exchange, merge + pair search -- one call, nothing waits on the host."""
         self._ok(self.lib.scTickTileStep(self.ctx, flags), "scTickTileStep")
