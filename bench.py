@@ -209,6 +209,64 @@ class OracleLeg:
         self.ow.close()
 
 
+def tile_pair_gate(args, rank, grid, producer_steps, got_pairs, got_total, mutate=None):
+    """The pair gate of ONE rank of a tiled world.  SynthWorld is deterministic per sector, so a rank
+    can rebuild, on its own, its tile PLUS the one-sector ring of its neighbours' sectors around it (clipped to the world),
+    bring that world to the frame the GPU ticked last with the oracle, run the oracle's grid search on the oracle's boxes,
+    and keep the pairs this rank has to report: those whose intersection's low corner lies in a sector it owns (the rule
+    the tiles use).  Ids are rank << 24 | dense index on both sides.  `got_pairs`: what the GPU listed.
+    mutate (tests only): applied to the rebuilt world before anything else -- a deterministic edit keyed on sector coordinates."""
+    from oracle import oracle_py as oracle
+    from sc_gameengine_amd import synth_world as sw
+    oracle.build()
+    tx, tz = grid
+    S = args.sectors
+    SX, SZ = (S // 2, S) if args.workload == "config5" else (S, S)
+    ox, oz = (rank % tx) * SX, (rank // tx) * SZ
+    x0, x1 = max(ox - 1, 0), min(ox + SX + 1, tx * SX)
+    z0, z1 = max(oz - 1, 0), min(oz + SZ + 1, tz * SZ)
+    ex, ez = x1 - x0, z1 - z0
+    if args.workload == "config5":
+        w = sw.generate_config5(ex, ez, origin=(x0, z0))
+    else:
+        w = sw.generate(ex, ez, PROPS, hierarchy=True, origin=(x0, z0))
+        if args.workload == "config3dyn":
+            per16 = (np.arange(w.n) % 16) == 4
+            w.group[per16], w.mask[per16] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    if mutate is not None:
+        mutate(w)
+    per = w.n // (ex * ez)
+    ow = oracle.OracleWorld.from_arrays(w.pos, w.rot, w.scale, w.parent, w.bmin, w.bmax, has_mesh=w.has_mesh, has_bounds=w.has_bounds)
+    vel = None if w.mover_kind is None else w.mover_vel.copy()
+    for _ in range(producer_steps):
+        if vel is None:
+            ow.nudge_roots_x(0.01)
+        else:
+            ow.advance_movers(w.mover_kind, vel, w.mover_lo, w.mover_hi, 1.0 / 60.0)
+    ow.transform_system()
+    mn, mx = ow.world_aabbs()
+    mn, mx = mn[:w.n], mx[:w.n]
+    want = oracle.broadphase_grid(mn, mx, w.group, w.mask, 64.0)
+    ow.close()
+    # who reports a pair: the tile that owns the sector holding the low corner of the two boxes' intersection
+    inv = np.float32(1.0) / np.float32(64.0)
+    lx = np.maximum(mn[want[:, 0], 0], mn[want[:, 1], 0]); lz = np.maximum(mn[want[:, 0], 2], mn[want[:, 1], 2])
+    sx = np.clip(np.floor(lx * inv).astype(np.int64), 0, tx * SX - 1); sz = np.clip(np.floor(lz * inv).astype(np.int64), 0, tz * SZ - 1)
+    mine = ((sz // SZ) * tx + (sx // SX)) == rank
+    # extended-world index -> rank << 24 | dense index inside that rank's tile (sectors row-major inside a tile, `per` entities each)
+    e = np.arange(w.n, dtype=np.int64)
+    gx, gz = w.sector_of[:, 0].astype(np.int64), w.sector_of[:, 1].astype(np.int64)
+    owner = (gz // SZ) * tx + (gx // SX)
+    dense = ((gz % SZ) * SX + (gx % SX)) * per + (e % per)
+    gid = (owner << 24) | dense
+    a, b = gid[want[mine, 0]], gid[want[mine, 1]]
+    wkey = np.sort(np.minimum(a, b).astype(np.uint64) << np.uint64(32) | np.maximum(a, b).astype(np.uint64))
+    gkey = np.sort(got_pairs[:, 0].astype(np.uint64) << np.uint64(32) | got_pairs[:, 1].astype(np.uint64))
+    crossing = int(((owner[want[mine, 0]] != rank) | (owner[want[mine, 1]] != rank)).sum())
+    return {"pairs_equal": bool(got_total == len(wkey) and np.array_equal(gkey, wkey)), "pairs": int(len(wkey)),
+            "pairs_with_a_neighbours_box": crossing, "ring_world_entities": int(w.n)}
+
+
 def end_of_tick_line(w, workload, SX, SZ, counts, kp_ms, stages, kind):
     """achieved rate of the end-of-tick kernel from its algorithmic bytes (end_of_tick_bytes) and its dispatch timestamps"""
     roots = int((w.parent < 0).sum())
@@ -467,6 +525,7 @@ def main():
                       "what": "tick + k_emit_draws (budget 6000) + staging kernel + one pinned D2H per frame on a copy stream; the host takes frame t-1 while tick t runs"}
         t.set_frame_readback(0, 0)
 
+    own_elapsed = elapsed
     if world_size > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=ctl_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -479,7 +538,14 @@ def main():
         leg = OracleLeg(w)
         parity = leg.parity(t, ticks_done[0], [s for s in stages if not (s == "broadphase" and world_size > 1)], view_proj)
         if world_size > 1:
-            parity["note"] = "per tile: visible list and matrices of every rank's own tile; cross-tile pairs are covered by tests/test_gpu_tiles*.py"
+            parity["note"] = ("per rank: visible list and matrices of the rank's own tile; pair set of the rank against the oracle on its tile plus the "
+                              "one-sector ring of its neighbours' sectors (pairs whose low corner lies in a sector the rank owns)")
+            if "broadphase" in stages:
+                got, total = t.pairs()
+                gate = tile_pair_gate(args, rank, grid, ticks_done[0], got, total)
+                parity.update(gate)
+                parity["border_lost"] = int(t.counts().border_lost)
+                parity["ok"] = bool(parity["ok"] and gate["pairs_equal"] and parity["border_lost"] == 0)
             ok = torch.tensor([1 if parity["ok"] else 0], dtype=torch.int32, device=ctl_device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             parity["all_ranks_ok"] = bool(int(ok.item()))
@@ -489,6 +555,20 @@ def main():
             if world_size > 1:
                 dist.destroy_process_group()
             sys.exit(3)
+
+    # ---- per-rank diagnostics (N > 1): what the first scaling curve will have to be read with ----
+    per_rank = None
+    if world_size > 1:
+        ci = t.comm_info() if borders is None else {}
+        mine = {"rank": rank, "border_lost": int(counts.border_lost), "pairs": int(counts.pairs), "visible": int(counts.visible),
+                "ms_per_step_own_clock": own_elapsed / args.steps * 1e3,
+                "tick_chain_us": {"k_xform_cull": float(np.mean(k1)) * 1e3 if len(k1) else None,
+                                  "compaction_and_pack": float(np.mean(k2)) * 1e3 if len(k2) else None},
+                "pair_chain_us": float(np.mean(kp)) * 1e3 if len(kp) else None,
+                "comm": ci}
+        box = [None] * world_size
+        dist.all_gather_object(box, mine)
+        per_rank = box
 
     if rank == 0:
         n_total = w.n * world_size
@@ -535,6 +615,7 @@ def main():
                 "rehearsal_same_device": bool(args.same_device),
             },
             "parity_in_run": parity,
+            "per_rank": per_rank,
             "end_to_end": end_to_end,
             "roofline": {
                 "bound": "hbm", "kernel": "k_xform_cull",

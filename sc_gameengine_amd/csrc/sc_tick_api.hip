@@ -93,6 +93,10 @@ struct ScTickContext
   bool pairGraphExchange[kMaxParity] = {};
   uint64_t pairGraphEpoch[kMaxParity] = { ~0ull, ~0ull, ~0ull, ~0ull };
   bool lastTickSampled = false;                        // the last scTickRun recorded profiling events (ran eagerly)
+  bool lastTickLearn = false;                          // the last scTickRun was a learn tick of the home slots (ran eagerly)
+  // home slots of the bins (binEntityWave): remembered at a learn tick, used until the world's shape changes or they age
+  bool homeEnabled = true, homeValid = false, homeCountsLive = false;
+  uint64_t homeEpoch = ~0ull; uint32_t homeAge = 0, homePeriod = 64;
   bool capturing = false;                              // enqueueStages runs inside a stream capture
   bool packedRides = false;                            // this tick's `packed` event was attached to the compaction + pack dispatch
 
@@ -489,6 +493,18 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
       launchXformCull(ds, p, grid, c->stream, ev.a, ev.b);
       c->times[SC_TICK_K_XFORM_CULL].push_back(ev);
     } else launchXformCull(ds, p, grid, c->stream);
+    if (p.homeMode == kHomeLearn) {
+      // the slots handed out by the fused kernel are the remembered ones (the level kernels' and the neighbours' records reserve
+      // behind them on every tick); the other copies of the bins start their next tick from the same counts
+      launchSnapshotHome(ds, c->sectors, c->stream);
+      if (c->pairsStream)
+        for (uint32_t q = 0; q < c->pipeDepth; ++q) {
+          if (q == p.parity) continue;
+          const DeviceState o = stateFor(c, q);
+          hipMemcpyAsync(o.binCount, ds.homeCount, (size_t)c->sectors * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream);
+          hipMemcpyAsync(o.binLayers, ds.homeLayers, (size_t)c->sectors * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream);
+        }
+    }
   }
   if (flags & kFlagHasDeep) {
     for (size_t lv = 0; lv + 1 < c->levelOffsets.size(); ++lv) {
@@ -654,8 +670,12 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
             && dalloc(c, d.bigList, (N + 8u * kBorderBigCap) * 2u, false) && dalloc(c, d.spill, 2u * (size_t)ovfRecords(c), false) && dalloc(c, d.spillSector, ovfRecords(c))
             && dalloc(c, d.ovfIdx, (size_t)kOvfWaves * kOvfPerSector, false) && dalloc(c, d.ovfLo, c->sectors, false) && dalloc(c, d.ovfHi, c->sectors)
             && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, (kMaxParity + 1u) * kPairShards * kShardStride)
-            && dalloc(c, c->dPairsOut, c->maxPairs, false) && dalloc(c, c->dPairTotal, 4);
+            && dalloc(c, c->dPairsOut, c->maxPairs, false) && dalloc(c, c->dPairTotal, 4)
+            && dalloc(c, d.homeA, N, false) && dalloc(c, d.homeB, N, false) && dalloc(c, d.homeCount, c->sectors) && dalloc(c, d.homeLayers, c->sectors);
+    if (ok) { e = hipMemset(d.homeA, 0xFF, N * sizeof(uint32_t)); if (e == hipSuccess) e = hipMemset(d.homeB, 0xFF, N * sizeof(uint32_t)); if (e != hipSuccess) ok = fail(c, "hipMemset", e); }
   }
+  if (c->variant & 2u) c->homeEnabled = false;          // SC_TICK_VARIANT bit 1: every record reserves its slot on every tick (A/B)
+  if (const char* hp = std::getenv("SC_TICK_HOME_PERIOD")) { const int v = std::atoi(hp); if (v > 0) c->homePeriod = (uint32_t)v; }
   if (ok && c->sectors) { e = hipMemset(d.ovfLo, 0xFF, (size_t)c->sectors * sizeof(uint32_t)); if (e != hipSuccess) ok = fail(c, "hipMemset", e); }
   if (ok) { void* p = nullptr; e = hipMalloc(&p, N * sizeof(ScTickDrawItem)); if (e != hipSuccess) ok = fail(c, "hipMalloc draws", e); else { c->allocs.push_back(p); c->dDraws = p; } }
   if (ok) {
@@ -794,6 +814,7 @@ int scTickUploadLayers(ScTickContext* c, uint32_t first, uint32_t count, const u
     packed[i] = (g & 0xFFFFu) | ((m & 0xFFFFu) << 16);
   }
   if (!h2d(c, c->d.layers + first, packed.data(), (size_t)count * 4u)) return 0;
+  c->homeValid = false;                 // the bins' remembered layer summaries are behind
   return sync(c) ? 1 : 0;
 }
 
@@ -1177,6 +1198,25 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   TickParams p; uint32_t grid;
   fillParams(c, flags, p, grid);
   c->lastFlags = flags;
+  c->lastTickLearn = false;
+  if ((flags & SC_TICK_BROADPHASE) && c->homeEnabled) {
+    // home slots: a learn tick when nothing is remembered, the world's shape changed (entities, hierarchy, layers) or the
+    // slots have aged; every bin copy must be idle and empty for it (a rare event: the streams are joined here)
+    if (!c->homeValid || c->homeEpoch != c->topoEpoch || c->homeAge >= c->homePeriod) {
+      if (c->pairsStream && !sync(c)) return 0;
+      if (c->homeCountsLive) {
+        for (uint32_t q = 0; q < (c->pairsStream ? c->pipeDepth : 1u); ++q) {
+          const DeviceState o = stateFor(c, q);
+          HIP_OK(c, hipMemsetAsync(o.binCount, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream));
+          HIP_OK(c, hipMemsetAsync(o.binLayers, 0, (size_t)c->sectors * sizeof(uint32_t), c->stream));
+        }
+      }
+      p.homeMode = kHomeLearn;
+      c->homeValid = true; c->homeEpoch = c->topoEpoch; c->homeAge = 0; c->lastTickLearn = true;
+    } else { p.homeMode = kHomeUse; c->homeAge++; }
+    p.homeReset = 1u;
+    c->homeCountsLive = true;
+  }
   if ((flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_SPLIT_PAIRS) && c->neighbourMask) {
     // every message of THIS tick parity needs its buffers: a missing one would make the pack skip that neighbour silently
     const DeviceState ds = stateFor(c, c->parity);
@@ -1190,7 +1230,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   const bool sampledTick = c->profiling && (c->tickIndex % c->profPeriod) == 0;     // events need eager launches
   c->lastTickSampled = sampledTick;
   waitParityFree(c, p);
-  if (c->graphMode && !sampledTick) {
+  if (c->graphMode && !sampledTick && !c->lastTickLearn) {
     const bool stale = !c->graphExec[q] || c->graphEpoch[q] != c->topoEpoch || std::memcmp(&p, &c->graphParams[q], sizeof p) != 0 || c->graphWhole[q] != c->captureWholeStep;
     if (stale) {
       dropGraph(c, (int)q);
@@ -1217,7 +1257,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   }
   publishPacked(c, p);
   if (flags & SC_TICK_BROADPHASE) {
-    const bool pairHalfDone = c->graphMode && !sampledTick && c->captureWholeStep;
+    const bool pairHalfDone = c->graphMode && !sampledTick && !c->lastTickLearn && c->captureWholeStep;
     if ((flags & SC_TICK_SPLIT_PAIRS) && !pairHalfDone) { c->pairsPending = true; c->pendingParams = p; }
     else { c->lastParity = c->parity; c->parity ^= 1u; }           // (in-order flows alternate between two copies)
   }
@@ -1236,7 +1276,7 @@ static int runPendingPairs(ScTickContext* c, bool withExchange)
   hipStream_t ps = c->pairsStream ? c->pairsStream : c->stream;
   if (c->pairsStream) {
     const TickParams& pp = c->pendingParams;
-    if (c->graphMode && !c->lastTickSampled) {
+    if (c->graphMode && !c->lastTickSampled && !c->lastTickLearn) {
       const bool stale = !c->pairGraphExec[q] || c->pairGraphEpoch[q] != c->topoEpoch || c->pairGraphExchange[q] != withExchange ||
                          std::memcmp(&pp, &c->pairGraphParams[q], sizeof pp) != 0;
       if (stale) {
@@ -1396,6 +1436,7 @@ int scTickSetPairsStream(ScTickContext* c, void* stream)
     }
     if (e != hipSuccess) return fail(c, "hipMemsetAsync (broadphase state)", e);
     c->parity = 0; c->lastParity = 0;
+    c->homeValid = false; c->homeCountsLive = false;      // every bin copy is empty again: the next tick learns its slots afresh
     return sync(c);
   };
   if (!stream) {

@@ -98,6 +98,13 @@ struct DeviceState {
   uint32_t* binCount;          // records per sector bin (self-cleaning: the pair kernel zeroes what it read)
   uint32_t* binLayers;         // OR of the records' (group | mask << 16) per bin: lets the pair kernel skip a bin unread
   float4* bins;                // [sector][kBinCap][2]: (min.xyz, layers) (max.xyz, id | primary<<31)
+  // Home slots (round 3): where an entity's records went the last time the bins were filled with reservations ("learn" tick).
+  // While the entity's box keeps its primary sector, its records go straight to those slots -- no reservation, i.e. no atomic,
+  // which on this chip executes at the memory side (11 of the fused kernel's 39 us were its atomics).  Shared by every parity copy.
+  uint32_t* homeA;             // [cap] primary sector of the entity's records at the learn tick (0xFFFFFFFF: none)
+  uint32_t* homeB;             // [cap] four 8-bit slots: the copies in sectors homeA + {0, 1, binSX, binSX + 1}; 0xFF = no reservation
+  uint32_t* homeCount;         // [sectors] slots of each bin that are reserved: what binCount starts a tick from
+  uint32_t* homeLayers;        // [sectors] OR of the reserved records' layer words: what binLayers starts a tick from
   float4* bigList;             // [cap][2] boxes that cannot be binned (too large, outside the rect, bin full)
   float4* spill;               // [ovfCap][2] sector OVERFLOW list: records that found their sector bin full -- this tile's own
                                // (fused kernel) and the neighbours' border records (merge) alike ...
@@ -142,6 +149,8 @@ constexpr uint32_t kPairShards = 64, kShardStride = 32, kWavePairBuf = 256;
 constexpr uint32_t kPrimary = 0x80000000u;
 // counters[]: 0 visible, 1 culled, 4 draws, 5 dropped, 6 renderables; per tick parity q: 8+8q+{0 pairs, 1 big, 2 bin-full}
 constexpr uint32_t kCtrPar = 8, kCtrPairs = 0, kCtrBig = 1, kCtrBinFull = 2, kCtrBorderLost = 3, kCtrBigLocal = 4, kCtrSpill = 5;
+constexpr uint32_t kHomeOff = 0, kHomeLearn = 1, kHomeUse = 2;
+constexpr uint32_t kNoHome = 0xFFFFFFFFu, kNoSlot = 0xFFu;
 // Tick "parity": which copy of the per-tick broadphase state a tick works on.  The in-order flows alternate between two
 // copies; pipelined tiles rotate through `depth` (2..kMaxParity) copies, so that the pair half of tick t may still run while
 // the fused kernels of ticks t+1 .. t+depth-1 refill the others.
@@ -172,6 +181,9 @@ struct TickParams {
   uint32_t bigCap;          // entries the big list can hold (capacity + room for the neighbours' boxes): every index into it is held below this
   uint32_t ovfCap;          // entries the sector overflow list can hold
   uint32_t pairRunLog2;     // pair role: a wave takes its sectors in runs of 2^pairRunLog2 consecutive ones (pairRunLog2())
+  uint32_t homeMode;        // bins: 0 every record reserves its slot (atomics), 1 the same and the slots are remembered (learn tick),
+                            // 2 records with a remembered slot are stored there directly (kHome*)
+  uint32_t homeReset;       // the pair search leaves binCount / binLayers at homeCount / homeLayers instead of zero
   uint32_t borderRecs;      // border messages: records per ring sector of a side, on average (scTickSetBorderCapacity; kBorderRecsPerBin)
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d
@@ -220,6 +232,7 @@ void launchOccupancy(const DeviceState& d, uint32_t n, const float4* q, uint32_t
 
 // launchers (sc_tick_kernels.hip)
 void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA = nullptr, hipEvent_t evB = nullptr);
+void launchSnapshotHome(const DeviceState& d, uint32_t sectors, hipStream_t s);
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 bool launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s, hipEvent_t done = nullptr);

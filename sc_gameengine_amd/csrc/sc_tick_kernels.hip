@@ -17,9 +17,6 @@ constexpr bool kNoDefer = true;       // A/B: world-matrix stores in place (roun
 #else
 constexpr bool kNoDefer = false;
 #endif
-#ifndef SC_BINV
-#define SC_BINV 3         // order of the bin reservations / stores inside binEntityWave (A/B)
-#endif
 #ifndef SC_ABL
 #define SC_ABL 0          // timing ablations of the fused kernel (tools only: results are wrong with any bit set)
 #endif
@@ -265,6 +262,13 @@ __device__ __forceinline__ void binInsertLane(const DeviceState& d, const TickPa
   }
 }
 
+// a record that overlaps nothing and passes no filter: a remembered bin slot whose copy does not exist this tick; padding of a border message
+__device__ __forceinline__ void nullRecord(float4& lo, float4& hi)
+{
+  lo = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0u));
+  hi = make_float4(-INFINITY, -INFINITY, -INFINITY, __uint_as_float(0x00FFFFFFu));
+}
+
 // Whole-wave broadphase step for one entity per lane: world AABB -> bins / big list.
 //
 // Round 3: ONE reservation round trip per tile.  Ablations of the round-2 form (profiles/r03/ab_ablation_binning.log) showed
@@ -288,12 +292,29 @@ __device__ __forceinline__ void spillLane(const DeviceState& d, const TickParams
 // storeM: the lane's freshly built world matrix is stored HERE, behind the reservations (they do not depend on it): the wait
 // for the reservations then does not include the stores' way to memory (vmcnt retires in order), and the bounds loads in
 // front of this call are not held behind the stores either.
+//
+// HOME SLOTS (round 3).  A reservation is a returning atomic, and a global atomic executes at the memory side of this chip
+// (MI355X_MICROARCH.md, Global atomics): ~1 us under load, a read-modify-write of a 64-byte line per lane.  With every
+// reservation switched off -- records stored at made-up slots -- the fused kernel ran 28 instead of 39 us
+// (profiles/r03/ab_noatomics.log).  Boxes rarely change sector from one tick to the next, so the slots are REMEMBERED: on a
+// learn tick (TickParams::homeMode 1; the first tick, then now and then) every record reserves its slot as before and the lane
+// notes, per entity, its primary sector and the slots of its up to four copies (homeA / homeB); a small kernel then notes how
+// many slots of each bin were handed out (homeCount) and the layer summary they gave (homeLayers), and the pair search leaves
+// the bins' counters at those values instead of zero.  On the ticks in between (homeMode 2) a record whose sector is still
+// the one its slot was reserved in is stored straight there -- no atomic, no wait; a copy that no longer exists (the box left
+// the sector, shrank, lost its bounds) stores a NULL record in its slot, so that every reserved slot is written by its owner
+// on every tick and no parity copy of the bins ever shows a stale record; a copy without a reservation (the box entered a
+// new sector, a bin was full at the learn tick, level kernels, border records) reserves behind the remembered slots as before.
+// Same records in the same bins -- the pair search sees a few null records more, which pass no filter and overlap nothing.
 __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickParams& p, uint32_t i, bool collider,
                                               const Aff& M, const BoundsCE& b, bool storeM)
 {
   float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
   BinPlan plan; plan.collide = false; plan.big = false; plan.x0 = plan.z0 = 0.0f; plan.nx = plan.nz = 0;
   float4 rmin = make_float4(0, 0, 0, 0), rmax = make_float4(0, 0, 0, 0);
+  const uint32_t mode = p.homeMode;
+  uint32_t hA = kNoHome, hB = 0xFFFFFFFFu;
+  if (mode == kHomeUse && i < p.n) { hA = d.homeA[i]; hB = d.homeB[i]; }
   if (collider) {
     worldAabb(M, b, mn, mx);
     plan = planBins(p, mn, mx);
@@ -303,64 +324,45 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
   const bool want = plan.collide && !plan.big;
   const uint32_t sector = (uint32_t)plan.z0 * p.binSX + (uint32_t)plan.x0;
   const uint32_t lane = threadIdx.x & 63u;
-  const unsigned long long act = ballot64(want);
+  // ---- the copies: 0 = the primary (every box has exactly one), 1..3 = the sectors next to it that the box reaches into
+  const bool c1 = want && plan.nx > 1u, c2 = want && plan.nz > 1u, c3 = c1 && c2;
+  const uint32_t sec1 = sector + 1u, sec2 = sector + p.binSX, sec3 = sec2 + 1u;
+  // remembered slots count while the box's primary sector is the one they were reserved from
+  const bool atHome = want && hA == sector;
+  const uint32_t h0 = atHome ? (hB & 0xFFu) : kNoSlot, h1 = atHome ? ((hB >> 8) & 0xFFu) : kNoSlot,
+                 h2 = atHome ? ((hB >> 16) & 0xFFu) : kNoSlot, h3 = atHome ? (hB >> 24) : kNoSlot;
+  const bool a0 = want && h0 == kNoSlot, a1 = c1 && h1 == kNoSlot, a2 = c2 && h2 == kNoSlot, a3 = c3 && h3 == kNoSlot;   // copies that reserve
+  uint32_t slot = h0, q1 = h1, q2 = h2, q3 = h3;
+  float4 rm = rmax;
+  rm.w = __uint_as_float(i | p.rankBits | kPrimary);
+  const uint32_t myLay = __float_as_uint(rmin.w);
+
+  const unsigned long long act = ballot64(a0);
+  uint32_t myHead = lane, runEnd = lane + 1u;
   if (act) {
-    // ---- the primary copies (every box has exactly one): consecutive lanes that target the same sector form a run, whose
-    // first lane reserves the slots of the whole run
-    const uint32_t key = want ? sector : 0xFFFFFFFFu;
+    // ---- primary copies that reserve: consecutive lanes that target the same sector form a run, whose first lane reserves
+    // the slots of the whole run
+    const uint32_t key = a0 ? sector : 0xFFFFFFFFu;
     const uint32_t prev = __shfl_up(key, 1, 64);
-    const bool head = want && (lane == 0 || prev != key);
+    const bool head = a0 && (lane == 0 || prev != key);
     const unsigned long long heads = ballot64(head);
     const unsigned long long upto = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
-    const uint32_t myHead = (63u - (uint32_t)__clzll(heads & upto)) & 63u;
+    myHead = (63u - (uint32_t)__clzll(heads & upto)) & 63u;
     const unsigned long long above = (myHead == 63u) ? 0ull : ~((2ull << myHead) - 1ull);
     const unsigned long long ends = (heads | ~act) & above;
-    const uint32_t runEnd = ends ? (uint32_t)__ffsll((long long)ends) - 1u : 64u;
+    runEnd = ends ? (uint32_t)__ffsll((long long)ends) - 1u : 64u;
     // OR of the run's collision layers for the head lane.  Runs are almost always uniform (one layer
     // word): one cross-lane read decides; only a wave with a mixed run pays the segmented OR.
-    const uint32_t myLay = want ? __float_as_uint(rmin.w) : 0u;
-    uint32_t lay = myLay;
+    uint32_t lay = a0 ? myLay : 0u;
     const uint32_t headLay = (uint32_t)__shfl((int)lay, (int)myHead, 64);
-    if (ballot64(want && headLay != lay)) {
+    if (ballot64(a0 && headLay != lay)) {
 #pragma unroll
       for (uint32_t o = 1; o < 64u; o <<= 1) {
         const uint32_t other = (uint32_t)__shfl_down((int)lay, o, 64);
-        if (want && lane + o < runEnd) lay |= other;
+        if (a0 && lane + o < runEnd) lay |= other;
       }
     }
-    // ---- the copies in the neighbouring sectors of a box that straddles a sector edge (a few lanes per wave; every ground
-    // slab): the lanes concerned reserve their slots themselves
-    const bool c1 = want && plan.nx > 1u, c2 = want && plan.nz > 1u, c3 = c1 && c2;
-    const uint32_t sec1 = sector + 1u, sec2 = sector + p.binSX, sec3 = sec2 + 1u;
-    uint32_t base = 0, q1 = 0, q2 = 0, q3 = 0;
-    float4 rm = rmax;
-    rm.w = __uint_as_float(i | p.rankBits | kPrimary);
-#if SC_BINV == 0
-    // ---- every reservation of the tile, back to back: one round trip
-    if (head) base = atomicAdd(&d.binCount[sector], runEnd - lane);
-    if (c1) q1 = atomicAdd(&d.binCount[sec1], 1u);
-    if (c2) q2 = atomicAdd(&d.binCount[sec2], 1u);
-    if (c3) q3 = atomicAdd(&d.binCount[sec3], 1u);
-    if (head) atomicOr(&d.binLayers[sector], lay);
-    if (c1) atomicOr(&d.binLayers[sec1], myLay);
-    if (c2) atomicOr(&d.binLayers[sec2], myLay);
-    if (c3) atomicOr(&d.binLayers[sec3], myLay);
-    if (storeM) storeRows(d, i, M);
-    base = __shfl(base, myHead, 64);
-#elif SC_BINV == 1
-    // reservations back to back, the layer summaries behind the record stores (off the wait)
-    if (head) base = atomicAdd(&d.binCount[sector], runEnd - lane);
-    if (c1) q1 = atomicAdd(&d.binCount[sec1], 1u);
-    if (c2) q2 = atomicAdd(&d.binCount[sec2], 1u);
-    if (c3) q3 = atomicAdd(&d.binCount[sec3], 1u);
-    if (storeM) storeRows(d, i, M);
-    base = __shfl(base, myHead, 64);
-#elif SC_BINV == 2
-    // round 2's order: primary reservation, its store; then each neighbour copy on its own
-    if (head) { base = atomicAdd(&d.binCount[sector], runEnd - lane); atomicOr(&d.binLayers[sector], lay); }
-    if (storeM) storeRows(d, i, M);
-    base = __shfl(base, myHead, 64);
-#elif SC_BINV == 3
+    uint32_t base = 0;
 #if SC_ABL & 128
     if (head && !(SC_ABL & 32)) atomicOr(&d.binLayers[sector], lay);
 #else
@@ -368,61 +370,69 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
 #endif
     if (storeM) storeRows(d, i, M);
     base = __shfl(base, myHead, 64);
-#endif
-    const uint32_t slot = base + (lane - myHead);
-    if (want && slot < kBinCap) {
-      float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
-      r[0] = rmin; r[1] = rm;
-    }
-#if SC_BINV == 2
-    if (c1) { q1 = atomicAdd(&d.binCount[sec1], 1u); atomicOr(&d.binLayers[sec1], myLay); if (q1 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec1 * kBinCap + q1); r[0] = rmin; r[1] = rmax; } }
-    if (c2) { q2 = atomicAdd(&d.binCount[sec2], 1u); atomicOr(&d.binLayers[sec2], myLay); if (q2 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec2 * kBinCap + q2); r[0] = rmin; r[1] = rmax; } }
-    if (c3) { q3 = atomicAdd(&d.binCount[sec3], 1u); atomicOr(&d.binLayers[sec3], myLay); if (q3 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec3 * kBinCap + q3); r[0] = rmin; r[1] = rmax; } }
-#else
-#if SC_BINV == 3
-#if SC_ABL & 256
-    q1 = 17u; q2 = 18u; q3 = 19u;                          // (timing only: no reservation, fixed slots)
-#else
-    if (c1) q1 = atomicAdd(&d.binCount[sec1], 1u);
-    if (c2) q2 = atomicAdd(&d.binCount[sec2], 1u);
-    if (c3) q3 = atomicAdd(&d.binCount[sec3], 1u);
-#endif
-#endif
-    if (c1 && q1 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec1 * kBinCap + q1); r[0] = rmin; r[1] = rmax; }
-    if (c2 && q2 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec2 * kBinCap + q2); r[0] = rmin; r[1] = rmax; }
-    if (c3 && q3 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec3 * kBinCap + q3); r[0] = rmin; r[1] = rmax; }
-#if SC_BINV == 1
-    if (head) atomicOr(&d.binLayers[sector], lay);
-#endif
-#if (SC_BINV == 1 || SC_BINV == 3) && !(SC_ABL & 32)
-    if (c1) atomicOr(&d.binLayers[sec1], myLay);
-    if (c2) atomicOr(&d.binLayers[sec2], myLay);
-    if (c3) atomicOr(&d.binLayers[sec3], myLay);
-#endif
-#endif
-    // bin full: the record joins the sector overflow list (primary copies: one reservation per wave)
-    const bool over = want && slot >= kBinCap;
-    const unsigned long long mo = ballot64(over);
-    if (mo) {
-      const uint32_t ctr = kCtrPar + 8u * p.parity;
-      const uint32_t first = (uint32_t)__ffsll((long long)mo) - 1u;
-      uint32_t at = 0;
-      if (lane == first) at = atomicAdd(&d.counters[ctr + kCtrSpill], (uint32_t)__popcll(mo));     // (every wave of the chip meets on this word: one atomic, not two)
-      at = __shfl(at, (int)first, 64) + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
-      if (over && at < p.ovfCap) {
-        d.spill[2u * (size_t)at] = rmin; d.spill[2u * (size_t)at + 1u] = rm; d.spillSector[at] = sector;
-        // the overflowing lanes of a run are its tail and their list indices ascend with the lane: the first one lowers the
-        // sector's slice bound, the last one raises it (two atomics per run, not per record)
-        if (slot == kBinCap || lane == myHead) atomicMin(&d.ovfLo[sector], at);
-        if (lane + 1u == runEnd) atomicMax(&d.ovfHi[sector], at + 1u);
-      } else if (over) atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);      // (cannot happen with the list sized by ovfRecords(): never silent anyway)
-    }
-    if (ballot64((c1 && q1 >= kBinCap) || (c2 && q2 >= kBinCap) || (c3 && q3 >= kBinCap))) {
-      if (c1 && q1 >= kBinCap) spillLane(d, p, sec1, rmin, rmax);
-      if (c2 && q2 >= kBinCap) spillLane(d, p, sec2, rmin, rmax);
-      if (c3 && q3 >= kBinCap) spillLane(d, p, sec3, rmin, rmax);
-    }
+    if (a0) slot = base + (lane - myHead);
   } else if (storeM) storeRows(d, i, M);
+  if (want && slot < kBinCap && !(SC_ABL & 64)) {
+    float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
+    r[0] = rmin; r[1] = rm;
+  }
+  // ---- the copies in the neighbouring sectors (a few lanes per wave; every ground slab): remembered slots are stored to
+  // directly, the rest reserve theirs -- the (up to three) reservations of a lane issued together, one wait
+#if SC_ABL & 256
+  if (a1) q1 = 17u; if (a2) q2 = 18u; if (a3) q3 = 19u;                          // (timing only: no reservation, fixed slots)
+#else
+  if (a1) q1 = atomicAdd(&d.binCount[sec1], 1u);
+  if (a2) q2 = atomicAdd(&d.binCount[sec2], 1u);
+  if (a3) q3 = atomicAdd(&d.binCount[sec3], 1u);
+#endif
+  if (c1 && q1 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec1 * kBinCap + q1); r[0] = rmin; r[1] = rmax; }
+  if (c2 && q2 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec2 * kBinCap + q2); r[0] = rmin; r[1] = rmax; }
+  if (c3 && q3 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec3 * kBinCap + q3); r[0] = rmin; r[1] = rmax; }
+#if !(SC_ABL & 32)
+  if (a1) atomicOr(&d.binLayers[sec1], myLay);
+  if (a2) atomicOr(&d.binLayers[sec2], myLay);
+  if (a3) atomicOr(&d.binLayers[sec3], myLay);
+#endif
+  // ---- remembered slots whose copy does not exist this tick: the owner writes a null record there
+  if (hA != kNoHome) {
+    const uint32_t g0 = hB & 0xFFu, g1 = (hB >> 8) & 0xFFu, g2 = (hB >> 16) & 0xFFu, g3 = hB >> 24;
+    const bool n0 = g0 != kNoSlot && !atHome, n1 = g1 != kNoSlot && !(atHome && c1), n2 = g2 != kNoSlot && !(atHome && c2), n3 = g3 != kNoSlot && !(atHome && c3);
+    if (n0 | n1 | n2 | n3) {
+      float4 lo, hi; nullRecord(lo, hi);
+      if (n0) { float4* r = d.bins + 2u * ((size_t)hA * kBinCap + g0); r[0] = lo; r[1] = hi; }
+      if (n1) { float4* r = d.bins + 2u * ((size_t)(hA + 1u) * kBinCap + g1); r[0] = lo; r[1] = hi; }
+      if (n2) { float4* r = d.bins + 2u * ((size_t)(hA + p.binSX) * kBinCap + g2); r[0] = lo; r[1] = hi; }
+      if (n3) { float4* r = d.bins + 2u * ((size_t)(hA + p.binSX + 1u) * kBinCap + g3); r[0] = lo; r[1] = hi; }
+    }
+  }
+  // ---- learn tick: remember where this entity's records went (reserved slots inside the bin only)
+  if (mode == kHomeLearn && i < p.n) {
+    d.homeA[i] = want ? sector : kNoHome;
+    d.homeB[i] = (want && slot < kBinCap ? slot : kNoSlot) | ((c1 && q1 < kBinCap ? q1 : kNoSlot) << 8) |
+                 ((c2 && q2 < kBinCap ? q2 : kNoSlot) << 16) | ((c3 && q3 < kBinCap ? q3 : kNoSlot) << 24);
+  }
+  // bin full: the record joins the sector overflow list (primary copies: one reservation per wave)
+  const bool over = a0 && slot >= kBinCap;
+  const unsigned long long mo = ballot64(over);
+  if (mo) {
+    const uint32_t ctr = kCtrPar + 8u * p.parity;
+    const uint32_t first = (uint32_t)__ffsll((long long)mo) - 1u;
+    uint32_t at = 0;
+    if (lane == first) at = atomicAdd(&d.counters[ctr + kCtrSpill], (uint32_t)__popcll(mo));     // (every wave of the chip meets on this word: one atomic, not two)
+    at = __shfl(at, (int)first, 64) + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
+    if (over && at < p.ovfCap) {
+      d.spill[2u * (size_t)at] = rmin; d.spill[2u * (size_t)at + 1u] = rm; d.spillSector[at] = sector;
+      // the overflowing lanes of a run are its tail and their list indices ascend with the lane: the first one lowers the
+      // sector's slice bound, the last one raises it (two atomics per run, not per record)
+      if (slot == kBinCap || lane == myHead) atomicMin(&d.ovfLo[sector], at);
+      if (lane + 1u == runEnd) atomicMax(&d.ovfHi[sector], at + 1u);
+    } else if (over) atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);      // (cannot happen with the list sized by ovfRecords(): never silent anyway)
+  }
+  if (ballot64((a1 && q1 >= kBinCap) || (a2 && q2 >= kBinCap) || (a3 && q3 >= kBinCap))) {
+    if (a1 && q1 >= kBinCap) spillLane(d, p, sec1, rmin, rmax);
+    if (a2 && q2 >= kBinCap) spillLane(d, p, sec2, rmin, rmax);
+    if (a3 && q3 >= kBinCap) spillLane(d, p, sec3, rmin, rmax);
+  }
   if (plan.collide && plan.big) appendBig(d, p, rmin, rmax);
 }
 
@@ -468,8 +478,16 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
 template <bool kCull, bool kAabb, uint32_t kChain>
 __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p);
 
+#ifndef SC_K1_WAVES
+#define SC_K1_WAVES 0
+#endif
+#if SC_K1_WAVES
+#define SC_K1_OCC __attribute__((amdgpu_waves_per_eu(SC_K1_WAVES, SC_K1_WAVES)))
+#else
+#define SC_K1_OCC
+#endif
 template <bool kCull, bool kAabb, uint32_t kChain>
-__global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, kChain>(d, p); }
+__global__ __launch_bounds__(kTile) SC_K1_OCC void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, kChain>(d, p); }
 
 template <bool kCull, bool kAabb, uint32_t kChain>
 __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p)
@@ -1353,8 +1371,12 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       myCount = d.binCount[mySector];
       const uint32_t lay = d.binLayers[mySector];      // requested together with the count: one round trip, not two
       myLay = lay;
+      // the bin's counters go back to where the next tick starts from: zero, or -- with remembered slots -- the slots that are
+      // reserved and the layer summary of their records (binEntityWave, "home slots")
+      uint32_t hc = 0u, hl = 0u;
+      if (p.homeReset) { hc = d.homeCount[mySector]; hl = d.homeLayers[mySector]; }
+      if (myCount != hc || lay != hl) { d.binCount[mySector] = hc; d.binLayers[mySector] = hl; }
       if (myCount) {
-        d.binCount[mySector] = 0u; d.binLayers[mySector] = 0u;
         // no record of this bin can pass the group/mask filter against another one: nothing to read
         if (nbig == 0u && ((lay & 0xFFFFu) & (lay >> 16)) == 0u) {
           if (myCount > kBinCap) { d.ovfLo[mySector] = 0xFFFFFFFFu; d.ovfHi[mySector] = 0u; }     // (its overflow slice goes unread too)
@@ -1794,13 +1816,6 @@ __device__ __forceinline__ uint32_t blockScanExclusive(uint32_t v, uint32_t carr
   *total = carry + sWave[0] + sWave[1] + sWave[2] + sWave[3];
   __syncthreads();
   return before + incl - v;
-}
-
-// a record that overlaps nothing and passes no filter: padding where a count was promised and the record could not be found
-__device__ __forceinline__ void nullRecord(float4& lo, float4& hi)
-{
-  lo = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0u));
-  hi = make_float4(-INFINITY, -INFINITY, -INFINITY, __uint_as_float(0x00FFFFFFu));
 }
 
 __device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickParams& p, uint32_t dir)
@@ -2284,9 +2299,25 @@ __global__ __launch_bounds__(kTile) void k_emit_draws_staged(const DeviceState d
   }
 }
 
+// Learn tick, right behind the fused kernel (before the level kernels and the border merge add records of their own): the
+// slots handed out so far are the remembered ones.
+__global__ __launch_bounds__(kTile) void k_snapshot_home(const DeviceState d, uint32_t sectors)
+{
+  const uint32_t s = blockIdx.x * kTile + threadIdx.x;
+  if (s >= sectors) return;
+  const uint32_t c = d.binCount[s];
+  d.homeCount[s] = c < kBinCap ? c : kBinCap;
+  d.homeLayers[s] = d.binLayers[s];
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+void launchSnapshotHome(const DeviceState& d, uint32_t sectors, hipStream_t s)
+{
+  if (!sectors) return;
+  hipLaunchKernelGGL(k_snapshot_home, dim3((sectors + kTile - 1) / kTile), dim3(kTile), 0, s, d, sectors);
+}
 // `done` (may be null): recorded by the dispatch itself -- the event the copy stream waits for, without a marker packet
 void launchEmitDrawsStaged(const DeviceState& d, uint32_t budget, uint32_t* block, uint32_t maxVisible, uint64_t tick, hipStream_t s, hipEvent_t done)
 {

@@ -275,3 +275,52 @@ def test_overflow_list_holds_every_copy_of_every_box(oracle):
     c = t.counts()
     assert c.bin_overflow > w.n and c.border_lost == 0 and c.pairs_truncated == 0 and c.pairs > 10000
     t.close(); ow.close()
+
+
+@pytest.mark.parametrize("period,variant", [("3", "0"), ("64", "0"), ("64", "2")])
+def test_remembered_bin_slots_over_many_ticks_with_boxes_changing_sectors(oracle, monkeypatch, period, variant):
+    """Home slots: records go to the slot they reserved at the last learn tick while their box keeps its
+    sector.  Forty ticks of a world whose roots move 2.3 m per tick -- boxes enter and leave sectors all the time, copies in
+    neighbouring sectors appear and lapse, deep chains and big boxes take the reserving path throughout -- with a learn tick
+    every 3 ticks, every 64 (so nearly every box ends up away from home), and with the slots switched off (SC_TICK_VARIANT
+    bit 1): the pair set must be the oracle's on every tick either way."""
+    monkeypatch.setenv("SC_TICK_HOME_PERIOD", period)
+    monkeypatch.setenv("SC_TICK_VARIANT", variant)
+    w = worlds.random_world(4000, seed=77, spread=220.0, max_depth=5)
+    w.bmin[:25] *= 40.0; w.bmax[:25] *= 40.0                                # a few big boxes (never binned)
+    w.pos[100:260] = np.float32([40.0, 0.0, -30.0]) + np.random.default_rng(5).uniform(-9, 9, (160, 3)).astype(np.float32)   # one crowded sector: bin overflow
+    t, ow = gpu_vs_oracle(oracle, w, brute=False, ticks=40, nudge=2.3, max_pairs=1 << 20)
+    c = t.counts()
+    assert c.pairs > 200 and c.pairs_truncated == 0 and c.bin_overflow > 50
+    t.close(); ow.close()
+
+
+def test_remembered_slots_survive_uploads_appends_and_removals(oracle, monkeypatch):
+    """Whatever changes the world's shape -- positions uploaded, layers changed, entities appended and removed -- between
+    ticks: the pair set stays the oracle's (layers, appends and removals force a learn tick; positions do not need one)."""
+    monkeypatch.setenv("SC_TICK_HOME_PERIOD", "1000")
+    w = worlds.random_world(2500, seed=78, spread=180.0, max_depth=2)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    t = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 19)
+    rng = np.random.default_rng(9)
+
+    def check():
+        ow.transform_system(); t.run(FLAGS)
+        mn, mx = ow.world_aabbs()
+        want = oracle.broadphase_grid(mn, mx, w.group, w.mask, 64.0)
+        got, total = t.pairs()
+        assert total == len(want) and np.array_equal(sorted_pairs(got), want)
+    check(); check()
+    # positions of a third of the roots jump across the world: their records leave home, no learn tick
+    roots = np.flatnonzero(w.parent < 0)
+    mv = rng.choice(roots, len(roots) // 3, replace=False)
+    w.pos[mv] = rng.uniform(-180, 180, (len(mv), 3)).astype(np.float32)
+    ow.set_local_positions(np.arange(w.n, dtype=np.uint32), w.pos)       # (setLocalPosition marks dirty: every entity, on both sides)
+    t.upload_positions(0, w.pos)
+    check(); check()
+    # layers flip for half of the world
+    flip = rng.random(w.n) < 0.5
+    w.group[flip], w.mask[flip] = 1, 0xFFFFFFFF
+    t.upload_layers(0, w.group, w.mask)
+    check(); check()
+    t.close(); ow.close()

@@ -71,7 +71,9 @@ def test_tiled_pairs_equal_whole_world_pairs(oracle, grid):
             p, total = t.pairs()
             assert total == len(p)
             c = t.counts()
-            assert c.big_boxes == 0 and c.bin_overflow == 0
+            # (no big boxes in this world; the sector overflow list may see a few records: props crowd onto the shared edge from
+            #  both tiles, and with remembered slots a box that moved on leaves a null record in its old slot until the next learn tick)
+            assert c.big_boxes == 0 and c.bin_overflow < 16 and c.border_lost == 0
             got.append(tiles.global_pair_ids(p, n))
         got = np.concatenate(got).astype(np.uint64)
         lo, hi = np.minimum(got[:, 0], got[:, 1]), np.maximum(got[:, 0], got[:, 1])
