@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SC_TICK_API_VERSION 3u
+#define SC_TICK_API_VERSION 4u
 #define SC_TICK_MAX_ENTITIES ((1u << 24) - 1u)   /* Entity::INDEX_BITS = 24 (sc_ecs.h:18-20); index 0xFFFFFF is the "no parent" value */
 #define SC_TICK_NO_PARENT (-1)
 

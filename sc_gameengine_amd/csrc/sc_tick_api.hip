@@ -668,6 +668,7 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
       ok = fail(c, "tile rectangle too large");           // (the pair search carries a sector's grid coordinates as 16 + 16 bits)
     ok = ok && dalloc(c, d.binCount, c->sectors) && dalloc(c, d.binLayers, c->sectors) && dalloc(c, d.bins, (size_t)c->sectors * kBinCap * 2u, false)
             && dalloc(c, d.bigList, (N + 8u * kBorderBigCap) * 2u, false) && dalloc(c, d.spill, 2u * (size_t)ovfRecords(c), false) && dalloc(c, d.spillSector, ovfRecords(c))
+            && dalloc(c, d.crowdQueue, (size_t)kMaxParity * c->sectors)
             && dalloc(c, d.ovfIdx, (size_t)kOvfWaves * kOvfPerSector, false) && dalloc(c, d.ovfLo, c->sectors, false) && dalloc(c, d.ovfHi, c->sectors)
             && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, (kMaxParity + 1u) * kPairShards * kShardStride)
             && dalloc(c, c->dPairsOut, c->maxPairs, false) && dalloc(c, c->dPairTotal, 4)

@@ -112,6 +112,7 @@ struct DeviceState {
   uint32_t* ovfLo;             // per sector: lowest overflow-list index tagged with it (0xFFFFFFFF: none) ...
   uint32_t* ovfHi;             // ... and one past the highest: the slice a sector's wave has to sweep (entities of a sector sit
                                // together in pool order, so its overflow records sit together in the list)
+  uint32_t* crowdQueue;        // [kMaxParity][sectors] crowded sectors of the tick -- queued by whoever was handed slot 64 of a bin -- for the pair search
   uint32_t* ovfIdx;            // [pair-role waves][kOvfPerSector] scratch: overflow-list indices of the sector a wave is working on
   uint2* pairs;                // (a, b) ids, a < b; id = rank << 24 | dense index; kPairShards segments of shardCap
   uint32_t* pairShardCount;    // [kMaxParity parities + snapshot][kPairShards] counters, one per 128-byte line (kShardStride words apart)
@@ -149,6 +150,7 @@ constexpr uint32_t kPairShards = 64, kShardStride = 32, kWavePairBuf = 256;
 constexpr uint32_t kPrimary = 0x80000000u;
 // counters[]: 0 visible, 1 culled, 4 draws, 5 dropped, 6 renderables; per tick parity q: 8+8q+{0 pairs, 1 big, 2 bin-full}
 constexpr uint32_t kCtrPar = 8, kCtrPairs = 0, kCtrBig = 1, kCtrBinFull = 2, kCtrBorderLost = 3, kCtrBigLocal = 4, kCtrSpill = 5;
+constexpr uint32_t kCtrCrowdTail = 6, kCtrCrowdHead = 7;     // crowded sectors queued by the binning / taken by the pair search (reset with the parity's counters)
 constexpr uint32_t kHomeOff = 0, kHomeLearn = 1, kHomeUse = 2;
 constexpr uint32_t kNoHome = 0xFFFFFFFFu, kNoSlot = 0xFFu;
 // Tick "parity": which copy of the per-tick broadphase state a tick works on.  The in-order flows alternate between two

@@ -244,6 +244,16 @@ __device__ __forceinline__ void appendBig(const DeviceState& d, const TickParams
   d.bigList[2u * (size_t)slot + 1u] = rmax;
 }
 
+// A sector becomes CROWDED the moment slot 64 of its bin is handed out (its counter keeps counting; the record goes to the
+// sector overflow list).  Whoever is handed that slot -- exactly one record per sector and tick -- puts the sector on the tick's
+// queue of crowded sectors, so that the queue is complete before the pair search starts (it is a launch of its own).
+__device__ __forceinline__ void queueCrowded(const DeviceState& d, const TickParams& p, uint32_t sector)
+{
+  const uint32_t at = atomicAdd(&d.counters[kCtrPar + 8u * p.parity + kCtrCrowdTail], 1u);
+  const uint32_t sectors = p.binSX * p.binSZ;
+  if (at < sectors) d.crowdQueue[p.parity * sectors + at] = sector;          // (one entry per sector at most: always room)
+}
+
 // One record into one sector's bin by the lane itself (or into the sector overflow list when the bin is full).
 __device__ __forceinline__ void binInsertLane(const DeviceState& d, const TickParams& p, uint32_t sector, const float4& rmin, const float4& rm)
 {
@@ -253,6 +263,7 @@ __device__ __forceinline__ void binInsertLane(const DeviceState& d, const TickPa
     float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
     r[0] = rmin; r[1] = rm;
   } else {
+    if (slot == kBinCap) queueCrowded(d, p, sector);
     const uint32_t ctr = kCtrPar + 8u * p.parity;
     const uint32_t at = atomicAdd(&d.counters[ctr + kCtrSpill], 1u);
     if (at < p.ovfCap) {
@@ -278,9 +289,10 @@ __device__ __forceinline__ void nullRecord(float4& lo, float4& hi)
 // the primary's returning atomic another 2.9.  Now every returning atomic of the tile -- the run heads' for the primary
 // copies, up to three per straddling lane for the others -- is issued before any result is used, the layer summaries'
 // atomicOr (nothing returns) behind them, and the stores follow one wait.
-__device__ __forceinline__ void spillLane(const DeviceState& d, const TickParams& p, uint32_t sector, const float4& rmin, const float4& rm)
+__device__ __forceinline__ void spillLane(const DeviceState& d, const TickParams& p, uint32_t sector, uint32_t slot, const float4& rmin, const float4& rm)
 {
-  // one record that found its sector's bin full: it joins the sector overflow list
+  // one record that found its sector's bin full (it was handed `slot` >= 64): it joins the sector overflow list
+  if (slot == kBinCap) queueCrowded(d, p, sector);
   const uint32_t ctr = kCtrPar + 8u * p.parity;
   const uint32_t at = atomicAdd(&d.counters[ctr + kCtrSpill], 1u);
   if (at < p.ovfCap) {
@@ -306,13 +318,14 @@ __device__ __forceinline__ void spillLane(const DeviceState& d, const TickParams
 // on every tick and no parity copy of the bins ever shows a stale record; a copy without a reservation (the box entered a
 // new sector, a bin was full at the learn tick, level kernels, border records) reserves behind the remembered slots as before.
 // Same records in the same bins -- the pair search sees a few null records more, which pass no filter and overlap nothing.
+template <uint32_t kHome>
 __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickParams& p, uint32_t i, bool collider,
                                               const Aff& M, const BoundsCE& b, bool storeM)
 {
   float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
   BinPlan plan; plan.collide = false; plan.big = false; plan.x0 = plan.z0 = 0.0f; plan.nx = plan.nz = 0;
   float4 rmin = make_float4(0, 0, 0, 0), rmax = make_float4(0, 0, 0, 0);
-  const uint32_t mode = p.homeMode;
+  constexpr uint32_t mode = kHome;                       // (a kernel instance per mode: the learn tick's bookkeeping costs the other ticks no registers)
   uint32_t hA = kNoHome, hB = 0xFFFFFFFFu;
   if (mode == kHomeUse && i < p.n) { hA = d.homeA[i]; hB = d.homeB[i]; }
   if (collider) {
@@ -324,15 +337,11 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
   const bool want = plan.collide && !plan.big;
   const uint32_t sector = (uint32_t)plan.z0 * p.binSX + (uint32_t)plan.x0;
   const uint32_t lane = threadIdx.x & 63u;
-  // ---- the copies: 0 = the primary (every box has exactly one), 1..3 = the sectors next to it that the box reaches into
-  const bool c1 = want && plan.nx > 1u, c2 = want && plan.nz > 1u, c3 = c1 && c2;
-  const uint32_t sec1 = sector + 1u, sec2 = sector + p.binSX, sec3 = sec2 + 1u;
   // remembered slots count while the box's primary sector is the one they were reserved from
   const bool atHome = want && hA == sector;
-  const uint32_t h0 = atHome ? (hB & 0xFFu) : kNoSlot, h1 = atHome ? ((hB >> 8) & 0xFFu) : kNoSlot,
-                 h2 = atHome ? ((hB >> 16) & 0xFFu) : kNoSlot, h3 = atHome ? (hB >> 24) : kNoSlot;
-  const bool a0 = want && h0 == kNoSlot, a1 = c1 && h1 == kNoSlot, a2 = c2 && h2 == kNoSlot, a3 = c3 && h3 == kNoSlot;   // copies that reserve
-  uint32_t slot = h0, q1 = h1, q2 = h2, q3 = h3;
+  const bool r0 = atHome && (hB & 0xFFu) != kNoSlot;
+  const bool a0 = want && !r0;                                     // the primary copy reserves its slot
+  uint32_t slot = hB & 0xFFu;
   float4 rm = rmax;
   rm.w = __uint_as_float(i | p.rankBits | kPrimary);
   const uint32_t myLay = __float_as_uint(rmin.w);
@@ -376,40 +385,67 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
     float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
     r[0] = rmin; r[1] = rm;
   }
-  // ---- the copies in the neighbouring sectors (a few lanes per wave; every ground slab): remembered slots are stored to
-  // directly, the rest reserve theirs -- the (up to three) reservations of a lane issued together, one wait
-#if SC_ABL & 256
-  if (a1) q1 = 17u; if (a2) q2 = 18u; if (a3) q3 = 19u;                          // (timing only: no reservation, fixed slots)
-#else
-  if (a1) q1 = atomicAdd(&d.binCount[sec1], 1u);
-  if (a2) q2 = atomicAdd(&d.binCount[sec2], 1u);
-  if (a3) q3 = atomicAdd(&d.binCount[sec3], 1u);
-#endif
-  if (c1 && q1 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec1 * kBinCap + q1); r[0] = rmin; r[1] = rmax; }
-  if (c2 && q2 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec2 * kBinCap + q2); r[0] = rmin; r[1] = rmax; }
-  if (c3 && q3 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec3 * kBinCap + q3); r[0] = rmin; r[1] = rmax; }
-#if !(SC_ABL & 32)
-  if (a1) atomicOr(&d.binLayers[sec1], myLay);
-  if (a2) atomicOr(&d.binLayers[sec2], myLay);
-  if (a3) atomicOr(&d.binLayers[sec3], myLay);
-#endif
-  // ---- remembered slots whose copy does not exist this tick: the owner writes a null record there
-  if (hA != kNoHome) {
-    const uint32_t g0 = hB & 0xFFu, g1 = (hB >> 8) & 0xFFu, g2 = (hB >> 16) & 0xFFu, g3 = hB >> 24;
-    const bool n0 = g0 != kNoSlot && !atHome, n1 = g1 != kNoSlot && !(atHome && c1), n2 = g2 != kNoSlot && !(atHome && c2), n3 = g3 != kNoSlot && !(atHome && c3);
-    if (n0 | n1 | n2 | n3) {
-      float4 lo, hi; nullRecord(lo, hi);
-      if (n0) { float4* r = d.bins + 2u * ((size_t)hA * kBinCap + g0); r[0] = lo; r[1] = hi; }
-      if (n1) { float4* r = d.bins + 2u * ((size_t)(hA + 1u) * kBinCap + g1); r[0] = lo; r[1] = hi; }
-      if (n2) { float4* r = d.bins + 2u * ((size_t)(hA + p.binSX) * kBinCap + g2); r[0] = lo; r[1] = hi; }
-      if (n3) { float4* r = d.bins + 2u * ((size_t)(hA + p.binSX + 1u) * kBinCap + g3); r[0] = lo; r[1] = hi; }
+  uint32_t learned = (want && slot < kBinCap) ? slot : kNoSlot;    // (learn tick: what homeB will hold)
+  // ---- the copies in the neighbouring sectors (a few lanes per wave; every ground slab).  With remembered slots (the usual
+  // case on a kHomeUse tick) a copy is a plain store; on the other ticks the (up to three) reservations of a lane are issued
+  // together and waited for once.
+  const bool c1 = want && plan.nx > 1u, c2 = want && plan.nz > 1u, c3 = c1 && c2;
+  if (mode == kHomeUse) {
+    // (the reservations of the copies that have no remembered slot -- boxes that entered a sector, crowded bins -- are issued
+    //  together and waited for once, like on the other ticks: one after the other they cost config 5's fused kernel 2.3 us)
+    const uint32_t sec1 = sector + 1u, sec2 = sector + p.binSX, sec3 = sec2 + 1u;
+    uint32_t q1 = (hB >> 8) & 0xFFu, q2 = (hB >> 16) & 0xFFu, q3 = hB >> 24;
+    const bool a1 = c1 && !(atHome && q1 != kNoSlot), a2 = c2 && !(atHome && q2 != kNoSlot), a3 = c3 && !(atHome && q3 != kNoSlot);
+    if (a1) q1 = atomicAdd(&d.binCount[sec1], 1u);
+    if (a2) q2 = atomicAdd(&d.binCount[sec2], 1u);
+    if (a3) q3 = atomicAdd(&d.binCount[sec3], 1u);
+    if (c1 && q1 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec1 * kBinCap + q1); r[0] = rmin; r[1] = rmax; }
+    if (c2 && q2 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec2 * kBinCap + q2); r[0] = rmin; r[1] = rmax; }
+    if (c3 && q3 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec3 * kBinCap + q3); r[0] = rmin; r[1] = rmax; }
+    if (a1) atomicOr(&d.binLayers[sec1], myLay);
+    if (a2) atomicOr(&d.binLayers[sec2], myLay);
+    if (a3) atomicOr(&d.binLayers[sec3], myLay);
+    if (ballot64((a1 && q1 >= kBinCap) || (a2 && q2 >= kBinCap) || (a3 && q3 >= kBinCap))) {
+      if (a1 && q1 >= kBinCap) spillLane(d, p, sec1, q1, rmin, rmax);
+      if (a2 && q2 >= kBinCap) spillLane(d, p, sec2, q2, rmin, rmax);
+      if (a3 && q3 >= kBinCap) spillLane(d, p, sec3, q3, rmin, rmax);
     }
-  }
-  // ---- learn tick: remember where this entity's records went (reserved slots inside the bin only)
-  if (mode == kHomeLearn && i < p.n) {
-    d.homeA[i] = want ? sector : kNoHome;
-    d.homeB[i] = (want && slot < kBinCap ? slot : kNoSlot) | ((c1 && q1 < kBinCap ? q1 : kNoSlot) << 8) |
-                 ((c2 && q2 < kBinCap ? q2 : kNoSlot) << 16) | ((c3 && q3 < kBinCap ? q3 : kNoSlot) << 24);
+    // remembered slots whose copy does not exist this tick: the owner writes a null record there
+    if (hA != kNoHome && !(atHome && c1 && c2)) {
+      float4 lo, hi; nullRecord(lo, hi);
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; ++k) {
+        const bool ck = k == 0u ? want : (k == 1u ? c1 : (k == 2u ? c2 : c3));
+        const uint32_t gk = (hB >> (8u * k)) & 0xFFu;
+        if (gk != kNoSlot && !(atHome && ck)) { float4* r = d.bins + 2u * ((size_t)(hA + (k & 1u) + (k >> 1) * p.binSX) * kBinCap + gk); r[0] = lo; r[1] = hi; }
+      }
+    }
+  } else {
+    const uint32_t sec1 = sector + 1u, sec2 = sector + p.binSX, sec3 = sec2 + 1u;
+    uint32_t q1 = 0, q2 = 0, q3 = 0;
+#if SC_ABL & 256
+    q1 = 17u; q2 = 18u; q3 = 19u;                                  // (timing only: no reservation, fixed slots)
+#else
+    if (c1) q1 = atomicAdd(&d.binCount[sec1], 1u);
+    if (c2) q2 = atomicAdd(&d.binCount[sec2], 1u);
+    if (c3) q3 = atomicAdd(&d.binCount[sec3], 1u);
+#endif
+    if (c1 && q1 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec1 * kBinCap + q1); r[0] = rmin; r[1] = rmax; }
+    if (c2 && q2 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec2 * kBinCap + q2); r[0] = rmin; r[1] = rmax; }
+    if (c3 && q3 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec3 * kBinCap + q3); r[0] = rmin; r[1] = rmax; }
+#if !(SC_ABL & 32)
+    if (c1) atomicOr(&d.binLayers[sec1], myLay);
+    if (c2) atomicOr(&d.binLayers[sec2], myLay);
+    if (c3) atomicOr(&d.binLayers[sec3], myLay);
+#endif
+    learned |= ((c1 && q1 < kBinCap ? q1 : kNoSlot) << 8) | ((c2 && q2 < kBinCap ? q2 : kNoSlot) << 16) | ((c3 && q3 < kBinCap ? q3 : kNoSlot) << 24);
+    if (ballot64((c1 && q1 >= kBinCap) || (c2 && q2 >= kBinCap) || (c3 && q3 >= kBinCap))) {
+      if (c1 && q1 >= kBinCap) spillLane(d, p, sec1, q1, rmin, rmax);
+      if (c2 && q2 >= kBinCap) spillLane(d, p, sec2, q2, rmin, rmax);
+      if (c3 && q3 >= kBinCap) spillLane(d, p, sec3, q3, rmin, rmax);
+    }
+    // ---- learn tick: remember where this entity's records went (reserved slots inside the bin only)
+    if (mode == kHomeLearn && i < p.n) { d.homeA[i] = want ? sector : kNoHome; d.homeB[i] = learned; }
   }
   // bin full: the record joins the sector overflow list (primary copies: one reservation per wave)
   const bool over = a0 && slot >= kBinCap;
@@ -420,6 +456,7 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
     uint32_t at = 0;
     if (lane == first) at = atomicAdd(&d.counters[ctr + kCtrSpill], (uint32_t)__popcll(mo));     // (every wave of the chip meets on this word: one atomic, not two)
     at = __shfl(at, (int)first, 64) + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
+    if (over && slot == kBinCap) queueCrowded(d, p, sector);
     if (over && at < p.ovfCap) {
       d.spill[2u * (size_t)at] = rmin; d.spill[2u * (size_t)at + 1u] = rm; d.spillSector[at] = sector;
       // the overflowing lanes of a run are its tail and their list indices ascend with the lane: the first one lowers the
@@ -427,11 +464,6 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
       if (slot == kBinCap || lane == myHead) atomicMin(&d.ovfLo[sector], at);
       if (lane + 1u == runEnd) atomicMax(&d.ovfHi[sector], at + 1u);
     } else if (over) atomicAdd(&d.counters[ctr + kCtrBorderLost], 1u);      // (cannot happen with the list sized by ovfRecords(): never silent anyway)
-  }
-  if (ballot64((a1 && q1 >= kBinCap) || (a2 && q2 >= kBinCap) || (a3 && q3 >= kBinCap))) {
-    if (a1 && q1 >= kBinCap) spillLane(d, p, sec1, rmin, rmax);
-    if (a2 && q2 >= kBinCap) spillLane(d, p, sec2, rmin, rmax);
-    if (a3 && q3 >= kBinCap) spillLane(d, p, sec3, rmin, rmax);
   }
   if (plan.collide && plan.big) appendBig(d, p, rmin, rmax);
 }
@@ -475,7 +507,7 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
 // host after scTickSetTopology.  Specialising on it removes dead levels from worlds that are flat or shallow.
 // (Requesting all levels' locals before multiplying -- one round trip instead of one per level -- was measured:
 // it needs 12 more VGPRs per level, 104-116 in all, and lost 5-25 %)
-template <bool kCull, bool kAabb, uint32_t kChain>
+template <bool kCull, bool kAabb, uint32_t kChain, uint32_t kHome>
 __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p);
 
 #ifndef SC_K1_WAVES
@@ -486,10 +518,10 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
 #else
 #define SC_K1_OCC
 #endif
-template <bool kCull, bool kAabb, uint32_t kChain>
-__global__ __launch_bounds__(kTile) SC_K1_OCC void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, kChain>(d, p); }
+template <bool kCull, bool kAabb, uint32_t kChain, uint32_t kHome>
+__global__ __launch_bounds__(kTile) SC_K1_OCC void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, kChain, kHome>(d, p); }
 
-template <bool kCull, bool kAabb, uint32_t kChain>
+template <bool kCull, bool kAabb, uint32_t kChain, uint32_t kHome>
 __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p)
 {
   const uint32_t lane = threadIdx.x & 63u;
@@ -604,10 +636,10 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
         // deeper entities are binned by the level kernels once their matrix is final
         const bool collider = hb && !(doXform && depth > kChain && depth != kUnreachable);
 #if SC_ABL & 2
-        if (M.r1[3] + b.cy == 12345.678f) binEntityWave(d, p, i, collider, M, b, false);
+        if (M.r1[3] + b.cy == 12345.678f) binEntityWave<kHome>(d, p, i, collider, M, b, false);
         if (recompute) storeRows(d, i, M);
 #else
-        binEntityWave(d, p, i, collider, M, b, recompute && !(SC_ABL & 1) && !kNoDefer);
+        binEntityWave<kHome>(d, p, i, collider, M, b, recompute && !(SC_ABL & 1) && !kNoDefer);
 #endif
       }
     }
@@ -624,185 +656,12 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// K1, LDS form (round 3).  The chain walk above is a string of DEPENDENT memory round trips per 64-entity tile -- own link
-// and dirty word, one trip per ancestor for its link / dirty words, one per chain level for its locals, then bounds, then
-// the bin reservation: about eight, ~14 us per tile and wave, and that -- not bytes, not instruction issue (an FMA-contracted
-// build and an SLP-vectorised one run at the same speed: profiles/r03/ab_diag_fma_slp_spans.log) -- is what the kernel's
-// duration was made of.  Here a workgroup's tile (256 consecutive entities) shares what the walk needs through LDS:
-//   trip 1   link word of every entity of the tile + the tile's eight dirty words          -> LDS, barrier
-//   walk     ancestors' link words and dirty bits come from LDS (an ancestor outside the tile: from memory, as before)
-//   trip 2   an entity that rebuilds loads its OWN locals once and leaves its local matrix in LDS; a clean one loads its
-//            stored rows; bounds are requested in the same trip                             -> barrier
-//   products world = world'(parent(top)) * local(top) * ... * local(self), left to right as the DFS does (sc_ecs.cpp:178-209),
-//            the ancestors' local matrices read from LDS (every ancestor at or below `top` rebuilds too, so its lane wrote one)
-//   trip 3   the bin reservation
-// Same arithmetic on the same values in the same order: bit-identical results.  LDS: 12 KiB of local matrices + 1 KiB of
-// link words per workgroup, seven workgroups per CU.
-// ------------------------------------------------------------------------------------------
-#ifndef SC_LDS_WAVES
-#define SC_LDS_WAVES 6
-#endif
-#if SC_LDS_WAVES
-#define SC_LDS_OCC __attribute__((amdgpu_waves_per_eu(SC_LDS_WAVES, SC_LDS_WAVES)))
-#else
-#define SC_LDS_OCC
-#endif
-#ifndef SC_EARLY_BOUNDS
-#define SC_EARLY_BOUNDS 0
-#endif
-constexpr bool kEarlyBounds = SC_EARLY_BOUNDS != 0;     // bounds requested in trip 2 (six more VGPRs across the products) or behind them
-template <bool kCull, bool kAabb, uint32_t kChain>
-__device__ __forceinline__ void xformCullLdsBody(const DeviceState& d, const TickParams& p, float (*sL)[kTile], uint32_t* sLink, uint32_t* sDirty);
-
-template <bool kCull, bool kAabb, uint32_t kChain>
-__global__ __launch_bounds__(kTile) SC_LDS_OCC void k_xform_cull_lds(const DeviceState d, const TickParams p)
-{
-  __shared__ float sL[12][kTile];
-  __shared__ uint32_t sLink[kTile];
-  __shared__ uint32_t sDirty[kTile / 32];
-  xformCullLdsBody<kCull, kAabb, kChain>(d, p, sL, sLink, sDirty);
-}
-
-template <bool kCull, bool kAabb, uint32_t kChain>
-__device__ __forceinline__ void xformCullLdsBody(const DeviceState& d, const TickParams& p, float (*sL)[kTile], uint32_t* sLink, uint32_t* sDirty)
-{
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t begin = blockIdx.x * p.span;
-  const uint32_t end = (begin + p.span < p.n) ? begin + p.span : p.n;
-  const bool doXform = (p.flags & SC_TICK_XFORM) != 0;
-  const bool wantCand = (p.flags & SC_TICK_CULLED_LIST) != 0;
-  const bool hasDeep = (p.flags & kFlagHasDeep) != 0;
-  const uint32_t dirtyWords = (p.n + 31u) >> 5;
-
-  uint32_t visCount = 0, candCount = 0;      // wave-uniform running sums
-
-  for (uint32_t base = begin; base < end; base += kTile) {
-    const uint32_t i = base + threadIdx.x;
-    const bool active = i < p.n;
-    // ---- trip 1: the tile's link and dirty words
-    const uint32_t lk = active ? ldU(d, kLINK, i) : ((kUnreachable << kDepthShift) | kNoParent);
-    if (doXform) {
-      sLink[threadIdx.x] = lk;
-      if (threadIdx.x < kTile / 32u) { const uint32_t w = (base >> 5) + threadIdx.x; sDirty[threadIdx.x] = w < dirtyWords ? d.dirty[w] : 0u; }
-    }
-    __syncthreads();
-    const uint32_t depth = linkDepth(lk);
-    const bool chain = depth <= kChain;
-    // ---- walk up: ancestors a[1..depth], top = dirty level nearest the root
-    uint32_t a[kChain + 1];
-    uint32_t rotFlags = lk >> 29;                      // 3 rotation-triviality bits per level (used for ancestors outside the tile)
-    a[0] = i;
-    int top = -1;
-#pragma unroll
-    for (uint32_t k = 1; k <= kChain; ++k) a[k] = i;
-    if (doXform && chain) {
-      if ((sDirty[threadIdx.x >> 5] >> (threadIdx.x & 31u)) & 1u) top = 0;
-      uint32_t cur = lk;
-#pragma unroll
-      for (uint32_t k = 1; k <= kChain; ++k) {
-        if (k <= depth) {
-          a[k] = cur & kParentMask;
-          const uint32_t r = a[k] - base;
-          bool ad;
-          if (r < kTile) { cur = sLink[r]; ad = (sDirty[r >> 5] >> (r & 31u)) & 1u; }
-          else { cur = ldU(d, kLINK, a[k]); ad = dirtyBit(d.dirty, a[k]); }
-          rotFlags |= (cur >> 29) << (3u * k);
-          if (ad) top = (int)k;
-        }
-      }
-    }
-    const bool recompute = top >= 0;
-    const bool fromRoot = recompute && (uint32_t)top == depth;       // the chain's root itself is rebuilt: world = local
-
-    // ---- trip 2: own locals (-> LDS) or own stored rows; the seed; bounds
-    Aff M;
-    if (recompute) {
-      {
-        const Aff Lown = loadLocal(d, i, lk);
-        sL[0][threadIdx.x] = Lown.r0[0]; sL[1][threadIdx.x] = Lown.r0[1]; sL[2][threadIdx.x] = Lown.r0[2]; sL[3][threadIdx.x] = Lown.r0[3];
-        sL[4][threadIdx.x] = Lown.r1[0]; sL[5][threadIdx.x] = Lown.r1[1]; sL[6][threadIdx.x] = Lown.r1[2]; sL[7][threadIdx.x] = Lown.r1[3];
-        sL[8][threadIdx.x] = Lown.r2[0]; sL[9][threadIdx.x] = Lown.r2[1]; sL[10][threadIdx.x] = Lown.r2[2]; sL[11][threadIdx.x] = Lown.r2[3];
-      }
-      if (!fromRoot) {
-        uint32_t seed = i;
-#pragma unroll
-        for (uint32_t k = 0; k < kChain; ++k) if ((uint32_t)top == k) seed = a[k + 1];
-        M = loadRows(d, seed);                           // clean parent of the top dirty ancestor: its stored (possibly stale) matrix
-      }
-    } else if ((kCull || kAabb) && active) {
-      M = loadRows(d, i);
-    }
-    const bool hb = active && (lk & kHasBounds);
-    BoundsCE b = {0, 0, 0, 0, 0, 0};
-    if (kEarlyBounds && (kCull || kAabb) && hb) b = loadBounds(d, i);
-    if (doXform) __syncthreads();
-
-    if (recompute) {
-      // the chain's local matrices come back from LDS, the entity's own included (level 0)
-#pragma unroll
-      for (int lev = (int)kChain; lev >= 0; --lev) {
-        if (lev <= top) {
-          Aff L;
-          const uint32_t r = a[lev] - base;
-          if (lev == 0 || r < kTile) {
-            L.r0[0] = sL[0][r]; L.r0[1] = sL[1][r]; L.r0[2] = sL[2][r]; L.r0[3] = sL[3][r];
-            L.r1[0] = sL[4][r]; L.r1[1] = sL[5][r]; L.r1[2] = sL[6][r]; L.r1[3] = sL[7][r];
-            L.r2[0] = sL[8][r]; L.r2[1] = sL[9][r]; L.r2[2] = sL[10][r]; L.r2[3] = sL[11][r];
-          } else L = loadLocal(d, a[lev], (rotFlags >> (3 * lev)) << 29);
-          if (lev == top && fromRoot) M = L;
-          else M = mulAff(M, L);
-        }
-      }
-      if (!kAabb) storeRows(d, i, M);                    // (with binning the store rides behind the bin reservations: binEntityWave)
-    }
-    if (!kEarlyBounds && (kCull || kAabb) && hb) b = loadBounds(d, i);
-
-    if (hasDeep) {
-      const unsigned long long rm = ballot64(recompute);
-      if (lane == 0 && (base + wave * 64u) < p.n) d.recomp[(base >> 6) + wave] = rm;
-    }
-
-    if (kCull || kAabb) {
-      const bool cand = active && (lk & kHasMesh);
-      if (kCull) {
-        bool visible = cand;
-        if (cand && hb && !p.freeze && p.frustumValid) {
-          const float* fr = d.frustum;
-          asm volatile("" : "+s"(fr));                 // opaque: keeps the plane loads inside the loop, at their use
-          visible = sphereVisibleAt(M, b, (ConstF)fr);
-        }
-        // deeper entities get their matrix (and their bit) from the level kernels
-        if (doXform && depth > kChain && depth != kUnreachable) visible = false;
-        const unsigned long long vm = ballot64(visible);
-        const unsigned long long cm = ballot64(cand);
-        if (lane == 0 && (base + wave * 64u) < p.n) {
-          d.vis[(base >> 6) + wave] = vm;
-          if (wantCand) d.cand[(base >> 6) + wave] = cm;
-        }
-        visCount += (uint32_t)__popcll(vm);
-        candCount += (uint32_t)__popcll(cm);
-      }
-      if (kAabb) {
-        // deeper entities are binned by the level kernels once their matrix is final
-        const bool collider = hb && !(doXform && depth > kChain && depth != kUnreachable);
-        binEntityWave(d, p, i, collider, M, b, recompute);
-      }
-    }
-  }
-
-  if (kCull) {
-    __shared__ uint32_t sVis[kTile / 64], sCand[kTile / 64];
-    if (lane == 0) { sVis[wave] = visCount; sCand[wave] = candCount; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      d.blockVis[blockIdx.x] = sVis[0] + sVis[1] + sVis[2] + sVis[3];
-      d.blockCand[blockIdx.x] = sCand[0] + sCand[1] + sCand[2] + sCand[3];
-    }
-  }
-}
-
+// (Round 3 built a second form of this kernel in which a workgroup's tile shares the walk through LDS -- link words, dirty
+// words and the local matrices of the entities that rebuild, so that ancestors cost no memory round trips: three dependent
+// trips per tile instead of eight, bit-identical results, all GPU tests green -- and it was no faster: 39.6 against 38.7 us at six
+// and seven waves per SIMD, 48 at five (profiles/r03/ab_lds_kernel.log), 35.6 against 33.0 us once the bins' atomics were gone
+// (ab_kernels_home.log).  The kernel's time was never its chain of round trips; it was the memory-side atomics of the binning
+// (binEntityWave, "home slots").  The variant is in the history at commit 3b44da7.)
 // ------------------------------------------------------------------------------------------
 // Level kernel for entities deeper than kMaxChain (rare): one launch per level, parents final.
 // nodeDirty = dirty || parent recomputed this tick (sc_ecs.cpp:184).
@@ -1311,6 +1170,7 @@ constexpr uint32_t kPairTabSize = kBinCap * (kBinCap - 1) / 2;
 constexpr uint32_t kFineThreshold = 24;      // bins with more records than this use the 4x4 cell grid
 constexpr uint32_t kCellWords = 16u * (1u + kOvfPerSector / 64u);     // 4x4 cell masks for the bin tile and every overflow tile of a sector
 constexpr uint32_t kCastDirect = 2;          // this few cast records are broadcast one after the other (no re-ordering of the bin)
+// crowded sectors (more records than the bin holds) wait in a queue of the whole launch; a full queue leaves a sector to the wave that met it
 constexpr uint32_t kCastMax = 20;            // up to this many self-compatible (dynamic) records per bin are broadcast one by one
 
 // pair predicate shared by both search paths: group/mask filter, closed-interval overlap, and "this sector
@@ -1337,7 +1197,6 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   const uint32_t ctr = kCtrPar + 8u * p.parity;
   const uint32_t nbig = min(d.counters[ctr + kCtrBig], p.bigCap);      // (bounded whatever the counter holds)
   const uint32_t novf = min(d.counters[ctr + kCtrSpill], p.ovfCap);     // sector overflow list: own boxes and neighbours' border records
-  uint32_t* ovfIdx = d.ovfIdx + (size_t)(waveGlobal < kOvfWaves ? waveGlobal : kOvfWaves - 1u) * kOvfPerSector;   // (the launcher keeps waves below kOvfWaves)
   float4* T = tile[wave];
   PairSink sink = { pairBuf[wave], 0u, bid % kPairShards };
 
@@ -1348,6 +1207,11 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   // broadcast path: with D records to cast, lane l plays (record l / G, partner phase l % G), G = 64 / D; the division by
   // the wave-uniform G is a multiplication by ceil(2^16 / G) (exact for l < 64)
   __shared__ uint32_t castTab[kCastMax + 1u];
+  // crowded sectors (more records than the bin holds) are not searched by the wave that meets them: they go to a queue of
+  // the whole launch, and every workgroup, done with its sweep, takes sectors from it, four waves to a sector (see
+  // "crowded sectors" below)
+  __shared__ uint32_t crowdGathered, crowdItem, crowdLayers;
+  if (threadIdx.x == 0) { crowdGathered = 0u; crowdLayers = 0u; }
   if (threadIdx.x >= 1u && threadIdx.x <= kCastMax) { const uint32_t G = 64u / threadIdx.x; castTab[threadIdx.x] = G | ((65536u / G + 1u) << 8); }
 
   // next tick's counter set starts clean (pipelined tiles do this in the end-of-tick kernel on the tick stream instead:
@@ -1378,10 +1242,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       if (myCount != hc || lay != hl) { d.binCount[mySector] = hc; d.binLayers[mySector] = hl; }
       if (myCount) {
         // no record of this bin can pass the group/mask filter against another one: nothing to read
-        if (nbig == 0u && ((lay & 0xFFFFu) & (lay >> 16)) == 0u) {
-          if (myCount > kBinCap) { d.ovfLo[mySector] = 0xFFFFFFFFu; d.ovfHi[mySector] = 0u; }     // (its overflow slice goes unread too)
-          myCount = 0u;
-        }
+        if (nbig == 0u && ((lay & 0xFFFFu) & (lay >> 16)) == 0u) myCount = 0u;      // (a crowded sector's overflow slice is reset by the workgroup that takes it off the queue)
       }
     }
     const bool myOver = myCount > kBinCap;             // the sector holds more records than its bin: the rest is in the overflow list
@@ -1396,7 +1257,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       const int dx = myGx == 0 ? -1 : (myGx == p.binSX - 1u ? 1 : 0), dz = myGz == 0 ? -1 : (myGz == p.binSZ - 1u ? 1 : 0);
       if ((dx != 0 && hasNb(p, dx, 0)) || (dz != 0 && hasNb(p, 0, dz))) mine = false;    // nearest tile is not this one
     }
-    const unsigned long long oursMask = ballot64(mine), overMask = ballot64(myOver);
+    const unsigned long long oursMask = ballot64(mine);
     // what a sector's turn needs from the lane that holds it: index, count, layer summary, grid coordinates -- four
     // cross-lane reads.  (ds_bpermute although the picked lane is wave-uniform: v_readlane measured slower, 27.1 against
     // 26.3 us on config3dyn -- a VALU slot each plus SGPR-hazard waits; and recomputing the index from the lane number
@@ -1427,7 +1288,6 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       }
 
       const uint32_t gx = gxz & 0xFFFFu, gz = gxz >> 16;
-      const bool over = (overMask >> it) & 1ull;
       const bool ours = (oursMask >> it) & 1ull;
       const bool valid = lane < n && ours;
       // Filter first (integer, cheap): like btDbvtBroadphase, which keeps static bodies in a separate set
@@ -1594,105 +1454,144 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       // arrived from a neighbour alike -- sit in the overflow list, tagged with the sector.  They belong to the sector as much
       // as the records in the bin: each meets the bin's records and the sector's other overflow records under the same rule
       // (low corner of the intersection in this sector), and -- if it is its box's primary copy -- the big boxes.
-      // The wave gathers the list indices of its sector in one sweep (scratch row in global memory), then walks them in
-      // tiles of 64: tile k in registers (one record per lane) against the bin and against tiles 0..k staged in LDS.
-      // Cost: one sweep of the list per overflowing sector + (records of the sector)^2 / 64 tests.
-      if (over && novf) {
-        // the slice of the list that holds this sector's records; the wave that consumes a sector resets its slice
-        uint32_t eLo = d.ovfLo[s], eHi = d.ovfHi[s];
-        if (lane == 0) { d.ovfLo[s] = 0xFFFFFFFFu; d.ovfHi[s] = 0u; }
-        if (eHi > novf) eHi = novf;
-        if (!ours) eLo = eHi;                                     // a neighbour's ring sector: its pairs are the neighbour's
-        uint32_t m = 0;
-        for (uint32_t e0 = eLo; e0 < eHi; e0 += 256u) {           // four tags per lane in flight: the sweep is latency-bound
-          uint32_t tag[4];
+      // That part of a crowded sector's search is not this wave's: the sector is on the tick's queue of crowded sectors (put
+      // there by whoever was handed slot 64 of its bin) and a whole workgroup takes it behind the sweep -- "crowded sectors" below.
+      __builtin_amdgcn_wave_barrier();
+      it = itNext; n = nNext; s = sNext; gxz = gxzNext; binLay = binLayNext; rmin = nmin; rmax = nmax;
+    }
+  }
+
+
+  // ---- crowded sectors, four waves to a sector (round 3).  A sector at the engine's own budget -- 200 boxes -- is a bin and
+  // three tiles of overflow records; searched by the one wave that met it, it was a serial chain of dependent loads (the
+  // slice sweep, four registrations, ten tile stagings, each through an index and a record) with nothing else on that SIMD to
+  // hide them: 120 us for a district of 512 such sectors while nine tenths of the chip idled (profiles/r02/crowded_sectors.json).
+  // Now the workgroup's waves share one parked sector at a time: the sweep of the sector's slice of the overflow list is cut
+  // into chunks of 256 tags taken in turn (the matches' list positions go to one scratch row through an LDS counter: their
+  // order is immaterial), the tiles register their boxes in the 4x4 cell masks in turn, and the (register tile, staged tile)
+  // combinations -- k(k+3)/2 of them for k overflow tiles -- go round the waves; each wave keeps its own staging tile and pair
+  // buffer.  Same predicate, same pair set.
+  const uint32_t crowded = min(d.counters[ctr + kCtrCrowdTail], sectors);      // complete: the binning kernels are over
+  for (; crowded != 0u;) {
+    __syncthreads();                                                  // (the sweep, or the last sector, is over for every wave)
+    if (threadIdx.x == 0) {
+      const uint32_t idx = atomicAdd(&d.counters[ctr + kCtrCrowdHead], 1u);   // (one fetch-and-add per sector: nobody queues during this launch)
+      crowdItem = idx < crowded ? d.crowdQueue[p.parity * sectors + idx] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const uint32_t s = crowdItem;
+    if (s >= sectors) break;
+    const uint32_t n = kBinCap;                                       // (a crowded sector's bin is full)
+    const uint32_t gx = s % p.binSX, gz = s / p.binSX;
+    const float secX = (float)gx, secZ = (float)gz;
+    // a ring sector on a side where a neighbour tile exists belongs to that neighbour: only its slice is reset
+    bool ours = true;
+    {
+      const int dx = gx == 0 ? -1 : (gx == p.binSX - 1u ? 1 : 0), dz = gz == 0 ? -1 : (gz == p.binSZ - 1u ? 1 : 0);
+      if ((dx != 0 && hasNb(p, dx, 0)) || (dz != 0 && hasNb(p, 0, dz))) ours = false;
+    }
+    uint32_t* row = d.ovfIdx + (size_t)(bid * (kTile / 64u) < kOvfWaves ? bid * (kTile / 64u) : kOvfWaves - 1u) * kOvfPerSector;
+    uint32_t eLo = d.ovfLo[s], eHi = d.ovfHi[s];
+    if (eHi > novf) eHi = novf;
+    if (!ours) eLo = eHi;
+    __syncthreads();                                                  // (everybody has the slice bounds)
+    if (threadIdx.x == 0) { d.ovfLo[s] = 0xFFFFFFFFu; d.ovfHi[s] = 0u; }
+    for (uint32_t e0 = eLo + wave * 256u; e0 < eHi; e0 += 4u * 256u) {      // four tags per lane in flight, as the one-wave sweep
+      uint32_t tag[4];
 #pragma unroll
-          for (uint32_t u = 0; u < 4u; ++u) { const uint32_t e = e0 + u * 64u + lane; tag[u] = e < eHi ? d.spillSector[e] : 0xFFFFFFFFu; }
+      for (uint32_t u = 0; u < 4u; ++u) { const uint32_t q = e0 + u * 64u + lane; tag[u] = q < eHi ? d.spillSector[q] : 0xFFFFFFFFu; }
 #pragma unroll
-          for (uint32_t u = 0; u < 4u; ++u) {
-            const bool match = tag[u] == s;
-            const unsigned long long mm = ballot64(match);
-            if (match) {
-              const uint32_t at = m + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-              if (at < kOvfPerSector) ovfIdx[at] = e0 + u * 64u + lane;
-            }
-            m += (uint32_t)__popcll(mm);
-          }
-        }
-        if (m > kOvfPerSector) { if (lane == 0) atomicAdd(&d.counters[ctr + kCtrBorderLost], m - kOvfPerSector); m = kOvfPerSector; }
-        __threadfence_block();                                  // the index row was written by other lanes of this wave
-        // The sector's records as tiles of 64: tile 0 = the bin, tiles 1.. = its overflow records.  As in the dense-bin path
-        // the sector is cut into 4x4 cells; every tile keeps, per cell, the lanes whose box touches it (LDS, one 64-bit mask
-        // per tile and cell: any monotone cell function keeps every overlapping pair, clamping included).  A lane then meets
-        // only the records that share a cell with its own box: at the engine's 200 boxes per sector about a dozen per tile
-        // pair instead of 64.
-        const uint32_t tiles = (m + 63u) / 64u + 1u;
-        unsigned long long* CM = cellMembers[wave];
-        for (uint32_t t = lane; t < tiles * 16u; t += 64u) CM[t] = 0ull;
+      for (uint32_t u = 0; u < 4u; ++u) {
+        const bool match = tag[u] == s;
+        const unsigned long long mm = ballot64(match);
+        if (!mm) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&crowdGathered, (uint32_t)__popcll(mm));
+        base = __shfl(base, 0, 64);
+        const uint32_t at = base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+        if (match && at < kOvfPerSector) row[at] = e0 + u * 64u + lane;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    uint32_t m = crowdGathered;
+    if (m > kOvfPerSector) { if (threadIdx.x == 0) atomicAdd(&d.counters[ctr + kCtrBorderLost], m - kOvfPerSector); m = kOvfPerSector; }
+    const uint32_t tiles = (m + 63u) / 64u + 1u;
+    unsigned long long* CM = cellMembers[0];                          // one set of cell masks for the workgroup
+    for (uint32_t t = threadIdx.x; t < tiles * 16u; t += kTile) CM[t] = 0ull;
+    __syncthreads();
+    if (threadIdx.x == 0) crowdGathered = 0u;                         // (for the next parked sector: nobody reads it again before the barrier above)
+    const float ox = (secX + p.binOx) * 4.0f, oz = (secZ + p.binOz) * 4.0f, inv4 = p.invSector * 4.0f;
+    auto loadRec = [&](uint32_t t, float4& lo, float4& hi) -> bool {
+      lo = make_float4(0, 0, 0, 0); hi = make_float4(0, 0, 0, 0);
+      if (t == 0u) {
+        if (lane >= n) return false;
+        const float4* rec = d.bins + 2u * ((size_t)s * kBinCap + lane);
+        lo = rec[0]; hi = rec[1];
+        return true;
+      }
+      const uint32_t q = (t - 1u) * 64u + lane;
+      if (q >= m) return false;
+      const uint32_t idx = row[q];
+      lo = d.spill[2u * (size_t)idx]; hi = d.spill[2u * (size_t)idx + 1u];
+      return true;
+    };
+    auto cellRange = [&](const float4& lo, const float4& hi, int& cx0, int& cx1, int& cz0, int& cz1) {
+      cx0 = min(3, max(0, (int)floorf(lo.x * inv4 - ox))); cx1 = min(3, max(0, (int)floorf(hi.x * inv4 - ox)));
+      cz0 = min(3, max(0, (int)floorf(lo.z * inv4 - oz))); cz1 = min(3, max(0, (int)floorf(hi.z * inv4 - oz)));
+    };
+    for (uint32_t t = wave; t < tiles; t += kTile / 64u) {           // registration, a tile per wave in turn
+      float4 lo, hi; int cx0, cx1, cz0, cz1;
+      const bool has = loadRec(t, lo, hi);
+      cellRange(lo, hi, cx0, cx1, cz0, cz1);
+      if (has) for (int cz = cz0; cz <= cz1; ++cz) for (int cx = cx0; cx <= cx1; ++cx) atomicOr(&CM[t * 16u + (uint32_t)(cz * 4 + cx)], 1ull << lane);
+      // the sector's layer summary, from the records themselves (the sweep has reset the bin's own by now)
+      uint32_t lay = has ? __float_as_uint(lo.w) : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) lay |= (uint32_t)__shfl_xor((int)lay, o, 64);
+      if (lane == 0 && lay) atomicOr(&crowdLayers, lay);
+    }
+    __syncthreads();
+    const uint32_t sectorLay = crowdLayers;
+    __syncthreads();
+    if (threadIdx.x == 0) crowdLayers = 0u;
+    // no record of this sector can pass the group/mask filter against another one, and no big box is about: nothing to test
+    if (nbig == 0u && ((sectorLay & 0xFFFFu) & (sectorLay >> 16)) == 0u) continue;
+    uint32_t combo = 0;
+    for (uint32_t k = 1; k < tiles; ++k) {                           // (tile 0 against itself was the sweep's work)
+      for (uint32_t jt = 0; jt <= k; ++jt, ++combo) {
+        if ((combo & (kTile / 64u - 1u)) != wave) continue;
+        float4 xmin, xmax; int cx0, cx1, cz0, cz1;
+        const bool has = loadRec(k, xmin, xmax);
+        cellRange(xmin, xmax, cx0, cx1, cz0, cz1);
         __builtin_amdgcn_wave_barrier();
-        const float ox = (secX + p.binOx) * 4.0f, oz = (secZ + p.binOz) * 4.0f, inv4 = p.invSector * 4.0f;
-        auto loadRec = [&](uint32_t t, float4& lo, float4& hi) -> bool {
-          lo = make_float4(0, 0, 0, 0); hi = make_float4(0, 0, 0, 0);
-          if (t == 0u) {
-            if (lane >= n) return false;
-            const float4* rec = d.bins + 2u * ((size_t)s * kBinCap + lane);
-            lo = rec[0]; hi = rec[1];
-            return true;
-          }
-          const uint32_t q = (t - 1u) * 64u + lane;
-          if (q >= m) return false;
-          const uint32_t e = ovfIdx[q];
-          lo = d.spill[2u * (size_t)e]; hi = d.spill[2u * (size_t)e + 1u];
-          return true;
-        };
-        auto cellRange = [&](const float4& lo, const float4& hi, int& cx0, int& cx1, int& cz0, int& cz1) {
-          cx0 = min(3, max(0, (int)floorf(lo.x * inv4 - ox))); cx1 = min(3, max(0, (int)floorf(hi.x * inv4 - ox)));
-          cz0 = min(3, max(0, (int)floorf(lo.z * inv4 - oz))); cz1 = min(3, max(0, (int)floorf(hi.z * inv4 - oz)));
-        };
-        for (uint32_t t = 0; t < tiles; ++t) {                   // registration
-          float4 lo, hi; int cx0, cx1, cz0, cz1;
-          const bool has = loadRec(t, lo, hi);
-          cellRange(lo, hi, cx0, cx1, cz0, cz1);
-          if (has) for (int cz = cz0; cz <= cz1; ++cz) for (int cx = cx0; cx <= cx1; ++cx) atomicOr(&CM[t * 16u + (uint32_t)(cz * 4 + cx)], 1ull << lane);
-        }
+        if (jt == k) { T[2u * lane] = xmin; T[2u * lane + 1u] = xmax; }
+        else { float4 lo, hi; loadRec(jt, lo, hi); T[2u * lane] = lo; T[2u * lane + 1u] = hi; }
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t k = 1; k < tiles; ++k) {                   // (tile 0 against itself is the main path's work)
-          float4 xmin, xmax; int cx0, cx1, cz0, cz1;
-          const bool has = loadRec(k, xmin, xmax);
-          cellRange(xmin, xmax, cx0, cx1, cz0, cz1);
-          for (uint32_t jt = 0; jt <= k; ++jt) {
-            __builtin_amdgcn_wave_barrier();
-            if (jt == k) { T[2u * lane] = xmin; T[2u * lane + 1u] = xmax; }
-            else { float4 lo, hi; loadRec(jt, lo, hi); T[2u * lane] = lo; T[2u * lane + 1u] = hi; }
-            __builtin_amdgcn_wave_barrier();
-            unsigned long long cand = 0ull;
-            if (has) {
-              for (int cz = cz0; cz <= cz1; ++cz) for (int cx = cx0; cx <= cx1; ++cx) cand |= CM[jt * 16u + (uint32_t)(cz * 4 + cx)];
-              if (jt == k) cand &= (1ull << lane) - 1ull;          // inside a tile: partners in lower lanes
-            }
-            while (ballot64(cand != 0ull)) {
-              bool hit = false; uint32_t ia = 0, ib = 0;
-              if (cand) {
-                const uint32_t i = (uint32_t)__ffsll((long long)cand) - 1u;
-                cand &= cand - 1ull;
-                hit = pairHit(p, xmin, xmax, T[2u * i], T[2u * i + 1u], secX, secZ, ia, ib);
-              }
-              sinkPush(d, p, sink, hit, ia, ib);
-            }
+        unsigned long long cand = 0ull;
+        if (has) {
+          for (int cz = cz0; cz <= cz1; ++cz) for (int cx = cx0; cx <= cx1; ++cx) cand |= CM[jt * 16u + (uint32_t)(cz * 4 + cx)];
+          if (jt == k) cand &= (1ull << lane) - 1ull;          // inside a tile: partners in lower lanes
+        }
+        while (ballot64(cand != 0ull)) {
+          bool hit = false; uint32_t ia = 0, ib = 0;
+          if (cand) {
+            const uint32_t i = (uint32_t)__ffsll((long long)cand) - 1u;
+            cand &= cand - 1ull;
+            hit = pairHit(p, xmin, xmax, T[2u * i], T[2u * i + 1u], secX, secZ, ia, ib);
           }
-          if (nbig) {
-            const bool mine = has && (__float_as_uint(xmax.w) & kPrimary);
-            const uint32_t xid = __float_as_uint(xmax.w) & ~kPrimary;
-            for (uint32_t b2 = 0; b2 < nbig; ++b2) {
-              const float4 gmin = d.bigList[2u * (size_t)b2], gmax = d.bigList[2u * (size_t)b2 + 1u];
-              const bool hit = mine && boxesOverlap(xmin, xmax, gmin, gmax) && filterPass(__float_as_uint(xmin.w), __float_as_uint(gmin.w));
-              sinkPush(d, p, sink, hit, xid, __float_as_uint(gmax.w));
-            }
+          sinkPush(d, p, sink, hit, ia, ib);
+        }
+        if (jt == 0u && nbig) {                                  // big boxes against this tile's primary copies, once per tile
+          const bool mine = has && (__float_as_uint(xmax.w) & kPrimary);
+          const uint32_t xid = __float_as_uint(xmax.w) & ~kPrimary;
+          for (uint32_t b2 = 0; b2 < nbig; ++b2) {
+            const float4 gmin = d.bigList[2u * (size_t)b2], gmax = d.bigList[2u * (size_t)b2 + 1u];
+            const bool hit = mine && boxesOverlap(xmin, xmax, gmin, gmax) && filterPass(__float_as_uint(xmin.w), __float_as_uint(gmin.w));
+            sinkPush(d, p, sink, hit, xid, __float_as_uint(gmax.w));
           }
         }
       }
-      __builtin_amdgcn_wave_barrier();
-      it = itNext; n = nNext; s = sNext; gxz = gxzNext; binLay = binLayNext; rmin = nmin; rmax = nmax;
     }
   }
 
@@ -1986,6 +1885,7 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
   // each, and the sector's slice bounds follow: two atomics per sector, not per record)
   auto reserve = [&](uint32_t sector, uint32_t c, uint32_t& slot0, uint32_t& q0) {
     slot0 = atomicAdd(&d.binCount[sector], c);
+    if (slot0 <= kBinCap && slot0 + c > kBinCap) queueCrowded(d, p, sector);         // (slot 64 is among the ones this reservation got)
     const uint32_t inBin = slot0 < kBinCap ? (c < kBinCap - slot0 ? c : kBinCap - slot0) : 0u;
     const uint32_t nOver = c - inBin;
     q0 = 0;
@@ -2339,16 +2239,19 @@ void launchStageFrame(const DeviceState& d, uint32_t* block, uint32_t maxVisible
 // evA / evB (both or neither): events that take the kernel's own begin / end timestamps (hipExtLaunchKernelGGL), so the
 // duration bench.py reports is the dispatch's, like the kernel trace's -- not the gap-inclusive span between two
 // hipEventRecord calls on the stream
+template <bool kCull, bool kAabb, uint32_t kChain, uint32_t kHome>
+static void launchHome(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA, hipEvent_t evB)
+{
+  if (evA) hipExtLaunchKernelGGL((k_xform_cull<kCull, kAabb, kChain, kHome>), dim3(grid), dim3(kTile), 0, s, evA, evB, 0, d, p);
+  else hipLaunchKernelGGL((k_xform_cull<kCull, kAabb, kChain, kHome>), dim3(grid), dim3(kTile), 0, s, d, p);
+}
 template <bool kCull, bool kAabb, uint32_t kChain>
 static void launchOne(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA, hipEvent_t evB)
 {
-  if (p.variant & 1u) {                                    // SC_TICK_VARIANT bit 0: round 2's chain walk through memory (A/B)
-    if (evA) hipExtLaunchKernelGGL((k_xform_cull<kCull, kAabb, kChain>), dim3(grid), dim3(kTile), 0, s, evA, evB, 0, d, p);
-    else hipLaunchKernelGGL((k_xform_cull<kCull, kAabb, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
-    return;
-  }
-  if (evA) hipExtLaunchKernelGGL((k_xform_cull_lds<kCull, kAabb, kChain>), dim3(grid), dim3(kTile), 0, s, evA, evB, 0, d, p);
-  else hipLaunchKernelGGL((k_xform_cull_lds<kCull, kAabb, kChain>), dim3(grid), dim3(kTile), 0, s, d, p);
+  // the bins' home slots: an instance per mode, and only where boxes are binned at all
+  if (!kAabb || p.homeMode == kHomeOff) launchHome<kCull, kAabb, kChain, kHomeOff>(d, p, grid, s, evA, evB);
+  else if (p.homeMode == kHomeUse) launchHome<kCull, kAabb, kChain, kHomeUse>(d, p, grid, s, evA, evB);
+  else launchHome<kCull, kAabb, kChain, kHomeLearn>(d, p, grid, s, evA, evB);
 }
 template <uint32_t kChain>
 static void launchXformCullChain(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA, hipEvent_t evB)
