@@ -1873,7 +1873,7 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
   const uint32_t bigHead0 = big[0], bigHead1 = big[1];
   const uint32_t lane = threadIdx.x & 63u;
   // One record to its place: slot `slot` of the sector's bin, or entry q of the sector overflow list when the bin is full.
-  auto place = [&](uint32_t sector, uint32_t slot, uint32_t q, const float4& lo, const float4& hi) {
+  auto place = [&](uint32_t sector, uint32_t slot, uint32_t q, const float4& lo, const float4& hi) __attribute__((always_inline)) {
     if (slot < kBinCap) {
       float4* dst = d.bins + 2u * ((size_t)sector * kBinCap + slot);
       dst[0] = lo; dst[1] = hi;
@@ -1883,7 +1883,7 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
   };
   // reserve room for c records of one landing sector: bin slots first, the rest in the sector overflow list (ONE reservation
   // each, and the sector's slice bounds follow: two atomics per sector, not per record)
-  auto reserve = [&](uint32_t sector, uint32_t c, uint32_t& slot0, uint32_t& q0) {
+  auto reserve = [&](uint32_t sector, uint32_t c, uint32_t& slot0, uint32_t& q0) __attribute__((always_inline)) {
     slot0 = atomicAdd(&d.binCount[sector], c);
     if (slot0 <= kBinCap && slot0 + c > kBinCap) queueCrowded(d, p, sector);         // (slot 64 is among the ones this reservation got)
     const uint32_t inBin = slot0 < kBinCap ? (c < kBinCap - slot0 ? c : kBinCap - slot0) : 0u;
@@ -1895,8 +1895,8 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
     }
     // (record r goes to slot0 + r while that is below the bin's capacity, else to list entry q0 + (slot0 + r - max(slot0, 64)))
   };
-  constexpr uint32_t kSerial = 4;                          // a sector's records up to this many are landed by its own thread
-  auto landBin = [&](uint32_t l, uint32_t off, uint32_t c) {
+  constexpr uint32_t kSerial = 24;                         // a sector's records up to this many are landed by its own thread (the wave-wide path costs a few round trips per sector: it is for crowded sectors, not for bins with five records)
+  auto landBin = [&](uint32_t l, uint32_t off, uint32_t c) __attribute__((always_inline)) {
     // the sender's ring cell l on its side (-dx,-dz) is this tile's cell l along its own side (dx,dz)
     const uint32_t sector = landingCell(p, dx, dz, l);
     const float4* src = records + 2u * (size_t)off;
@@ -1912,7 +1912,7 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
     if (lay) atomicOr(&d.binLayers[sector], lay);
   };
   // crowded landing sectors: the wave lands them one after the other, a record per lane and round
-  auto landCrowded = [&](uint32_t l, uint32_t off, uint32_t c, bool mine) {
+  auto landCrowded = [&](uint32_t l, uint32_t off, uint32_t c, bool mine) __attribute__((always_inline)) {
     unsigned long long todo = ballot64(mine);
     while (todo) {
       const int srcLane = __ffsll((long long)todo) - 1;
@@ -1935,7 +1935,12 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
       if (lane == 0 && lay) atomicOr(&d.binLayers[sector], lay);
     }
   };
+  // Two passes over the message's bins: the first lands the usual ones -- up to kSerial records, each bin by its own thread --,
+  // the second, which exists only when some bin holds more, lands those a wave at a time.  (kSerial was 4 at first: ring bins
+  // of the usual world hold 0-3 records but now and then five or six, and every such bin then cost its wave a few round trips of
+  // the wave-wide path -- the kernel took 23 instead of 10 us, the in-order tile step 89 instead of 73.)
   uint32_t carry = 0;
+  bool anyCrowded = false;
   for (uint32_t base = 0; base < L; base += 2u * kTile) {
     const uint32_t l0 = base + 2u * threadIdx.x, l1 = l0 + 1u;
     // (counts are what a neighbour wrote: held to what a sector can hold whatever arrives)
@@ -1946,9 +1951,22 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
     const bool ok0 = c0 && off0 + c0 <= recCap, ok1 = c1 && off0 + c0 + c1 <= recCap;
     if (ok0 && c0 <= kSerial) landBin(l0, off0, c0);
     if (ok1 && c1 <= kSerial) landBin(l1, off0 + c0, c1);
-    landCrowded(l0, off0, c0, ok0 && c0 > kSerial);
-    landCrowded(l1, off0 + c0, c1, ok1 && c1 > kSerial);
+    anyCrowded = anyCrowded || (ok0 && c0 > kSerial) || (ok1 && c1 > kSerial);
     carry = total;
+  }
+  if (__syncthreads_or(anyCrowded ? 1 : 0)) {
+    carry = 0;
+    for (uint32_t base = 0; base < L; base += 2u * kTile) {
+      const uint32_t l0 = base + 2u * threadIdx.x, l1 = l0 + 1u;
+      const uint32_t c0 = l0 < L ? min(msg[kBorderHeader + l0], kSectorRecMax) : 0u, c1 = l1 < L ? min(msg[kBorderHeader + l1], kSectorRecMax) : 0u;
+      uint32_t total;
+      const uint32_t off0 = blockScanExclusive(c0 + c1, carry, sWave, &total);
+      const uint32_t recCap = borderRecCap(L, p.borderRecs);
+      const bool ok0 = c0 && off0 + c0 <= recCap, ok1 = c1 && off0 + c0 + c1 <= recCap;
+      landCrowded(l0, off0, c0, ok0 && c0 > kSerial);
+      landCrowded(l1, off0 + c0, c1, ok1 && c1 > kSerial);
+      carry = total;
+    }
   }
   // the neighbour's big boxes that reach this tile join the big list behind this tile's own
   const uint32_t m = bigHead0 < kBorderBigCap ? bigHead0 : kBorderBigCap;
