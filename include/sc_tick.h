@@ -340,7 +340,7 @@ int scTickSetTrafficSpeedMultiplier(ScTickContext* ctx, float multiplier);
 /* TrafficLODSystem's tier selection (src/engine/traffic/sc_traffic_lod.cpp:269-274 threshold repair, :303-307 xz distance to
  * the player, :323-353 hysteresis, :355-417 the physics / kinematic caps -- candidates sorted by distance, descending, equal
  * distances in pool order, everything past the cap demoted): every agent's TrafficVehicle::mode becomes its desired tier.
- * The total cap and the despawn behind it (:419-465) are streaming and stay with the caller. */
+ * The total cap (:419-465) is scTickSelectTrafficDespawns below; the despawn itself stays with the caller. */
 typedef struct ScTickTierParams     /* TrafficDebugState, sc_traffic_common.h:67-75 */
 {
   float tier_a_enter, tier_a_exit, tier_b_enter, tier_b_exit;   /* 50 / 70 / 110 / 150 m */
@@ -348,6 +348,13 @@ typedef struct ScTickTierParams     /* TrafficDebugState, sc_traffic_common.h:67
 } ScTickTierParams;
 typedef struct ScTickTierCounts { uint32_t physics, kinematic, on_rails, total; } ScTickTierCounts;   /* tierPhysics / tierKinematic / tierOnRails / totalVehicles */
 int scTickSelectTrafficTiers(ScTickContext* ctx, const float player_pos[3], const ScTickTierParams* params, ScTickTierCounts* out);
+/* The total cap behind the tier selection (sc_traffic_lod.cpp:419-465): with more vehicles than max_total
+ * (TrafficDebugState::maxTrafficVehiclesTotal; 0 = no cap) the surplus is picked for despawning -- vehicles of the OnRails tier
+ * first, then Kinematic, then Physics (the tiers as scTickSelectTrafficTiers left them), the farthest from the player first inside
+ * a tier, equal distances in pool order.  *count = how many must go; their dense indices come back in that order (as many as
+ * capacity holds).  The despawn itself is the caller's: scTickRemoveEntities. */
+int scTickSelectTrafficDespawns(ScTickContext* ctx, const float player_pos[3], uint32_t max_total,
+                                uint32_t* dense_indices, uint32_t capacity, uint32_t* count);
 
 /* The renderer's draw order (VkRenderer::recordCommandBuffer, src/engine/src/sc_vk.cpp:1842-1864): draws whose
  * mesh handle is >= mesh_count or whose material handle has no Material are skipped, the rest sorted by

@@ -129,6 +129,8 @@ def lib():
     L.orc_traffic_front_ray_brakes.argtypes = [vp, F32P, F32P, U32P, U32P, U8P, U8P, C.c_float, C.c_float, F32P]
     L.orc_lanes_query_nearest.argtypes = [vp, F32P, U32P, F32P]
     L.orc_lanes_query_nearest.restype = C.c_int
+    L.orc_traffic_lod_despawns.argtypes = [vp, U8P, U8P, F32P, C.c_uint32, U32P]
+    L.orc_traffic_lod_despawns.restype = C.c_uint32
     L.orc_traffic_lod_tiers.argtypes = [vp, U8P, U8P, F32P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, U8P, U32P]
     _LIB = L
     return L
@@ -421,6 +423,14 @@ class OracleWorld:
         assert lane_id.dtype == np.uint32 and lane_s.dtype == np.float32 and target_speed.dtype == np.float32
         self.L.orc_traffic_ai_onrails_braked(self.w, lanes.g, ia.ctypes.data_as(U8P), _u(lane_id), _f(lane_s), _f(target_speed),
                                              md.ctypes.data_as(U8P), _f(la), None if br is None else _f(br), float(speed_multiplier), float(dt))
+
+    def traffic_lod_despawns(self, is_agent, mode, player_pos, max_total):
+        """dense indices TrafficLODSystem's total cap flags for despawning, in flagging order (sc_traffic_lod.cpp:419-465)"""
+        ia, md = np.ascontiguousarray(is_agent, np.uint8), np.ascontiguousarray(mode, np.uint8)
+        pp = _c32(player_pos)
+        out = np.zeros(max(int(ia.sum()), 1), np.uint32)
+        k = self.L.orc_traffic_lod_despawns(self.w, ia.ctypes.data_as(U8P), md.ctypes.data_as(U8P), _f(pp), int(max_total), _u(out))
+        return out[:k].copy()
 
     def traffic_lod_tiers(self, is_agent, mode, player_pos, a_enter=50.0, a_exit=70.0, b_enter=110.0, b_exit=150.0, max_physics=24, max_kinematic=64):
         ia, md = np.ascontiguousarray(is_agent, np.uint8), np.ascontiguousarray(mode, np.uint8)

@@ -216,6 +216,9 @@ void     orc_traffic_lod_tiers(OrcWorld* w, const uint8_t* isAgent, const uint8_
                                float tierAEnter, float tierAExit, float tierBEnter, float tierBExit,
                                uint32_t maxPhysics, uint32_t maxKinematic, uint8_t* desiredOut, uint32_t counts[3]);
 
+/* the total cap behind it (sc_traffic_lod.cpp:419-465): dense indices flagged for despawning, in flagging order; returns their number */
+uint32_t orc_traffic_lod_despawns(OrcWorld* w, const uint8_t* isAgent, const uint8_t* mode, const float playerPos[3], uint32_t maxTotal, uint32_t* outIdx);
+
 /* ---- whole-tick convenience for the cpu_baseline leg: Transform + Camera + Culling ---- */
 void orc_tick(OrcWorld* w, OrcCameraState* cam, OrcCullingState* cull);
 

@@ -459,3 +459,46 @@ void orc_traffic_lod_tiers(OrcWorld* w, const uint8_t* isAgent, const uint8_t* m
   counts[0] = physicsCount; counts[1] = kinematicCount; counts[2] = onRailsCount;
   free(idx); free(dist); free(des); free(sel);
 }
+
+/* The total cap of TrafficLODSystem, sc_traffic_lod.cpp:419-465: with more vehicles than maxTotal the surplus is flagged for
+ * despawning -- the OnRails bucket sorted by distance descending first, then the Kinematic one, then the Physics one (std::sort
+ * there: order of equal distances unspecified; here they keep their pool order, one of the orders it may produce).  `mode` is
+ * the tier of every vehicle after the caps (what `desired` holds at that point).  Returns how many are flagged; outIdx receives
+ * their dense indices in flagging order. */
+uint32_t orc_traffic_lod_despawns(OrcWorld* w, const uint8_t* isAgent, const uint8_t* mode, const float playerPos[3], uint32_t maxTotal, uint32_t* outIdx)
+{
+  const OrcTransform* d = orc_transform_dense_data(w);
+  const uint32_t n = orc_transform_count(w);
+  uint32_t m = 0;
+  for (uint32_t i = 0; i < n; ++i) if (isAgent[i]) m++;
+  if (maxTotal == 0 || m <= maxTotal) return 0;
+  uint32_t toRemove = m - maxTotal, flagged = 0;
+  uint32_t* idx = xr(NULL, (size_t)m * 4u); float* dist = xr(NULL, (size_t)m * 4u); uint32_t* sel = xr(NULL, (size_t)m * 4u);
+  m = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!isAgent[i]) continue;
+    const float dx = d[i].localPos[0] - playerPos[0], dz = d[i].localPos[2] - playerPos[2];
+    idx[m] = i; dist[m++] = sqrtf(dx * dx + dz * dz);
+  }
+  const uint8_t order[3] = { 2u, 1u, 0u };                                      /* OnRails, Kinematic, Physics */
+  for (int b = 0; b < 3 && toRemove > 0; ++b) {
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < m; ++k) if (mode[idx[k]] == order[b]) sel[c++] = k;
+    /* stable merge sort by distance, descending (buckets hold up to every vehicle: no quadratic insertion here) */
+    uint32_t* tmp = xr(NULL, (size_t)(c ? c : 1) * 4u);
+    for (uint32_t width = 1; width < c; width *= 2u) {
+      for (uint32_t lo = 0; lo < c; lo += 2u * width) {
+        const uint32_t mid = lo + width < c ? lo + width : c, hi = lo + 2u * width < c ? lo + 2u * width : c;
+        uint32_t a = lo, bb = mid, o = lo;
+        while (a < mid && bb < hi) tmp[o++] = (dist[sel[bb]] > dist[sel[a]]) ? sel[bb++] : sel[a++];
+        while (a < mid) tmp[o++] = sel[a++];
+        while (bb < hi) tmp[o++] = sel[bb++];
+      }
+      memcpy(sel, tmp, (size_t)c * 4u);
+    }
+    free(tmp);
+    for (uint32_t k = 0; k < c && toRemove > 0; ++k) { outIdx[flagged++] = idx[sel[k]]; toRemove--; }
+  }
+  free(idx); free(dist); free(sel);
+  return flagged;
+}

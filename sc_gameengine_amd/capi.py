@@ -143,6 +143,7 @@ SYMBOLS = {
     "scTickSetTrafficSensors": (C.c_int, [_CTX, C.c_int, C.c_float, C.c_float]),
     "scTickReadTrafficBrakes": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
     "scTickSelectTrafficTiers": (C.c_int, [_CTX, F32P, C.POINTER(TierParams), C.POINTER(TierCounts)]),
+    "scTickSelectTrafficDespawns": (C.c_int, [_CTX, F32P, C.c_uint32, U32P, C.c_uint32, U32P]),
     "scTickSetViewProj": (C.c_int, [_CTX, F32P]),
     "scTickSetFrustumPlanes": (C.c_int, [_CTX, F32P, C.c_int]),
     "scTickGetFrustumPlanes": (C.c_int, [_CTX, F32P, C.POINTER(C.c_int)]),

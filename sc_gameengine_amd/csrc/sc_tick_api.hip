@@ -2080,6 +2080,38 @@ int scTickSelectTrafficTiers(ScTickContext* c, const float playerPos[3], const S
   return 1;
 }
 
+int scTickSelectTrafficDespawns(ScTickContext* c, const float playerPos[3], uint32_t maxTotal, uint32_t* denseIndices, uint32_t capacity, uint32_t* count)
+{
+  if (!c || !playerPos || !count) return c ? fail(c, "null argument") : 0;
+  *count = 0;
+  if (!bind(c) || !flushLinks(c)) return 0;
+  if (!c->d.aLane) return fail(c, "no traffic agents uploaded");
+  if (maxTotal == 0 || !c->n) return 1;                                  // dbg.maxTrafficVehiclesTotal == 0: no cap (:421)
+  // every agent with its ordering key, then the top of the order on the host (the list is short-lived scratch)
+  uint32_t* dCount = nullptr; uint32_t* dIdx = nullptr; unsigned long long* dKey = nullptr;
+  if (!dalloc(c, dCount, 4) || !dalloc(c, dIdx, c->n, false) || !dalloc(c, dKey, c->n, false)) return 0;
+  launchTrafficDespawnKeys(c->d, c->n, playerPos[0], playerPos[2], dCount, dIdx, dKey, c->stream);
+  uint32_t agents = 0;
+  int ok = d2h(c, &agents, dCount, sizeof agents) && sync(c);
+  std::vector<uint32_t> idx; std::vector<unsigned long long> key;
+  if (ok && agents > maxTotal) {
+    idx.resize(agents); key.resize(agents);
+    ok = d2h(c, idx.data(), dIdx, (size_t)agents * 4u) && d2h(c, key.data(), dKey, (size_t)agents * 8u) && sync(c);
+  }
+  dfree(c, dCount); dfree(c, dIdx); dfree(c, dKey);
+  if (!ok) return 0;
+  if (agents <= maxTotal) return 1;
+  const uint32_t toRemove = agents - maxTotal;
+  std::vector<uint32_t> order(agents);
+  for (uint32_t k = 0; k < agents; ++k) order[k] = k;
+  // OnRails before Kinematic before Physics, the farthest first; equal keys in pool order (std::sort there leaves it unspecified)
+  auto before = [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] > key[b] : idx[a] < idx[b]; };
+  std::partial_sort(order.begin(), order.begin() + toRemove, order.end(), before);
+  *count = toRemove;
+  for (uint32_t k = 0; k < toRemove && k < capacity && denseIndices; ++k) denseIndices[k] = idx[order[k]];
+  return 1;
+}
+
 // ---- the border exchange, owned by the library -------------------------------------------------------------------
 static const RcclApi* needRccl(ScTickContext* c)
 {

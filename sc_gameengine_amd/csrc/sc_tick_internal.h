@@ -249,6 +249,7 @@ void launchAdvanceMovers(const DeviceState& d, uint32_t n, float dt, float traff
 struct TierParams { float px, pz, aEnter, aExit, bEnter, bExit; };
 void launchTrafficTiers(const DeviceState& d, uint32_t n, const TierParams& tp, hipStream_t s);
 void launchApplyTiers(const DeviceState& d, uint32_t n, const uint2* patches, uint32_t patchCount, hipStream_t s);
+void launchTrafficDespawnKeys(const DeviceState& d, uint32_t n, float px, float pz, uint32_t* count, uint32_t* outIdx, unsigned long long* outKey, hipStream_t s);
 void launchDenseAabbs(const DeviceState& d, uint32_t n, hipStream_t s);
 void launchSetDirtyRange(const DeviceState& d, uint32_t first, uint32_t count, hipStream_t s);
 void launchSetDirtyIndices(const DeviceState& d, const uint32_t* idx, uint32_t count, hipStream_t s);

@@ -2066,6 +2066,32 @@ __global__ __launch_bounds__(kTile) void k_traffic_tiers(const DeviceState d, ui
   }
 }
 
+// The total cap of TrafficLODSystem (sc_traffic_lod.cpp:419-465): when more vehicles exist than maxTrafficVehiclesTotal the surplus
+// is despawned -- OnRails vehicles first, then Kinematic, then Physics, the farthest first inside a tier.  The device lists every
+// agent with a key that orders exactly so (tier rank in the high word, the bits of its xz distance to the player -- never
+// negative, so they order like the value -- in the low one); the host takes the top of that list (scTickSelectTrafficDespawns).
+__global__ __launch_bounds__(kTile) void k_traffic_despawn_keys(const DeviceState d, uint32_t n, float px, float pz, uint32_t* __restrict__ count,
+                                                                uint32_t* __restrict__ outIdx, unsigned long long* __restrict__ outKey)
+{
+  const uint32_t i = blockIdx.x * kTile + threadIdx.x;
+  const bool agent = i < n && d.moverKind[i] == kMoverTraffic;
+  const unsigned long long m = ballot64(agent);
+  if (!m) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
+  base = __shfl(base, 0, 64);
+  if (agent) {
+    const float dx = d.px[i] - px, dz = d.pz[i] - pz;
+    const float dist = sqrtf(dx * dx + dz * dz);                                   // :303-307, as the tier selection
+    const uint32_t mode = d.aMode[i];
+    const uint32_t rank = mode == kTierOnRails ? 2u : (mode == kTierKinematic ? 1u : 0u);
+    const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    outIdx[at] = i;
+    outKey[at] = ((unsigned long long)rank << 32) | __float_as_uint(dist);
+  }
+}
+
 // TrafficVehicle::mode = the desired tier (applyMode, sc_traffic_lod.cpp:486-487), then the handful the caps changed
 __global__ __launch_bounds__(kTile) void k_apply_tiers(const DeviceState d, uint32_t n)
 {
@@ -2389,6 +2415,11 @@ void launchTrafficTiers(const DeviceState& d, uint32_t n, const TierParams& tp, 
 {
   if (!n || !d.moverKind || !d.aMode) return;
   hipLaunchKernelGGL(k_traffic_tiers, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, tp);
+}
+void launchTrafficDespawnKeys(const DeviceState& d, uint32_t n, float px, float pz, uint32_t* count, uint32_t* outIdx, unsigned long long* outKey, hipStream_t s)
+{
+  if (!n || !d.moverKind || !d.aMode) return;
+  hipLaunchKernelGGL(k_traffic_despawn_keys, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, px, pz, count, outIdx, outKey);
 }
 void launchApplyTiers(const DeviceState& d, uint32_t n, const uint2* patches, uint32_t patchCount, hipStream_t s)
 {

@@ -334,6 +334,16 @@ class WorldTick:
         self._ok(self.lib.scTickSelectTrafficTiers(self.ctx, _f(pp), C.byref(tp), C.byref(out)), "scTickSelectTrafficTiers")
         return out.physics, out.kinematic, out.on_rails
 
+    def select_traffic_despawns(self, player_pos, max_total):
+        """TrafficLODSystem's total cap: dense indices of the vehicles to despawn, in the reference's order"""
+        pp = _c32(player_pos)
+        cnt = C.c_uint32()
+        self._ok(self.lib.scTickSelectTrafficDespawns(self.ctx, _f(pp), int(max_total), None, 0, C.byref(cnt)), "scTickSelectTrafficDespawns")
+        out = np.zeros(max(cnt.value, 1), np.uint32)
+        if cnt.value:
+            self._ok(self.lib.scTickSelectTrafficDespawns(self.ctx, _f(pp), int(max_total), _u(out), cnt.value, C.byref(cnt)), "scTickSelectTrafficDespawns")
+        return out[:cnt.value].copy()
+
     def set_frame_producer(self, kind, param=0.0):
         """0 none, 1 nudge roots by `param`, 2 advance movers by dt=`param`: run() then is the whole frame"""
         self._ok(self.lib.scTickSetFrameProducer(self.ctx, int(kind), float(param)), "scTickSetFrameProducer")

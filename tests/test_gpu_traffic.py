@@ -231,3 +231,28 @@ def test_tier_selection_hysteresis_and_caps(oracle):
         t.advance_movers(DT)
         assert_agents_equal(t, w, st, ow)
     t.close(); ow.close(); ol.close()
+
+
+def test_total_cap_picks_the_farthest_onrails_first_then_kinematic_then_physics(oracle):
+    """TrafficLODSystem's total cap (sc_traffic_lod.cpp:419-465) after a tier selection: the surplus over maxTrafficVehiclesTotal
+    goes tier by tier -- OnRails, Kinematic, Physics --, the farthest first.  Caps that bite into the second and third bucket,
+    a cap above the vehicle count, no cap; the list and its order equal the oracle's."""
+    w = laned_world(12, 12, seed=17)
+    ow, ol, st = oracle_side(oracle, w)
+    t = WorldTick.from_world(w, broadphase=False)
+    a = w.is_agent.astype(bool)
+    player = np.float32([380.0, 0.0, 400.0])
+    want_modes, counts = ow.traffic_lod_tiers(w.is_agent, st["mode"], player, max_physics=0, max_kinematic=0)
+    t.select_traffic_tiers(player, max_physics=0, max_kinematic=0)
+    st["mode"][a] = want_modes[a]
+    total = int(a.sum())
+    assert counts[0] > 3 and counts[1] > 10 and counts[2] > 100
+    for max_total in (0, total + 5, total, total - 1, total - 50, counts[0] + counts[1] + 7, counts[0] + 4, 3, 1):
+        want = ow.traffic_lod_despawns(w.is_agent, st["mode"], player, max_total)
+        got = t.select_traffic_despawns(player, max_total)
+        assert np.array_equal(got, want), f"max_total {max_total}: {len(got)} vs {len(want)}"
+        if max_total and max_total < total:
+            assert len(got) == total - max_total
+            tiers = st["mode"][got]
+            assert (np.diff((2 - tiers.astype(np.int32))) >= 0).all()      # OnRails (2) block, then Kinematic (1), then Physics (0)
+    t.close(); ow.close(); ol.close()

@@ -77,3 +77,32 @@ def test_oracle_on_rails_and_tiers(oracle):
     _, capped = ow.traffic_lod_tiers(w.is_agent, mode, player, max_physics=2, max_kinematic=3)
     assert capped[0] == 2 and capped[1] == 3 and sum(capped) == a.sum()
     ow.close(); ol.close()
+
+
+def test_total_cap_order_against_a_plain_python_restatement(oracle):
+    """orc_traffic_lod_despawns (sc_traffic_lod.cpp:419-465) against the same rule written with Python's stable sort."""
+    import numpy as np
+    from sc_gameengine_amd import synth_world as sw
+    from tests import worlds
+    w = sw.generate_config5(6, 6, laned=True)
+    rng = np.random.default_rng(4)
+    mode = w.agent_mode.copy()
+    agents = np.flatnonzero(w.is_agent)
+    mode[rng.choice(agents, 40, replace=False)] = 1
+    mode[rng.choice(agents, 15, replace=False)] = 0
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    player = np.float32([150.0, 0.0, 170.0])
+    d = np.sqrt(((w.pos[agents, 0] - player[0]) ** 2 + (w.pos[agents, 2] - player[2]) ** 2).astype(np.float32)).astype(np.float32)
+    for max_total in (0, len(agents), len(agents) - 10, 60, 20, 2):
+        got = ow.traffic_lod_despawns(w.is_agent, mode, player, max_total)
+        want = []
+        if max_total and len(agents) > max_total:
+            left = len(agents) - max_total
+            for tier in (2, 1, 0):
+                bucket = [k for k in range(len(agents)) if mode[agents[k]] == tier]
+                bucket.sort(key=lambda k: -float(d[k]))                      # stable: equal distances keep pool order
+                take = bucket[:left]
+                want += [int(agents[k]) for k in take]
+                left -= len(take)
+        assert list(got) == want, f"max_total {max_total}"
+    ow.close()
