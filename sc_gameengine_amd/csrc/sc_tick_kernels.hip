@@ -12,14 +12,6 @@
 #include <hip/hip_ext.h>
 #include "../../include/sc_tick.h"
 
-#ifdef SC_NO_DEFER
-constexpr bool kNoDefer = true;       // A/B: world-matrix stores in place (round 2) instead of behind the bin reservations
-#else
-constexpr bool kNoDefer = false;
-#endif
-#ifndef SC_ABL
-#define SC_ABL 0          // timing ablations of the fused kernel (tools only: results are wrong with any bit set)
-#endif
 
 namespace sctick {
 
@@ -64,11 +56,7 @@ __device__ __forceinline__ void storeStream16(void* p, const float4& v)
 }
 __device__ __forceinline__ void stRow(const DeviceState& d, uint32_t row, uint32_t i, const float4& v)
 {
-#ifdef SC_NT_ROWS
-  storeStream16(d.rslab + (row * d.capBytes16 + i * 16u), v);
-#else
   *reinterpret_cast<float4*>(d.rslab + (row * d.capBytes16 + i * 16u)) = v;
-#endif
 }
 
 // local = T * (R * S) with R = (Rz * Ry) * Rx  (sc_math.cpp:100-142).
@@ -372,16 +360,12 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
       }
     }
     uint32_t base = 0;
-#if SC_ABL & 128
-    if (head && !(SC_ABL & 32)) atomicOr(&d.binLayers[sector], lay);
-#else
-    if (head) { base = atomicAdd(&d.binCount[sector], runEnd - lane); if (!(SC_ABL & 32)) atomicOr(&d.binLayers[sector], lay); }
-#endif
+    if (head) { base = atomicAdd(&d.binCount[sector], runEnd - lane); atomicOr(&d.binLayers[sector], lay); }
     if (storeM) storeRows(d, i, M);
     base = __shfl(base, myHead, 64);
     if (a0) slot = base + (lane - myHead);
   } else if (storeM) storeRows(d, i, M);
-  if (want && slot < kBinCap && !(SC_ABL & 64)) {
+  if (want && slot < kBinCap) {
     float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
     r[0] = rmin; r[1] = rm;
   }
@@ -423,21 +407,15 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
   } else {
     const uint32_t sec1 = sector + 1u, sec2 = sector + p.binSX, sec3 = sec2 + 1u;
     uint32_t q1 = 0, q2 = 0, q3 = 0;
-#if SC_ABL & 256
-    q1 = 17u; q2 = 18u; q3 = 19u;                                  // (timing only: no reservation, fixed slots)
-#else
     if (c1) q1 = atomicAdd(&d.binCount[sec1], 1u);
     if (c2) q2 = atomicAdd(&d.binCount[sec2], 1u);
     if (c3) q3 = atomicAdd(&d.binCount[sec3], 1u);
-#endif
     if (c1 && q1 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec1 * kBinCap + q1); r[0] = rmin; r[1] = rmax; }
     if (c2 && q2 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec2 * kBinCap + q2); r[0] = rmin; r[1] = rmax; }
     if (c3 && q3 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec3 * kBinCap + q3); r[0] = rmin; r[1] = rmax; }
-#if !(SC_ABL & 32)
     if (c1) atomicOr(&d.binLayers[sec1], myLay);
     if (c2) atomicOr(&d.binLayers[sec2], myLay);
     if (c3) atomicOr(&d.binLayers[sec3], myLay);
-#endif
     learned |= ((c1 && q1 < kBinCap ? q1 : kNoSlot) << 8) | ((c2 && q2 < kBinCap ? q2 : kNoSlot) << 16) | ((c3 && q3 < kBinCap ? q3 : kNoSlot) << 24);
     if (ballot64((c1 && q1 >= kBinCap) || (c2 && q2 >= kBinCap) || (c3 && q3 >= kBinCap))) {
       if (c1 && q1 >= kBinCap) spillLane(d, p, sec1, q1, rmin, rmax);
@@ -510,16 +488,8 @@ __device__ __forceinline__ void binEntitySingle(const DeviceState& d, const Tick
 template <bool kCull, bool kAabb, uint32_t kChain, uint32_t kHome>
 __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p);
 
-#ifndef SC_K1_WAVES
-#define SC_K1_WAVES 0
-#endif
-#if SC_K1_WAVES
-#define SC_K1_OCC __attribute__((amdgpu_waves_per_eu(SC_K1_WAVES, SC_K1_WAVES)))
-#else
-#define SC_K1_OCC
-#endif
 template <bool kCull, bool kAabb, uint32_t kChain, uint32_t kHome>
-__global__ __launch_bounds__(kTile) SC_K1_OCC void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, kChain, kHome>(d, p); }
+__global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, kChain, kHome>(d, p); }
 
 template <bool kCull, bool kAabb, uint32_t kChain, uint32_t kHome>
 __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p)
@@ -565,18 +535,11 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
 #pragma unroll
       for (uint32_t k = 1; k <= kChain; ++k) a[k] = i;
     }
-#if SC_ABL & 4
-    if (top > 0) top = 0;
-#endif
     const bool recompute = top >= 0;
 
     Aff M;
     if (recompute) {
-#if SC_ABL & 4
-      const bool fromRoot = true;
-#else
       const bool fromRoot = (uint32_t)top == depth;       // the chain's root itself is rebuilt: world = local
-#endif
       uint32_t seed = i;
 #pragma unroll
       for (uint32_t k = 0; k < kChain; ++k) if ((uint32_t)top == k) seed = a[k + 1];
@@ -590,11 +553,7 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
           else M = mulAff(M, L);
         }
       }
-#if SC_ABL & 1
-      if (M.r0[0] == 12345.678f) storeRows(d, i, M);
-#else
-      if (!kAabb || kNoDefer) storeRows(d, i, M);        // (with binning the store rides behind the bin reservations: binEntityWave)
-#endif
+      if (!kAabb) storeRows(d, i, M);                     // (with binning the store rides behind the bin reservations: binEntityWave)
     } else if ((kCull || kAabb) && active) {
       M = loadRows(d, i);
     }
@@ -615,11 +574,7 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
         if (cand && hb && !p.freeze && p.frustumValid) {
           const float* fr = d.frustum;
           asm volatile("" : "+s"(fr));                 // opaque: keeps the plane loads inside the loop, at their use
-#if SC_ABL & 8
-          visible = M.r0[3] + b.cx > -1e30f;
-#else
           visible = sphereVisibleAt(M, b, (ConstF)fr);
-#endif
         }
         // deeper entities get their matrix (and their bit) from the level kernels
         if (doXform && depth > kChain && depth != kUnreachable) visible = false;
@@ -635,12 +590,7 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
       if (kAabb) {
         // deeper entities are binned by the level kernels once their matrix is final
         const bool collider = hb && !(doXform && depth > kChain && depth != kUnreachable);
-#if SC_ABL & 2
-        if (M.r1[3] + b.cy == 12345.678f) binEntityWave<kHome>(d, p, i, collider, M, b, false);
-        if (recompute) storeRows(d, i, M);
-#else
-        binEntityWave<kHome>(d, p, i, collider, M, b, recompute && !(SC_ABL & 1) && !kNoDefer);
-#endif
+        binEntityWave<kHome>(d, p, i, collider, M, b, recompute);
       }
     }
   }
