@@ -96,6 +96,7 @@ struct ScTickContext
   bool lastTickLearn = false;                          // the last scTickRun was a learn tick of the home slots (ran eagerly)
   // home slots of the bins (binEntityWave): remembered at a learn tick, used until the world's shape changes or they age
   bool homeEnabled = true, homeValid = false, homeCountsLive = false;
+  bool lazyEnabled = true;                             // lazy records (DeviceState::lazyCtl)
   uint64_t homeEpoch = ~0ull; uint32_t homeAge = 0, homePeriod = 64;
   bool capturing = false;                              // enqueueStages runs inside a stream capture
   bool packedRides = false;                            // this tick's `packed` event was attached to the compaction + pack dispatch
@@ -171,7 +172,9 @@ bool dalloc(ScTickContext* c, T*& p, size_t count, bool zero = true)
   const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
   hipError_t e = hipMalloc(&v, bytes);
   if (e != hipSuccess) return fail(c, "hipMalloc", e);
-  if (zero) { e = hipMemset(v, 0, bytes); if (e != hipSuccess) return fail(c, "hipMemset", e); }
+  // (the tick stream is non-blocking, i.e. not ordered against the null stream this memset runs on, and a memset of device memory may
+  //  return before it is done: wait for it, so that whatever is enqueued next sees the zeros -- allocations are rare)
+  if (zero) { e = hipMemset(v, 0, bytes); if (e == hipSuccess) e = hipStreamSynchronize(nullptr); if (e != hipSuccess) return fail(c, "hipMemset", e); }
   c->allocs.push_back(v);
   p = static_cast<T*>(v);
   return true;
@@ -496,7 +499,7 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     if (p.homeMode == kHomeLearn) {
       // the slots handed out by the fused kernel are the remembered ones (the level kernels' and the neighbours' records reserve
       // behind them on every tick); the other copies of the bins start their next tick from the same counts
-      launchSnapshotHome(ds, c->sectors, c->stream);
+      launchSnapshotHome(ds, c->sectors, c->n, p.binSX, p.binSZ, c->stream);
       if (c->pairsStream)
         for (uint32_t q = 0; q < c->pipeDepth; ++q) {
           if (q == p.parity) continue;
@@ -672,9 +675,10 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
             && dalloc(c, d.ovfIdx, (size_t)kOvfWaves * kOvfPerSector, false) && dalloc(c, d.ovfLo, c->sectors, false) && dalloc(c, d.ovfHi, c->sectors)
             && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, (kMaxParity + 1u) * kPairShards * kShardStride)
             && dalloc(c, c->dPairsOut, c->maxPairs, false) && dalloc(c, c->dPairTotal, 4)
-            && dalloc(c, d.homeA, N, false) && dalloc(c, d.homeB, N, false) && dalloc(c, d.homeCount, c->sectors) && dalloc(c, d.homeLayers, c->sectors);
+            && dalloc(c, d.homeA, N, false) && dalloc(c, d.homeB, N, false) && dalloc(c, d.homeCount, c->sectors) && dalloc(c, d.homeLayers, c->sectors) && dalloc(c, d.lazyCtl, 4);
     if (ok) { e = hipMemset(d.homeA, 0xFF, N * sizeof(uint32_t)); if (e == hipSuccess) e = hipMemset(d.homeB, 0xFF, N * sizeof(uint32_t)); if (e != hipSuccess) ok = fail(c, "hipMemset", e); }
   }
+  if (c->variant & 32u) c->lazyEnabled = false;         // SC_TICK_VARIANT bit 5: every remembered slot is written on every tick (A/B)
   if (c->variant & 2u) c->homeEnabled = false;          // SC_TICK_VARIANT bit 1: every record reserves its slot on every tick (A/B)
   if (const char* hp = std::getenv("SC_TICK_HOME_PERIOD")) { const int v = std::atoi(hp); if (v > 0) c->homePeriod = (uint32_t)v; }
   if (ok && c->sectors) { e = hipMemset(d.ovfLo, 0xFF, (size_t)c->sectors * sizeof(uint32_t)); if (e != hipSuccess) ok = fail(c, "hipMemset", e); }
@@ -1216,6 +1220,9 @@ int scTickRun(ScTickContext* c, uint32_t flags)
       c->homeValid = true; c->homeEpoch = c->topoEpoch; c->homeAge = 0; c->lastTickLearn = true;
     } else { p.homeMode = kHomeUse; c->homeAge++; }
     p.homeReset = 1u;
+    // lazy records: only while nothing but this tick's own pair search reads the bins, and that search runs before the next
+    // tick rewrites the world matrices (it rebuilds unwritten records from them)
+    p.lazy = (p.homeMode == kHomeUse && c->lazyEnabled && !c->pairsStream && !(flags & SC_TICK_RAYS) && !c->sensors) ? 1u : 0u;
     c->homeCountsLive = true;
   }
   if ((flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_SPLIT_PAIRS) && c->neighbourMask) {
@@ -2089,7 +2096,9 @@ int scTickSelectTrafficDespawns(ScTickContext* c, const float playerPos[3], uint
   if (maxTotal == 0 || !c->n) return 1;                                  // dbg.maxTrafficVehiclesTotal == 0: no cap (:421)
   // every agent with its ordering key, then the top of the order on the host (the list is short-lived scratch)
   uint32_t* dCount = nullptr; uint32_t* dIdx = nullptr; unsigned long long* dKey = nullptr;
-  if (!dalloc(c, dCount, 4) || !dalloc(c, dIdx, c->n, false) || !dalloc(c, dKey, c->n, false)) return 0;
+  if (!dalloc(c, dCount, 4, false) || !dalloc(c, dIdx, c->n, false) || !dalloc(c, dKey, c->n, false)) return 0;
+  // (zeroed on the tick stream itself: a hipMemset on the null stream is not ordered against a non-blocking stream)
+  if (hipMemsetAsync(dCount, 0, 4 * sizeof(uint32_t), c->stream) != hipSuccess) { dfree(c, dCount); dfree(c, dIdx); dfree(c, dKey); return fail(c, "hipMemsetAsync"); }
   launchTrafficDespawnKeys(c->d, c->n, playerPos[0], playerPos[2], dCount, dIdx, dKey, c->stream);
   uint32_t agents = 0;
   int ok = d2h(c, &agents, dCount, sizeof agents) && sync(c);

@@ -105,6 +105,11 @@ struct DeviceState {
   uint32_t* homeB;             // [cap] four 8-bit slots: the copies in sectors homeA + {0, 1, binSX, binSX + 1}; 0xFF = no reservation
   uint32_t* homeCount;         // [sectors] slots of each bin that are reserved: what binCount starts a tick from
   uint32_t* homeLayers;        // [sectors] OR of the reserved records' layer words: what binLayers starts a tick from
+  // Lazy records (round 3): a bin whose reserved records cannot pass the group/mask filter against each other is read by the
+  // pair search only when a record from elsewhere arrives that can -- so its owners do not write it (homeB bit 6 of a slot
+  // byte = "write every tick"), and the wave that does need such a bin rebuilds its records from the owners' matrices.
+  uint32_t* lazyCtl;           // [0] big boxes of the last pair search (!= 0: the next fused kernel writes every record),
+                               // [1] 1 = the last fused kernel wrote every reserved record (what its pair search goes by)
   float4* bigList;             // [cap][2] boxes that cannot be binned (too large, outside the rect, bin full)
   float4* spill;               // [ovfCap][2] sector OVERFLOW list: records that found their sector bin full -- this tile's own
                                // (fused kernel) and the neighbours' border records (merge) alike ...
@@ -153,6 +158,8 @@ constexpr uint32_t kCtrPar = 8, kCtrPairs = 0, kCtrBig = 1, kCtrBinFull = 2, kCt
 constexpr uint32_t kCtrCrowdTail = 6, kCtrCrowdHead = 7;     // crowded sectors queued by the binning / taken by the pair search (reset with the parity's counters)
 constexpr uint32_t kHomeOff = 0, kHomeLearn = 1, kHomeUse = 2;
 constexpr uint32_t kNoHome = 0xFFFFFFFFu, kNoSlot = 0xFFu;
+constexpr uint32_t kHomeHot = 0x80000000u;                         // homeCount: the bin was rebuilt since the learn tick, its owners write it again
+constexpr uint32_t kSlotMask = 0x3Fu, kSlotAlways = 0x40u;     // a homeB slot byte: slot in the bin, "written on every tick" (lazy records)
 // Tick "parity": which copy of the per-tick broadphase state a tick works on.  The in-order flows alternate between two
 // copies; pipelined tiles rotate through `depth` (2..kMaxParity) copies, so that the pair half of tick t may still run while
 // the fused kernels of ticks t+1 .. t+depth-1 refill the others.
@@ -187,6 +194,8 @@ struct TickParams {
                             // 2 records with a remembered slot are stored there directly (kHome*)
   uint32_t homeReset;       // the pair search leaves binCount / binLayers at homeCount / homeLayers instead of zero
   uint32_t borderRecs;      // border messages: records per ring sector of a side, on average (scTickSetBorderCapacity; kBorderRecsPerBin)
+  uint32_t lazy;            // kHomeUse ticks: reserved records of bins that cannot produce a pair may be left unwritten (DeviceState::lazyCtl);
+                            // 0 when something else reads the bins (ray queries, traffic sensors) or the pair half runs pipelined
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d
 __host__ __device__ inline void borderDir(uint32_t d, int& dx, int& dz) { const uint32_t k = d < 4 ? d : d + 1; dx = (int)(k % 3) - 1; dz = (int)(k / 3) - 1; }
@@ -234,7 +243,7 @@ void launchOccupancy(const DeviceState& d, uint32_t n, const float4* q, uint32_t
 
 // launchers (sc_tick_kernels.hip)
 void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA = nullptr, hipEvent_t evB = nullptr);
-void launchSnapshotHome(const DeviceState& d, uint32_t sectors, hipStream_t s);
+void launchSnapshotHome(const DeviceState& d, uint32_t sectors, uint32_t n, uint32_t binSX, uint32_t binSZ, hipStream_t s);
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 bool launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s, hipEvent_t done = nullptr);

@@ -262,10 +262,23 @@ __device__ __forceinline__ void binInsertLane(const DeviceState& d, const TickPa
 }
 
 // a record that overlaps nothing and passes no filter: a remembered bin slot whose copy does not exist this tick; padding of a border message
-__device__ __forceinline__ void nullRecord(float4& lo, float4& hi)
+__device__ __forceinline__ void nullRecord(float4& lo, float4& hi, uint32_t id = 0x00FFFFFFu)
 {
   lo = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0u));
-  hi = make_float4(-INFINITY, -INFINITY, -INFINITY, __uint_as_float(0x00FFFFFFu));
+  hi = make_float4(-INFINITY, -INFINITY, -INFINITY, __uint_as_float(id));
+}
+
+// Lazy records.  The pair search reads a bin only if two of its records can pass the group/mask filter against each other
+// (or a big box is about); in a city most bins hold static props only, which never do.  The records a bin's OWNERS keep in
+// their remembered slots (home slots, below) have a layer summary that is known from the learn tick on -- homeLayers -- so
+// when that summary admits no pair, the owners do not write their records at all on the ticks in between: nothing would read
+// them.  If a record from elsewhere then makes such a bin admissible after all (a vehicle drives in; a big box appears), the
+// wave that searches the bin rebuilds the owners' records from their world matrices (rebuildHomeRecord: the arithmetic of
+// binEntityWave) -- rare, and only where it is needed.  Ring sectors are always written: the border pack copies them.
+__device__ __forceinline__ bool binWrittenEveryTick(uint32_t homeLayers, uint32_t sector, uint32_t binSX, uint32_t binSZ)
+{
+  const uint32_t gx = sector % binSX, gz = sector / binSX;
+  return ((homeLayers & 0xFFFFu) & (homeLayers >> 16)) != 0u || gx == 0u || gz == 0u || gx + 1u == binSX || gz + 1u == binSZ;
 }
 
 // Whole-wave broadphase step for one entity per lane: world AABB -> bins / big list.
@@ -308,7 +321,7 @@ __device__ __forceinline__ void spillLane(const DeviceState& d, const TickParams
 // Same records in the same bins -- the pair search sees a few null records more, which pass no filter and overlap nothing.
 template <uint32_t kHome>
 __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickParams& p, uint32_t i, bool collider,
-                                              const Aff& M, const BoundsCE& b, bool storeM)
+                                              const Aff& M, const BoundsCE& b, bool storeM, bool lazyOn)
 {
   float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
   BinPlan plan; plan.collide = false; plan.big = false; plan.x0 = plan.z0 = 0.0f; plan.nx = plan.nz = 0;
@@ -329,7 +342,9 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
   const bool atHome = want && hA == sector;
   const bool r0 = atHome && (hB & 0xFFu) != kNoSlot;
   const bool a0 = want && !r0;                                     // the primary copy reserves its slot
-  uint32_t slot = hB & 0xFFu;
+  uint32_t slot = hB & kSlotMask;
+  // lazy records: a remembered slot of a bin that cannot produce a pair is not written (binWrittenEveryTick)
+  const bool skip0 = r0 && lazyOn && !(hB & kSlotAlways);
   float4 rm = rmax;
   rm.w = __uint_as_float(i | p.rankBits | kPrimary);
   const uint32_t myLay = __float_as_uint(rmin.w);
@@ -365,7 +380,7 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
     base = __shfl(base, myHead, 64);
     if (a0) slot = base + (lane - myHead);
   } else if (storeM) storeRows(d, i, M);
-  if (want && slot < kBinCap) {
+  if (want && slot < kBinCap && !skip0) {
     float4* r = d.bins + 2u * ((size_t)sector * kBinCap + slot);
     r[0] = rmin; r[1] = rm;
   }
@@ -378,14 +393,18 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
     // (the reservations of the copies that have no remembered slot -- boxes that entered a sector, crowded bins -- are issued
     //  together and waited for once, like on the other ticks: one after the other they cost config 5's fused kernel 2.3 us)
     const uint32_t sec1 = sector + 1u, sec2 = sector + p.binSX, sec3 = sec2 + 1u;
-    uint32_t q1 = (hB >> 8) & 0xFFu, q2 = (hB >> 16) & 0xFFu, q3 = hB >> 24;
-    const bool a1 = c1 && !(atHome && q1 != kNoSlot), a2 = c2 && !(atHome && q2 != kNoSlot), a3 = c3 && !(atHome && q3 != kNoSlot);
+    const uint32_t b1 = (hB >> 8) & 0xFFu, b2 = (hB >> 16) & 0xFFu, b3 = hB >> 24;
+    uint32_t q1 = b1 & kSlotMask, q2 = b2 & kSlotMask, q3 = b3 & kSlotMask;
+    const bool h1 = atHome && b1 != kNoSlot, h2 = atHome && b2 != kNoSlot, h3 = atHome && b3 != kNoSlot;    // remembered
+    const bool a1 = c1 && !h1, a2 = c2 && !h2, a3 = c3 && !h3;
+    const bool w1 = c1 && !(h1 && lazyOn && !(b1 & kSlotAlways)), w2 = c2 && !(h2 && lazyOn && !(b2 & kSlotAlways)),
+               w3 = c3 && !(h3 && lazyOn && !(b3 & kSlotAlways));
     if (a1) q1 = atomicAdd(&d.binCount[sec1], 1u);
     if (a2) q2 = atomicAdd(&d.binCount[sec2], 1u);
     if (a3) q3 = atomicAdd(&d.binCount[sec3], 1u);
-    if (c1 && q1 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec1 * kBinCap + q1); r[0] = rmin; r[1] = rmax; }
-    if (c2 && q2 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec2 * kBinCap + q2); r[0] = rmin; r[1] = rmax; }
-    if (c3 && q3 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec3 * kBinCap + q3); r[0] = rmin; r[1] = rmax; }
+    if (w1 && q1 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec1 * kBinCap + q1); r[0] = rmin; r[1] = rmax; }
+    if (w2 && q2 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec2 * kBinCap + q2); r[0] = rmin; r[1] = rmax; }
+    if (w3 && q3 < kBinCap) { float4* r = d.bins + 2u * ((size_t)sec3 * kBinCap + q3); r[0] = rmin; r[1] = rmax; }
     if (a1) atomicOr(&d.binLayers[sec1], myLay);
     if (a2) atomicOr(&d.binLayers[sec2], myLay);
     if (a3) atomicOr(&d.binLayers[sec3], myLay);
@@ -394,14 +413,17 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
       if (a2 && q2 >= kBinCap) spillLane(d, p, sec2, q2, rmin, rmax);
       if (a3 && q3 >= kBinCap) spillLane(d, p, sec3, q3, rmin, rmax);
     }
-    // remembered slots whose copy does not exist this tick: the owner writes a null record there
+    // remembered slots whose copy does not exist this tick: the owner writes a null record there (under its own id: whoever
+    // rebuilds an unwritten bin goes by the ids in the slots)
     if (hA != kNoHome && !(atHome && c1 && c2)) {
-      float4 lo, hi; nullRecord(lo, hi);
+      float4 lo, hi; nullRecord(lo, hi, i | p.rankBits);
 #pragma unroll
       for (uint32_t k = 0; k < 4u; ++k) {
         const bool ck = k == 0u ? want : (k == 1u ? c1 : (k == 2u ? c2 : c3));
         const uint32_t gk = (hB >> (8u * k)) & 0xFFu;
-        if (gk != kNoSlot && !(atHome && ck)) { float4* r = d.bins + 2u * ((size_t)(hA + (k & 1u) + (k >> 1) * p.binSX) * kBinCap + gk); r[0] = lo; r[1] = hi; }
+        if (gk != kNoSlot && !(atHome && ck) && !(lazyOn && !(gk & kSlotAlways))) {
+          float4* r = d.bins + 2u * ((size_t)(hA + (k & 1u) + (k >> 1) * p.binSX) * kBinCap + (gk & kSlotMask)); r[0] = lo; r[1] = hi;
+        }
       }
     }
   } else {
@@ -503,6 +525,12 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
   const bool hasDeep = (p.flags & kFlagHasDeep) != 0;
 
   uint32_t visCount = 0, candCount = 0;      // wave-uniform running sums
+  // lazy records (binWrittenEveryTick): off while big boxes are about -- they are tested against every bin; the tick's pair
+  // search learns from lazyCtl[1] what this kernel did
+  bool lazyOn = false;
+  if (kAabb) {
+    lazyOn = kHome == kHomeUse && p.lazy != 0u && d.lazyCtl[0] == 0u;      // (first needed at the end of the first tile; noted for the pair search below)
+  }
 
   for (uint32_t base = begin; base < end; base += kTile) {
     const uint32_t i = base + threadIdx.x;
@@ -590,11 +618,12 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
       if (kAabb) {
         // deeper entities are binned by the level kernels once their matrix is final
         const bool collider = hb && !(doXform && depth > kChain && depth != kUnreachable);
-        binEntityWave<kHome>(d, p, i, collider, M, b, recompute);
+        binEntityWave<kHome>(d, p, i, collider, M, b, recompute, lazyOn);
       }
     }
   }
 
+  if (kAabb && blockIdx.x == 0 && threadIdx.x == 0) d.lazyCtl[1] = lazyOn ? 0u : 1u;
   if (kCull) {
     __shared__ uint32_t sVis[kTile / 64], sCand[kTile / 64];
     if (lane == 0) { sVis[wave] = visCount; sCand[wave] = candCount; }
@@ -1135,6 +1164,44 @@ __device__ __forceinline__ bool pairHit(const TickParams& p, const float4& amin,
   return ia != ib && (floorf(lx * p.invSector) - p.binOx) == secX && (floorf(lz * p.invSector) - p.binOz) == secZ;
 }
 
+// Lazy records: the record a remembered slot of bin `sector` WOULD hold this tick, rebuilt from its owner's world matrix --
+// binEntityWave's arithmetic and its rules (the slot carries a record only while the owner's box keeps the primary sector
+// the slot was reserved from and still has this copy; a null record otherwise).  The slot itself holds whatever its owner
+// wrote last -- always under the owner's id.
+//
+// A bin that had to be rebuilt once is likely to be needed again (a vehicle that drove into a street of props stays a while):
+// its owners are told to write it from the next tick on (kSlotAlways in their homeB byte for this copy; kHomeHot in the bin's
+// homeCount), until the next learn tick sorts the bins afresh.
+__device__ __forceinline__ void rebuildHomeRecord(const DeviceState& d, const TickParams& p, uint32_t sector, float4& rmin, float4& rmax)
+{
+  const uint32_t i = __float_as_uint(rmax.w) & 0x00FFFFFFu;
+  float4 lo, hi; nullRecord(lo, hi, i | p.rankBits);
+  if (i < p.n && (ldU(d, kLINK, i) & kHasBounds)) {
+    const uint32_t hA = d.homeA[i];
+    {
+      const uint32_t offH = sector - hA;                  // which of the owner's copies this slot is
+      const uint32_t k = offH == 0u ? 0u : (offH == 1u ? 1u : (offH == p.binSX ? 2u : 3u));
+      atomicOr(&d.homeB[i], kSlotAlways << (8u * k));
+    }
+    const Aff M = loadRows(d, i);
+    const BoundsCE b = loadBounds(d, i);
+    float mn[3], mx[3];
+    worldAabb(M, b, mn, mx);
+    const BinPlan plan = planBins(p, mn, mx);
+    if (plan.collide && !plan.big) {
+      const uint32_t s0 = (uint32_t)plan.z0 * p.binSX + (uint32_t)plan.x0;
+      const bool c1 = plan.nx > 1u, c2 = plan.nz > 1u;
+      const uint32_t off = sector - s0;
+      const bool here = hA == s0 && (off == 0u || (c1 && off == 1u) || (c2 && off == p.binSX) || (c1 && c2 && off == p.binSX + 1u));
+      if (here) {
+        lo = make_float4(mn[0], mn[1], mn[2], __uint_as_float(ldU(d, kLAYERS, i)));
+        hi = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i | p.rankBits | (off == 0u ? kPrimary : 0u)));
+      }
+    }
+  }
+  rmin = lo; rmax = hi;
+}
+
 __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks,
                                           float4 (*tile)[2 * kBinCap], uint16_t* pairTab, uint2 (*pairBuf)[kWavePairBuf],
                                           unsigned long long (*cellMembers)[kCellWords])
@@ -1147,6 +1214,10 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   const uint32_t ctr = kCtrPar + 8u * p.parity;
   const uint32_t nbig = min(d.counters[ctr + kCtrBig], p.bigCap);      // (bounded whatever the counter holds)
   const uint32_t novf = min(d.counters[ctr + kCtrSpill], p.ovfCap);     // sector overflow list: own boxes and neighbours' border records
+  // lazy records: did this tick's fused kernel write every remembered slot?  If not, the slots of a bin whose own records admit
+  // no pair hold old records, and a wave that needs such a bin rebuilds them (rebuildHomeRecord)
+  const bool freshAll = !p.homeReset || d.lazyCtl[1] != 0u;
+  if (bid == 0u && threadIdx.x == 0u) d.lazyCtl[0] = nbig;             // (what the next fused kernel goes by)
   float4* T = tile[wave];
   PairSink sink = { pairBuf[wave], 0u, bid % kPairShards };
 
@@ -1179,7 +1250,8 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   const uint32_t runLog = p.pairRunLog2, runLen = 1u << runLog, runsPerRound = 64u >> runLog;
   for (uint32_t round = 0; ((round * runsPerRound) * totalWaves + waveGlobal) << runLog < sectors; ++round) {
     const uint32_t mySector = (((round * runsPerRound + (lane >> runLog)) * totalWaves + waveGlobal) << runLog) + ((lane + waveGlobal) & (runLen - 1u));
-    uint32_t myCount = 0, myLay = 0;
+    uint32_t myCount = 0, myLay = 0, myHome = 0;
+    bool myStale = false;
     const uint32_t myGx = mySector % p.binSX, myGz = mySector / p.binSX;     // once per 64 sectors, not once per sector
     if (mySector < sectors) {
       myCount = d.binCount[mySector];
@@ -1188,8 +1260,12 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       // the bin's counters go back to where the next tick starts from: zero, or -- with remembered slots -- the slots that are
       // reserved and the layer summary of their records (binEntityWave, "home slots")
       uint32_t hc = 0u, hl = 0u;
-      if (p.homeReset) { hc = d.homeCount[mySector]; hl = d.homeLayers[mySector]; }
+      bool hot = false;
+      if (p.homeReset) { hc = d.homeCount[mySector]; hl = d.homeLayers[mySector]; hot = (hc & kHomeHot) != 0u; hc &= ~kHomeHot; }
       if (myCount != hc || lay != hl) { d.binCount[mySector] = hc; d.binLayers[mySector] = hl; }
+      myHome = hc;
+      myStale = !freshAll && !hot && hc != 0u && ((hl & 0xFFFFu) & (hl >> 16)) == 0u &&
+                !(myGx == 0u || myGz == 0u || myGx + 1u == p.binSX || myGz + 1u == p.binSZ);      // (!binWrittenEveryTick)
       if (myCount) {
         // no record of this bin can pass the group/mask filter against another one: nothing to read
         if (nbig == 0u && ((lay & 0xFFFFu) & (lay >> 16)) == 0u) myCount = 0u;      // (a crowded sector's overflow slice is reset by the workgroup that takes it off the queue)
@@ -1208,6 +1284,24 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       if ((dx != 0 && hasNb(p, dx, 0)) || (dz != 0 && hasNb(p, 0, dz))) mine = false;    // nearest tile is not this one
     }
     const unsigned long long oursMask = ballot64(mine);
+    // lazy records: bins of unwritten records that have to be read after all (a record from elsewhere made them admissible; a
+    // big box is about) are rebuilt in place first -- rare, and outside the loop below
+    const unsigned long long staleMask = ballot64(myStale && myCount != 0u);
+    if (staleMask) {
+      for (unsigned long long st = staleMask; st; st &= st - 1ull) {
+        const int k = __ffsll((long long)st) - 1;
+        const uint32_t sK = __shfl(mySector, k, 64), hcK = __shfl(myHome, k, 64);
+        if (lane < hcK) {
+          float4* r = d.bins + 2u * ((size_t)sK * kBinCap + lane);
+          float4 lo = r[0], hi = r[1];
+          rebuildHomeRecord(d, p, sK, lo, hi);
+          r[0] = lo; r[1] = hi;
+        }
+      }
+      __threadfence();
+      // (marked behind the fence: whoever sees the mark -- the workgroup that takes a crowded sector off the queue -- sees the records)
+      if (myStale && myCount != 0u) d.homeCount[mySector] = myHome | kHomeHot;
+    }
     // what a sector's turn needs from the lane that holds it: index, count, layer summary, grid coordinates -- four
     // cross-lane reads.  (ds_bpermute although the picked lane is wave-uniform: v_readlane measured slower, 27.1 against
     // 26.3 us on config3dyn -- a VALU slot each plus SGPR-hazard waits; and recomputing the index from the lane number
@@ -1442,6 +1536,18 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     }
     uint32_t* row = d.ovfIdx + (size_t)(bid * (kTile / 64u) < kOvfWaves ? bid * (kTile / 64u) : kOvfWaves - 1u) * kOvfPerSector;
     uint32_t eLo = d.ovfLo[s], eHi = d.ovfHi[s];
+    // lazy records: the bin's remembered slots hold old records -- rebuilt in place (the sweep's wave may have done so already,
+    // or be doing it now: same ids, same values)
+    const uint32_t hcRaw = freshAll ? kHomeHot : d.homeCount[s];     // (the sweep's wave may have marked the bin hot a moment ago: then it rebuilt it, too)
+    if (!(hcRaw & kHomeHot) && !binWrittenEveryTick(d.homeLayers[s], s, p.binSX, p.binSZ)) {
+      if (wave == 0u && lane < hcRaw) {
+        float4* r = d.bins + 2u * ((size_t)s * kBinCap + lane);
+        float4 lo = r[0], hi = r[1];
+        rebuildHomeRecord(d, p, s, lo, hi);
+        r[0] = lo; r[1] = hi;
+      }
+      __threadfence();
+    }
     if (eHi > novf) eHi = novf;
     if (!ours) eLo = eHi;
     __syncthreads();                                                  // (everybody has the slice bounds)
@@ -2204,13 +2310,32 @@ __global__ __launch_bounds__(kTile) void k_snapshot_home(const DeviceState d, ui
   d.homeLayers[s] = d.binLayers[s];
 }
 
+// ... and every remembered slot learns whether its bin is one that is written on every tick (lazy records): a bin whose
+// reserved records can pass the group/mask filter against each other, or a ring sector (the border pack reads those).
+__global__ __launch_bounds__(kTile) void k_home_flags(const DeviceState d, uint32_t n, uint32_t binSX, uint32_t binSZ)
+{
+  const uint32_t i = blockIdx.x * kTile + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t hA = d.homeA[i];
+  if (hA == kNoHome) return;
+  uint32_t hB = d.homeB[i];
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) {
+    if (((hB >> (8u * k)) & 0xFFu) == kNoSlot) continue;
+    const uint32_t sec = hA + (k & 1u) + (k >> 1) * binSX;
+    if (binWrittenEveryTick(d.homeLayers[sec], sec, binSX, binSZ)) hB |= kSlotAlways << (8u * k);
+  }
+  d.homeB[i] = hB;
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-void launchSnapshotHome(const DeviceState& d, uint32_t sectors, hipStream_t s)
+void launchSnapshotHome(const DeviceState& d, uint32_t sectors, uint32_t n, uint32_t binSX, uint32_t binSZ, hipStream_t s)
 {
   if (!sectors) return;
   hipLaunchKernelGGL(k_snapshot_home, dim3((sectors + kTile - 1) / kTile), dim3(kTile), 0, s, d, sectors);
+  if (n) hipLaunchKernelGGL(k_home_flags, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, binSX, binSZ);
 }
 // `done` (may be null): recorded by the dispatch itself -- the event the copy stream waits for, without a marker packet
 void launchEmitDrawsStaged(const DeviceState& d, uint32_t budget, uint32_t* block, uint32_t maxVisible, uint64_t tick, hipStream_t s, hipEvent_t done)

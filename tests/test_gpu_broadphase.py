@@ -324,3 +324,95 @@ def test_remembered_slots_survive_uploads_appends_and_removals(oracle, monkeypat
     t.upload_layers(0, w.group, w.mask)
     check(); check()
     t.close(); ow.close()
+
+
+def _static_city_with_wanderers(n, dyn, seed, spread=440.0):
+    """Static props (group 2 / mask 1) everywhere, a few dynamic bodies (1 / all) among them: most bins admit no pair."""
+    w = worlds.random_world(n, seed=seed, spread=spread, max_depth=1, p_child=0.2, p_no_bounds=0.02)
+    w.group[:] = sw.GROUP_STATIC; w.mask[:] = sw.MASK_STATIC
+    roots = np.flatnonzero(w.parent < 0)
+    w.pos[roots, 1] *= np.float32(0.02)                                  # a flat city: boxes meet in y
+    d = roots[:dyn]
+    w.group[d] = sw.GROUP_DYNAMIC; w.mask[d] = sw.MASK_ALL
+    w.bmin[d] = np.float32([-3.0, -1.0, -3.0]); w.bmax[d] = np.float32([3.0, 2.0, 3.0])
+    return w, d
+
+
+@pytest.mark.parametrize("variant", ["0", "32"])
+def test_unwritten_bins_are_rebuilt_when_a_body_from_elsewhere_arrives(oracle, monkeypatch, variant):
+    """Lazy records: the remembered slots of a bin whose own records admit no pair -- static props only --
+    are not written between learn ticks; when a dynamic body drives into such a sector, the wave that searches it rebuilds the
+    props' records from their world matrices.  Dynamic bodies jump to new places every other tick, every root drifts 1.7 m a
+    tick (so props leave their sectors too and their slots lapse), one learn tick at the start: the pair set is the
+    oracle's on every tick.  Variant 32 writes every slot every tick (the A/B switch): same pairs."""
+    monkeypatch.setenv("SC_TICK_HOME_PERIOD", "1000")
+    monkeypatch.setenv("SC_TICK_VARIANT", variant)
+    w, dyn = _static_city_with_wanderers(7000, 60, seed=91)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    t = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 18)
+    rng = np.random.default_rng(17)
+    seen = 0
+    for k in range(24):
+        if k:
+            ow.nudge_roots_x(1.7); t.nudge_roots_x(1.7)
+        if k % 2 == 1:
+            pos = t.positions()
+            pos[dyn] = rng.uniform(-450, 450, (len(dyn), 3)).astype(np.float32) * np.float32([1, 0.01, 1])
+            ow.set_local_positions(np.arange(w.n, dtype=np.uint32), pos)
+            t.upload_positions(0, pos)
+        ow.transform_system(); t.run(FLAGS)
+        mn, mx = ow.world_aabbs()
+        gmn, gmx = t.world_aabbs()
+        assert np.array_equal(gmn, mn) and np.array_equal(gmx, mx)
+        want = oracle.broadphase_grid(mn, mx, w.group, w.mask, 64.0)
+        got, total = t.pairs()
+        assert total == len(want), f"tick {k}: {total} pairs, oracle {len(want)}"
+        assert np.array_equal(sorted_pairs(got), want), f"tick {k}"
+        seen += total
+    assert seen > 200 and t.counts().pairs_truncated == 0
+    t.close(); ow.close()
+
+
+def test_unwritten_bins_and_a_big_box_that_appears(oracle, monkeypatch):
+    """A big box (tested against every bin's primary records) appears between learn ticks: on its first tick the bins were
+    not written (nobody knew), so every wave rebuilds what it needs; from the next tick on the fused kernel writes every record
+    again.  Then it shrinks back.  Pairs equal the oracle's throughout, and ray queries (which read the bins) switch the
+    lazy records off for their tick."""
+    from tests.test_gpu_rays import compare
+    monkeypatch.setenv("SC_TICK_HOME_PERIOD", "1000")
+    w, dyn = _static_city_with_wanderers(5000, 30, seed=92, spread=430.0)
+    t = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 19)
+    big = int(dyn[0])
+    small = (w.bmin.copy(), w.bmax.copy())
+    state = {}
+
+    def check(flags=FLAGS):
+        ow = worlds.oracle_world(oracle, w, camera=False)      # (nothing moves in this test: the oracle's world is rebuilt from w)
+        ow.transform_system(); t.run(flags)
+        mn, mx = ow.world_aabbs()
+        gmn, gmx = t.world_aabbs()
+        assert np.array_equal(gmn, mn) and np.array_equal(gmx, mx)
+        want = oracle.broadphase_grid(mn, mx, w.group, w.mask, 64.0)
+        got, total = t.pairs()
+        assert total == len(want) and np.array_equal(sorted_pairs(got), want)
+        state["aabbs"] = (mn, mx)
+        ow.close()
+        return total
+    check(); check(); base = check()
+    w.bmin[big] = np.float32([-400, -5, -400]); w.bmax[big] = np.float32([400, 5, 400])
+    t.upload_bounds(0, w.bmin, w.bmax, w.has_bounds)
+    grown = check()
+    assert grown > base + 500                                    # the big dynamic box meets the props under it
+    assert check() == grown and check() == grown
+    w.bmin[:], w.bmax[:] = small
+    t.upload_bounds(0, w.bmin, w.bmax, w.has_bounds)
+    assert check() == base and check() == base and check() == base
+    # a tick with ray queries reads the bins: every record is there
+    rays = (np.float32([[0, 50, 0], [100, 50, -80], [-200, 40, 150]]), np.float32([[0, -1, 0], [0.6, -0.8, 0], [0, -1, 0]]),
+            np.float32([200, 300, 200]), np.uint32([0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF]))
+    t.set_ray_queries(*rays)
+    assert check(FLAGS | capi.RAYS) == base
+    mn, mx = state["aabbs"]
+    compare(t.ray_hits(), oracle.raycast_boxes(mn, mx, w.group, w.mask, *rays))
+    assert check() == base
+    t.close()
