@@ -33,10 +33,20 @@ TILE_SECTORS = 256
 PROPS = 15
 
 
-def algorithmic_bytes_per_entity(child_frac, stages, dirty_frac=1.0):
+def records_written_frac(t):
+    """share of the broadphase records the fused kernel writes on an ordinary tick (scTickGetBinStats): 1 unless the tick may
+    leave the slots of bins that admit no pair unwritten (lazy records)"""
+    bs = t.bin_stats()
+    if not bs["lazy_last_tick"] or not bs["remembered_slots"]:
+        return 1.0
+    return bs["written_every_tick"] / bs["remembered_slots"]
+
+
+def algorithmic_bytes_per_entity(child_frac, stages, dirty_frac=1.0, records_frac=1.0):
     """Per-launch algorithmic bytes of the dominant kernel k_xform_cull:
     xform 88 + 48*C/N (SURVEY 8d); cull +24 (bounds; the 4*V/N index list is written by the end-of-tick kernel);
-    broadphase +32 (the AABB record written into its sector bin; bounds are read once for both).
+    broadphase +32 x records_frac (the AABB record written into its sector bin -- only the share of records that IS written
+    is counted: bins that admit no pair are left unwritten, records_written_frac(); bounds are read once for both).
     SURVEY 8d's further 96 B/entity of broadphase traffic (dense AABB array, sort scatter) do not
     exist in this design -- boxes are binned directly -- and are NOT counted anywhere.
     dirty_frac < 1 (config 5): a clean entity re-reads its stored matrix (48 B) instead of 40 B in / 48 B out."""
@@ -44,7 +54,7 @@ def algorithmic_bytes_per_entity(child_frac, stages, dirty_frac=1.0):
     if "cull" in stages or "broadphase" in stages:
         b += 24.0
     if "broadphase" in stages:
-        b += 32.0
+        b += 32.0 * records_frac
     return b
 
 
@@ -316,17 +326,18 @@ def secondary_leg(args, workload, device, steps=20, warmup=5):
     kp = t.kernel_times_ms(capi.K_PAIRS)
     t.set_profiling(0)
     counts = t.counts()
+    rec_frac = records_written_frac(t) if "broadphase" in stages else 1.0
     leg = OracleLeg(w)
     parity = leg.parity(t, ticks, stages, vp)
     leg.close()
     eot_ms, eot_bytes, eot_achieved = end_of_tick_line(w, workload, SX, SZ, counts, kp, stages, kind)
     dirty_frac = 0.5 if workload == "config5" else 1.0
-    bpe = algorithmic_bytes_per_entity(0.0 if workload == "config5" else float((w.parent >= 0).mean()), stages, dirty_frac)
+    bpe = algorithmic_bytes_per_entity(0.0 if workload == "config5" else float((w.parent >= 0).mean()), stages, dirty_frac, rec_frac)
     k1_ms = float(np.mean(k1))
     out = {"workload": workload, "entities": int(w.n), "steps": steps, "warmup": warmup,
            "ms_per_step": elapsed / steps * 1e3, "value": w.n * steps / elapsed, "unit": "entities/s",
            "pairs": int(counts.pairs), "visible": int(counts.visible), "border_lost": int(counts.border_lost),
-           "k_xform_cull": {"avg_launch_ms": k1_ms, "bytes_per_entity": bpe, "frac": w.n * bpe / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "k_xform_cull": {"avg_launch_ms": k1_ms, "bytes_per_entity": bpe, "records_written_frac": rec_frac, "frac": w.n * bpe / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "traffic": pmc_traffic(stages, w.n, workload)},
            "end_of_tick_kernel": {"avg_launch_ms": eot_ms, "algorithmic_bytes": eot_bytes, "achieved": eot_achieved,
                                   "frac": (eot_achieved / HBM_PEAK_GBS) if eot_achieved else None,
@@ -491,6 +502,7 @@ def main():
     kp = t.kernel_times_ms(capi.K_PAIRS)
     t.set_profiling(0)
     counts = t.counts()
+    rec_frac = records_written_frac(t) if "broadphase" in stages else 1.0
 
     # End to end, as the engine would run it in resident mode: every frame also emits the draw items (the sandbox's budget,
     # 6000: src/sandbox/src/main.cpp:96) and reads back counts + visible list + draw items -- staged by a small kernel, ONE
@@ -575,7 +587,7 @@ def main():
         child_frac = float((w.parent >= 0).mean())
         roots = int((w.parent < 0).sum())
         dirty_frac = 0.5 if args.workload == "config5" else 1.0      # config 5: only the movers (half the world, all roots) are rebuilt
-        bpe = algorithmic_bytes_per_entity(0.0 if args.workload == "config5" else child_frac, stages, dirty_frac)
+        bpe = algorithmic_bytes_per_entity(0.0 if args.workload == "config5" else child_frac, stages, dirty_frac, rec_frac)
         k1_ms = float(np.mean(k1)) if len(k1) else None
         achieved = (w.n * bpe) / (k1_ms * 1e-3) / 1e9 if len(k1) else None
         eot_ms, eot_bytes, eot_achieved = end_of_tick_line(w, args.workload, SX, SZ, counts, kp, stages, kind)
@@ -622,7 +634,7 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": pmc_traffic(stages, w.n, args.workload),
-                "bytes_per_entity": bpe, "avg_launch_ms": k1_ms, "launches_timed": int(len(k1)),
+                "bytes_per_entity": bpe, "records_written_frac": rec_frac, "avg_launch_ms": k1_ms, "launches_timed": int(len(k1)),
                 "timed_where": "every launch of the steps that follow the timed region directly (timing a launch costs ~12 us of gap per step)",
                 "avg_launch_ms_in_timed_region": float(np.mean(k1_region)) if len(k1_region) else None,
                 "launches_timed_in_timed_region": int(len(k1_region)),

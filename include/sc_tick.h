@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SC_TICK_API_VERSION 4u
+#define SC_TICK_API_VERSION 5u
 #define SC_TICK_MAX_ENTITIES ((1u << 24) - 1u)   /* Entity::INDEX_BITS = 24 (sc_ecs.h:18-20); index 0xFFFFFF is the "no parent" value */
 #define SC_TICK_NO_PARENT (-1)
 
@@ -254,6 +254,16 @@ typedef struct ScTickCommInfo
   double   host_tick_half_us, host_pair_half_us;
 } ScTickCommInfo;
 int scTickGetCommInfo(ScTickContext* ctx, ScTickCommInfo* out);
+
+/* Broadphase bins, how they are filled (diagnostics; the pair set never depends on any of it).  Records keep the bin slot they
+ * reserved at the last "learn" tick while their box stays in its sector (no reservation, i.e. no atomic, on the ticks in
+ * between; SC_TICK_HOME_PERIOD ticks apart, default 64; SC_TICK_VARIANT bit 1 switches the slots off), and the slots of a bin
+ * whose own records cannot pass the group/mask filter against each other -- static props only -- are not even written until a
+ * record from elsewhere needs them (the pair search then rebuilds them; SC_TICK_VARIANT bit 5 switches that off; ticks with
+ * ray queries or traffic sensors, and pipelined tiles, write every record).
+ * stats[0] remembered slots, [1] of those written on every tick, [2] 1 if the last tick was allowed to leave slots unwritten,
+ * [3] learn ticks so far.  Reads the slots back (a few MB): not for the frame loop. */
+int scTickGetBinStats(ScTickContext* ctx, uint32_t stats[4]);
 int scTickResetHostTimes(ScTickContext* ctx);
 int scTickTileStep(ScTickContext* ctx, uint32_t flags);
 /* the middle third of scTickTileStep on its own, for hosts that interleave other work: after scTickRun(... | SC_TICK_SPLIT_PAIRS) */

@@ -126,6 +126,7 @@ SYMBOLS = {
     "scTickCommDestroy": (C.c_int, [_CTX]),
     "scTickSetPipelined": (C.c_int, [_CTX, C.c_int]),
     "scTickGetCommInfo": (C.c_int, [_CTX, C.POINTER(CommInfo)]),
+    "scTickGetBinStats": (C.c_int, [_CTX, U32P]),
     "scTickResetHostTimes": (C.c_int, [_CTX]),
     "scTickTileStep": (C.c_int, [_CTX, C.c_uint32]),
     "scTickExchangeBorders": (C.c_int, [_CTX]),

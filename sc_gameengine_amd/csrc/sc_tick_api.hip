@@ -97,6 +97,7 @@ struct ScTickContext
   // home slots of the bins (binEntityWave): remembered at a learn tick, used until the world's shape changes or they age
   bool homeEnabled = true, homeValid = false, homeCountsLive = false;
   bool lazyEnabled = true;                             // lazy records (DeviceState::lazyCtl)
+  bool lastTickLazy = false; uint32_t learnTicks = 0;  // scTickGetBinStats
   uint64_t homeEpoch = ~0ull; uint32_t homeAge = 0, homePeriod = 64;
   bool capturing = false;                              // enqueueStages runs inside a stream capture
   bool packedRides = false;                            // this tick's `packed` event was attached to the compaction + pack dispatch
@@ -1217,12 +1218,13 @@ int scTickRun(ScTickContext* c, uint32_t flags)
         }
       }
       p.homeMode = kHomeLearn;
-      c->homeValid = true; c->homeEpoch = c->topoEpoch; c->homeAge = 0; c->lastTickLearn = true;
+      c->homeValid = true; c->homeEpoch = c->topoEpoch; c->homeAge = 0; c->lastTickLearn = true; c->learnTicks++;
     } else { p.homeMode = kHomeUse; c->homeAge++; }
     p.homeReset = 1u;
     // lazy records: only while nothing but this tick's own pair search reads the bins, and that search runs before the next
     // tick rewrites the world matrices (it rebuilds unwritten records from them)
     p.lazy = (p.homeMode == kHomeUse && c->lazyEnabled && !c->pairsStream && !(flags & SC_TICK_RAYS) && !c->sensors) ? 1u : 0u;
+    c->lastTickLazy = p.lazy != 0u;
     c->homeCountsLive = true;
   }
   if ((flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_SPLIT_PAIRS) && c->neighbourMask) {
@@ -2118,6 +2120,28 @@ int scTickSelectTrafficDespawns(ScTickContext* c, const float playerPos[3], uint
   std::partial_sort(order.begin(), order.begin() + toRemove, order.end(), before);
   *count = toRemove;
   for (uint32_t k = 0; k < toRemove && k < capacity && denseIndices; ++k) denseIndices[k] = idx[order[k]];
+  return 1;
+}
+
+int scTickGetBinStats(ScTickContext* c, uint32_t stats[4])
+{
+  if (!c || !stats) return c ? fail(c, "null argument") : 0;
+  stats[0] = stats[1] = stats[2] = stats[3] = 0u;
+  if (!bind(c)) return 0;
+  if (!c->d.homeA || !c->n) return 1;
+  stats[2] = c->lastTickLazy ? 1u : 0u; stats[3] = c->learnTicks;
+  if (!c->homeValid) return 1;
+  if (!sync(c)) return 0;
+  std::vector<uint32_t> a(c->n), b(c->n);
+  if (!d2h(c, a.data(), c->d.homeA, (size_t)c->n * 4u) || !d2h(c, b.data(), c->d.homeB, (size_t)c->n * 4u) || !sync(c)) return 0;
+  for (uint32_t i = 0; i < c->n; ++i) {
+    if (a[i] == kNoHome) continue;
+    for (uint32_t k = 0; k < 4u; ++k) {
+      const uint32_t byte = (b[i] >> (8u * k)) & 0xFFu;
+      if (byte == kNoSlot) continue;
+      stats[0]++; if (byte & kSlotAlways) stats[1]++;
+    }
+  }
   return 1;
 }
 

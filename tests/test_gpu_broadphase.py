@@ -369,7 +369,18 @@ def test_unwritten_bins_are_rebuilt_when_a_body_from_elsewhere_arrives(oracle, m
         assert total == len(want), f"tick {k}: {total} pairs, oracle {len(want)}"
         assert np.array_equal(sorted_pairs(got), want), f"tick {k}"
         seen += total
+        if k == 0:
+            first = t.bin_stats()
     assert seen > 200 and t.counts().pairs_truncated == 0
+    bs = t.bin_stats()
+    assert bs["learn_ticks"] == 1 and bs["remembered_slots"] == first["remembered_slots"] > w.n // 2
+    # after the learn tick some bins are written on every tick (a dynamic body lives there; ring sectors), the others are not;
+    # every bin a dynamic body jumped into since was rebuilt once and is written from then on
+    assert 0 < first["written_every_tick"] < first["remembered_slots"] * 3 // 4
+    if variant == "0":
+        assert bs["lazy_last_tick"] and first["written_every_tick"] < bs["written_every_tick"] <= bs["remembered_slots"]
+    else:
+        assert not bs["lazy_last_tick"] and bs["written_every_tick"] == first["written_every_tick"]
     t.close(); ow.close()
 
 

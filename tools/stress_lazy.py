@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Lazy records under random worlds: mostly static props with a few dynamic bodies, many ticks without a learn tick, bodies
+teleporting, roots drifting, ticks with and without ray queries, crowded sectors, random
+learn periods.  Pair SET and world AABBs must equal the oracle's on every tick.  A confidence run, not part of the suite.
+    python tools/stress_lazy.py [--seeds 40] [--ticks 14]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seeds", type=int, default=40)
+ap.add_argument("--ticks", type=int, default=14)
+args = ap.parse_args()
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+bad = 0
+for seed in range(args.seeds):
+    rng = np.random.default_rng(7000 + seed)
+    os.environ["SC_TICK_HOME_PERIOD"] = str(int(rng.choice([2, 5, 1000, 1000])))
+    from sc_gameengine_amd import capi, synth_world as sw            # noqa: E402
+    from sc_gameengine_amd.tick import WorldTick                      # noqa: E402
+    from oracle import oracle_py as oracle                            # noqa: E402
+    from tests import worlds                                          # noqa: E402
+    from tests.test_gpu_rays import random_rays                        # noqa: E402
+    if seed == 0:
+        oracle.build()
+    FLAGS = capi.XFORM | capi.BROADPHASE | capi.DENSE_AABBS
+    n = int(rng.integers(500, 9000))
+    spread = float(rng.choice([120.0, 300.0, 440.0]))
+    w = worlds.random_world(n, seed=seed, spread=spread, max_depth=int(rng.integers(0, 3)), p_child=float(rng.choice([0.0, 0.3])), p_no_bounds=0.03)
+    roots = np.flatnonzero(w.parent < 0)
+    w.pos[roots, 1] *= np.float32(0.03)
+    pdyn = float(rng.choice([0.0, 0.002, 0.01, 0.05]))
+    dyn = rng.random(n) < pdyn
+    w.group[:] = np.where(dyn, sw.GROUP_DYNAMIC, sw.GROUP_STATIC).astype(np.uint32)
+    w.mask[:] = np.where(dyn, sw.MASK_ALL, sw.MASK_STATIC).astype(np.uint32)
+    if seed % 5 == 2:                                               # one crowded corner (bins beyond 64, overflow lists)
+        k = min(n, 300)
+        w.pos[roots[:k]] = np.float32([30.0, 0.0, -40.0]) + rng.uniform(-12, 12, (k, 3)).astype(np.float32) * np.float32([1, 0.05, 1])
+    dyn_roots = roots[dyn[roots]]
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    t = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 22)
+    rays = random_rays(rng, 50, spread)
+    t.set_ray_queries(*rays)
+    for tick in range(args.ticks):
+        step = float(rng.choice([0.0, 0.9, 3.1]))
+        if tick and step:
+            ow.nudge_roots_x(step); t.nudge_roots_x(step)
+        if len(dyn_roots) and rng.random() < 0.5:                    # dynamic bodies jump
+            pos = t.positions()
+            mv = rng.choice(dyn_roots, max(1, len(dyn_roots) // 2), replace=False)
+            pos[mv] = rng.uniform(-spread, spread, (len(mv), 3)).astype(np.float32) * np.float32([1, 0.02, 1])
+            ow.set_local_positions(np.arange(w.n, dtype=np.uint32), pos)
+            t.upload_positions(0, pos)
+        flags = FLAGS | (capi.RAYS if rng.random() < 0.2 else 0)
+        ow.transform_system(); t.run(flags)
+        mn, mx = ow.world_aabbs(); gmn, gmx = t.world_aabbs()
+        want = oracle.broadphase_grid(mn, mx, w.group, w.mask, 64.0)
+        got, total = t.pairs()
+        p = np.asarray(got, np.uint64).reshape(-1, 2)
+        gk = np.sort(p[:, 0] << np.uint64(32) | p[:, 1])
+        q = np.asarray(want, np.uint64).reshape(-1, 2)
+        wk = np.sort(q[:, 0] << np.uint64(32) | q[:, 1])
+        c = t.counts()
+        same = np.array_equal(gmn, mn) and np.array_equal(gmx, mx) and total == len(want) and np.array_equal(gk, wk)
+        if not same or c.pairs_truncated or c.border_lost:
+            bad += 1
+            print(f"seed {seed} tick {tick}: MISMATCH n={n} spread={spread} pdyn={pdyn} period={os.environ['SC_TICK_HOME_PERIOD']} "
+                  f"pairs {total} vs {len(want)} missing {len(np.setdiff1d(wk, gk))} extra {len(np.setdiff1d(gk, wk))} truncated {c.pairs_truncated}", flush=True)
+            break
+    else:
+        print(f"seed {seed}: ok n={n} spread={spread} pdyn={pdyn} period={os.environ['SC_TICK_HOME_PERIOD']} last pairs {total} overflow {c.bin_overflow}", flush=True)
+    t.close(); ow.close()
+print(f"{args.seeds - bad} of {args.seeds} equal")
+sys.exit(1 if bad else 0)
