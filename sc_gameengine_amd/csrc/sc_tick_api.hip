@@ -98,6 +98,7 @@ struct ScTickContext
   bool homeEnabled = true, homeValid = false, homeCountsLive = false;
   bool lazyEnabled = true;                             // lazy records (DeviceState::lazyCtl)
   bool lastTickLazy = false; uint32_t learnTicks = 0;  // scTickGetBinStats
+  bool boxesTouched = false;                           // bounds or world matrices were uploaded since the last broadphase tick (TickParams::cleanStay)
   uint64_t homeEpoch = ~0ull; uint32_t homeAge = 0, homePeriod = 64;
   bool capturing = false;                              // enqueueStages runs inside a stream capture
   bool packedRides = false;                            // this tick's `packed` event was attached to the compaction + pack dispatch
@@ -782,6 +783,7 @@ int scTickUploadBounds(ScTickContext* c, uint32_t first, uint32_t count, const f
   if (!c || !min3 || !max3) return c ? fail(c, "null argument") : 0;
   if (!bind(c) || !rangeOk(c, first, count)) return 0;
   if (!count) return 1;
+  c->boxesTouched = true;
   if (!upload3(c, min3, first, count, c->d.bminx, c->d.bminy, c->d.bminz)) return 0;
   if (!upload3(c, max3, first, count, c->d.bmaxx, c->d.bmaxy, c->d.bmaxz)) return 0;
   for (uint32_t i = 0; i < count; ++i) {
@@ -1106,6 +1108,7 @@ int scTickUploadWorldMatrices(ScTickContext* c, uint32_t first, uint32_t count, 
   if (!c || !m16) return c ? fail(c, "null argument") : 0;
   if (!bind(c) || !rangeOk(c, first, count)) return 0;
   if (!count) return 1;
+  c->boxesTouched = true;
   std::vector<float4> r0(count), r1(count), r2(count);
   for (uint32_t i = 0; i < count; ++i) {
     const float* m = m16 + 16 * (size_t)i;
@@ -1205,6 +1208,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   fillParams(c, flags, p, grid);
   c->lastFlags = flags;
   c->lastTickLearn = false;
+  if ((flags & SC_TICK_XFORM) && !(flags & SC_TICK_BROADPHASE)) c->boxesTouched = true;      // matrices change, the bins do not follow
   if ((flags & SC_TICK_BROADPHASE) && c->homeEnabled) {
     // home slots: a learn tick when nothing is remembered, the world's shape changed (entities, hierarchy, layers) or the
     // slots have aged; every bin copy must be idle and empty for it (a rare event: the streams are joined here)
@@ -1225,6 +1229,9 @@ int scTickRun(ScTickContext* c, uint32_t flags)
     // tick rewrites the world matrices (it rebuilds unwritten records from them)
     p.lazy = (p.homeMode == kHomeUse && c->lazyEnabled && !c->pairsStream && !(flags & SC_TICK_RAYS) && !c->sensors) ? 1u : 0u;
     c->lastTickLazy = p.lazy != 0u;
+    // records of entities that did not move stay as they are, unless something else changed boxes since the last tick
+    p.cleanStay = (p.homeMode == kHomeUse && c->lazyEnabled && !c->pairsStream && !c->boxesTouched) ? 1u : 0u;
+    c->boxesTouched = false;
     c->homeCountsLive = true;
   }
   if ((flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_SPLIT_PAIRS) && c->neighbourMask) {

@@ -194,6 +194,8 @@ struct TickParams {
                             // 2 records with a remembered slot are stored there directly (kHome*)
   uint32_t homeReset;       // the pair search leaves binCount / binLayers at homeCount / homeLayers instead of zero
   uint32_t borderRecs;      // border messages: records per ring sector of a side, on average (scTickSetBorderCapacity; kBorderRecsPerBin)
+  uint32_t cleanStay;       // kHomeUse ticks: an entity whose matrix was not rebuilt leaves its (always written) slots as they are -- they hold
+                            // this very record; 0 after anything else changed boxes (bounds / matrix uploads) and when the pair half runs pipelined
   uint32_t lazy;            // kHomeUse ticks: reserved records of bins that cannot produce a pair may be left unwritten (DeviceState::lazyCtl);
                             // 0 when something else reads the bins (ray queries, traffic sensors) or the pair half runs pipelined
 };

@@ -344,7 +344,10 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
   const bool a0 = want && !r0;                                     // the primary copy reserves its slot
   uint32_t slot = hB & kSlotMask;
   // lazy records: a remembered slot of a bin that cannot produce a pair is not written (binWrittenEveryTick)
-  const bool skip0 = r0 && lazyOn && !(hB & kSlotAlways);
+  // ... and neither is a slot that is written on every tick when its owner's matrix did not change: it holds this very record
+  // (TickParams::cleanStay; storeM = the matrix was rebuilt)
+  const bool stay = p.cleanStay != 0u && !storeM;
+  const bool skip0 = r0 && ((hB & kSlotAlways) ? stay : lazyOn);
   float4 rm = rmax;
   rm.w = __uint_as_float(i | p.rankBits | kPrimary);
   const uint32_t myLay = __float_as_uint(rmin.w);
@@ -397,8 +400,8 @@ __device__ __forceinline__ void binEntityWave(const DeviceState& d, const TickPa
     uint32_t q1 = b1 & kSlotMask, q2 = b2 & kSlotMask, q3 = b3 & kSlotMask;
     const bool h1 = atHome && b1 != kNoSlot, h2 = atHome && b2 != kNoSlot, h3 = atHome && b3 != kNoSlot;    // remembered
     const bool a1 = c1 && !h1, a2 = c2 && !h2, a3 = c3 && !h3;
-    const bool w1 = c1 && !(h1 && lazyOn && !(b1 & kSlotAlways)), w2 = c2 && !(h2 && lazyOn && !(b2 & kSlotAlways)),
-               w3 = c3 && !(h3 && lazyOn && !(b3 & kSlotAlways));
+    const bool w1 = c1 && !(h1 && ((b1 & kSlotAlways) ? stay : lazyOn)), w2 = c2 && !(h2 && ((b2 & kSlotAlways) ? stay : lazyOn)),
+               w3 = c3 && !(h3 && ((b3 & kSlotAlways) ? stay : lazyOn));
     if (a1) q1 = atomicAdd(&d.binCount[sec1], 1u);
     if (a2) q2 = atomicAdd(&d.binCount[sec2], 1u);
     if (a3) q3 = atomicAdd(&d.binCount[sec3], 1u);

@@ -427,3 +427,48 @@ def test_unwritten_bins_and_a_big_box_that_appears(oracle, monkeypatch):
     compare(t.ray_hits(), oracle.raycast_boxes(mn, mx, w.group, w.mask, *rays))
     assert check() == base
     t.close()
+
+
+def test_records_of_boxes_that_did_not_move_stay_in_their_slots(oracle, monkeypatch):
+    """Between learn ticks an entity whose matrix was not rebuilt leaves its bin slots alone -- they hold this very record.
+    Only ranges of the world move from tick to tick (the rest is clean), some ticks run the transforms WITHOUT the broadphase
+    (the bins do not follow: the next broadphase tick must write every record), bounds change under clean entities: the pair
+    set is the oracle's on every broadphase tick."""
+    monkeypatch.setenv("SC_TICK_HOME_PERIOD", "1000")
+    w = worlds.random_world(6000, seed=93, spread=260.0, max_depth=2, p_child=0.3, p_no_bounds=0.03)
+    roots = np.flatnonzero(w.parent < 0)
+    w.pos[roots, 1] *= np.float32(0.05)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    t = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 20)
+    rng = np.random.default_rng(23)
+    pos = w.pos.copy()
+    seen = 0
+    for k in range(26):
+        xform_only = k in (7, 8, 15)
+        if k:
+            a = int(rng.integers(0, w.n - 700)); b = a + int(rng.integers(50, 700))
+            sel = np.arange(a, b, dtype=np.uint32)
+            mv = sel[w.parent[sel] < 0]
+            pos[mv] += rng.uniform(-6, 6, (len(mv), 3)).astype(np.float32) * np.float32([1, 0.02, 1])
+            ow.set_local_positions(sel, pos[sel])
+            t.upload_positions(a, pos[a:b])
+        if k == 19:                                      # boxes change under entities that do not move
+            w.bmin[1000:3000] *= np.float32(1.5); w.bmax[1000:3000] *= np.float32(1.5)
+            ow.close(); ow = worlds.oracle_world(oracle, w, camera=False)
+            ow.set_local_positions(np.arange(w.n, dtype=np.uint32), pos)
+            t.upload_bounds(0, w.bmin, w.bmax, w.has_bounds)
+            t.mark_dirty(0, w.n)
+        ow.transform_system()
+        if xform_only:
+            t.run(capi.XFORM)
+            continue
+        t.run(FLAGS)
+        mn, mx = ow.world_aabbs(); gmn, gmx = t.world_aabbs()
+        assert np.array_equal(gmn, mn) and np.array_equal(gmx, mx), f"tick {k}"
+        want = oracle.broadphase_grid(mn, mx, w.group, w.mask, 64.0)
+        got, total = t.pairs()
+        assert total == len(want), f"tick {k}: {total} pairs, oracle {len(want)}"
+        assert np.array_equal(sorted_pairs(got), want), f"tick {k}"
+        seen += total
+    assert seen > 1000
+    t.close(); ow.close()
