@@ -23,6 +23,7 @@ ap.add_argument("libs", nargs="+")
 ap.add_argument("--workload", default="config3")
 ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--burst", type=int, default=400)
+ap.add_argument("--separate-producer", action="store_true", help="the frame producer as a launch of its own (what the end-of-tick kernel costs without it)")
 args = ap.parse_args()
 
 if args.workload == "config5":
@@ -35,7 +36,7 @@ else:
         w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
     kind, param = 1, 0.01
 vp = camera_view_proj(w.camera)
-flags = capi.FULL | capi.PRODUCE_NEXT
+flags = capi.FULL | (0 if args.separate_producer else capi.PRODUCE_NEXT)
 
 ctxs = {}
 for path in args.libs:

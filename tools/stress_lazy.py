@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Lazy records under random worlds: mostly static props with a few dynamic bodies, many ticks without a learn tick, bodies
-teleporting, roots drifting, ticks with and without ray queries, crowded sectors, random
+teleporting, roots drifting, ranges moving while the rest stays clean, transform-only ticks, ticks with and without ray queries, crowded sectors, random
 learn periods.  Pair SET and world AABBs must equal the oracle's on every tick.  A confidence run, not part of the suite.
     python tools/stress_lazy.py [--seeds 40] [--ticks 14]"""
 import argparse
@@ -54,8 +54,20 @@ for seed in range(args.seeds):
             pos[mv] = rng.uniform(-spread, spread, (len(mv), 3)).astype(np.float32) * np.float32([1, 0.02, 1])
             ow.set_local_positions(np.arange(w.n, dtype=np.uint32), pos)
             t.upload_positions(0, pos)
+        if tick and rng.random() < 0.5:                               # a range of the world moves, the rest stays clean
+            a = int(rng.integers(0, max(1, n - 400))); b = min(n, a + int(rng.integers(20, 400)))
+            sel = np.arange(a, b, dtype=np.uint32)
+            pos = t.positions()
+            mv = sel[w.parent[sel] < 0]
+            pos[mv] += rng.uniform(-5, 5, (len(mv), 3)).astype(np.float32) * np.float32([1, 0.02, 1])
+            ow.set_local_positions(sel, pos[sel])
+            t.upload_positions(a, pos[a:b])
         flags = FLAGS | (capi.RAYS if rng.random() < 0.2 else 0)
-        ow.transform_system(); t.run(flags)
+        ow.transform_system()
+        if tick and rng.random() < 0.15:                              # transforms without the broadphase: the bins do not follow
+            t.run(capi.XFORM)
+            continue
+        t.run(flags)
         mn, mx = ow.world_aabbs(); gmn, gmx = t.world_aabbs()
         want = oracle.broadphase_grid(mn, mx, w.group, w.mask, 64.0)
         got, total = t.pairs()
