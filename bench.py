@@ -34,15 +34,16 @@ PROPS = 15
 
 
 def records_written_frac(t):
-    """share of the broadphase records the fused kernel writes on an ordinary tick (scTickGetBinStats): 1 unless the tick may
-    leave the slots of bins that admit no pair unwritten (lazy records)"""
+    """(share of the broadphase records of REBUILT entities the fused kernel writes on an ordinary tick, whether records of
+    entities that were not rebuilt stay unwritten) from scTickGetBinStats: (1, False) unless the tick may leave the slots of
+    bins that admit no pair unwritten and unchanged records alone ("Records nobody reads")"""
     bs = t.bin_stats()
     if not bs["lazy_last_tick"] or not bs["remembered_slots"]:
-        return 1.0
-    return bs["written_every_tick"] / bs["remembered_slots"]
+        return 1.0, False
+    return bs["written_every_tick"] / bs["remembered_slots"], True
 
 
-def algorithmic_bytes_per_entity(child_frac, stages, dirty_frac=1.0, records_frac=1.0):
+def algorithmic_bytes_per_entity(child_frac, stages, dirty_frac=1.0, records_frac=1.0, clean_stay=False):
     """Per-launch algorithmic bytes of the dominant kernel k_xform_cull:
     xform 88 + 48*C/N (SURVEY 8d); cull +24 (bounds; the 4*V/N index list is written by the end-of-tick kernel);
     broadphase +32 x records_frac (the AABB record written into its sector bin -- only the share of records that IS written
@@ -54,7 +55,7 @@ def algorithmic_bytes_per_entity(child_frac, stages, dirty_frac=1.0, records_fra
     if "cull" in stages or "broadphase" in stages:
         b += 24.0
     if "broadphase" in stages:
-        b += 32.0 * records_frac
+        b += 32.0 * records_frac * (dirty_frac if clean_stay else 1.0)      # (a record that did not change is not rewritten)
     return b
 
 
@@ -326,13 +327,13 @@ def secondary_leg(args, workload, device, steps=20, warmup=5):
     kp = t.kernel_times_ms(capi.K_PAIRS)
     t.set_profiling(0)
     counts = t.counts()
-    rec_frac = records_written_frac(t) if "broadphase" in stages else 1.0
+    rec_frac, clean_stay = records_written_frac(t) if "broadphase" in stages else (1.0, False)
     leg = OracleLeg(w)
     parity = leg.parity(t, ticks, stages, vp)
     leg.close()
     eot_ms, eot_bytes, eot_achieved = end_of_tick_line(w, workload, SX, SZ, counts, kp, stages, kind)
     dirty_frac = 0.5 if workload == "config5" else 1.0
-    bpe = algorithmic_bytes_per_entity(0.0 if workload == "config5" else float((w.parent >= 0).mean()), stages, dirty_frac, rec_frac)
+    bpe = algorithmic_bytes_per_entity(0.0 if workload == "config5" else float((w.parent >= 0).mean()), stages, dirty_frac, rec_frac, clean_stay)
     k1_ms = float(np.mean(k1))
     out = {"workload": workload, "entities": int(w.n), "steps": steps, "warmup": warmup,
            "ms_per_step": elapsed / steps * 1e3, "value": w.n * steps / elapsed, "unit": "entities/s",
@@ -502,7 +503,7 @@ def main():
     kp = t.kernel_times_ms(capi.K_PAIRS)
     t.set_profiling(0)
     counts = t.counts()
-    rec_frac = records_written_frac(t) if "broadphase" in stages else 1.0
+    rec_frac, clean_stay = records_written_frac(t) if "broadphase" in stages else (1.0, False)
 
     # End to end, as the engine would run it in resident mode: every frame also emits the draw items (the sandbox's budget,
     # 6000: src/sandbox/src/main.cpp:96) and reads back counts + visible list + draw items -- staged by a small kernel, ONE
@@ -587,7 +588,7 @@ def main():
         child_frac = float((w.parent >= 0).mean())
         roots = int((w.parent < 0).sum())
         dirty_frac = 0.5 if args.workload == "config5" else 1.0      # config 5: only the movers (half the world, all roots) are rebuilt
-        bpe = algorithmic_bytes_per_entity(0.0 if args.workload == "config5" else child_frac, stages, dirty_frac, rec_frac)
+        bpe = algorithmic_bytes_per_entity(0.0 if args.workload == "config5" else child_frac, stages, dirty_frac, rec_frac, clean_stay)
         k1_ms = float(np.mean(k1)) if len(k1) else None
         achieved = (w.n * bpe) / (k1_ms * 1e-3) / 1e9 if len(k1) else None
         eot_ms, eot_bytes, eot_achieved = end_of_tick_line(w, args.workload, SX, SZ, counts, kp, stages, kind)

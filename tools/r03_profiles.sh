@@ -32,10 +32,13 @@ for W in config3 config3dyn config5; do
   python3 -c "import json; d=json.load(open('$OUT/pmc_traffic_$W.json')); print('$W', {k: round(v.get('hbm_bytes_per_launch', 0)/1e6, 1) for k, v in d['kernels'].items()})"
 done
 rm -f $OUT/pmc_calib
-# crowded sectors: the all-district probe and a district of 512 crowded sectors inside the 1M world (VARIANT 16 = round 2's one-wave search)
-(timeout -k 10 200 python3 tools/crowd_probe.py; timeout -k 10 200 python3 tools/crowd_probe2.py; SC_TICK_VARIANT=16 timeout -k 10 200 python3 tools/crowd_probe2.py) 2>&1 | grep -v amdgpu.ids > $OUT/crowded_sectors.json; cat $OUT/crowded_sectors.json
+# crowded sectors: the all-district probe and a district of 512 crowded sectors inside the 1M world (round 2's one-wave search,
+# 2.06 ms on this probe, left the source with the round-3 clean-up: profiles/r02/crowded_sectors.json and the history hold it)
+(timeout -k 10 200 python3 tools/crowd_probe.py; timeout -k 10 200 python3 tools/crowd_probe2.py) 2>&1 | grep -v amdgpu.ids > $OUT/crowded_sectors.json; cat $OUT/crowded_sectors.json
 # home slots on / off in one process, three workloads
 for W in config3 config3dyn config5; do timeout -k 10 250 python3 tools/ab_step.py --rounds 3 --workload $W sc_gameengine_amd/libsc_tick.so@2 sc_gameengine_amd/libsc_tick.so 2>&1 | grep -v amdgpu.ids >> $OUT/ab_home_slots_final.log; done; cat $OUT/ab_home_slots_final.log
+# lazy / unchanged records on / off (SC_TICK_VARIANT bit 5) in one process, three workloads
+for W in config3 config3dyn config5; do timeout -k 10 250 python3 tools/ab_step.py --rounds 3 --workload $W sc_gameengine_amd/libsc_tick.so@32 sc_gameengine_amd/libsc_tick.so 2>&1 | grep -v amdgpu.ids >> $OUT/ab_lazy_on_off_final.log; done; cat $OUT/ab_lazy_on_off_final.log
 # what one GPU can show of the tiled step: loop-back RCCL, in order / pipelined, 16 and 4 operations per group
 timeout -k 10 300 python3 tools/pipeline_check.py > $OUT/tile_step_16ops.log 2>&1; tail -1 $OUT/tile_step_16ops.log > $OUT/tile_step_16ops.json
 timeout -k 10 300 python3 tools/pipeline_check.py --row 1 > $OUT/tile_step_4ops.log 2>&1; tail -1 $OUT/tile_step_4ops.log > $OUT/tile_step_4ops.json
