@@ -589,6 +589,7 @@ def main():
         roots = int((w.parent < 0).sum())
         dirty_frac = 0.5 if args.workload == "config5" else 1.0      # config 5: only the movers (half the world, all roots) are rebuilt
         bpe = algorithmic_bytes_per_entity(0.0 if args.workload == "config5" else child_frac, stages, dirty_frac, rec_frac, clean_stay)
+        bpe_all = algorithmic_bytes_per_entity(0.0 if args.workload == "config5" else child_frac, stages, dirty_frac)
         k1_ms = float(np.mean(k1)) if len(k1) else None
         achieved = (w.n * bpe) / (k1_ms * 1e-3) / 1e9 if len(k1) else None
         eot_ms, eot_bytes, eot_achieved = end_of_tick_line(w, args.workload, SX, SZ, counts, kp, stages, kind)
@@ -636,6 +637,10 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": pmc_traffic(stages, w.n, args.workload),
                 "bytes_per_entity": bpe, "records_written_frac": rec_frac, "avg_launch_ms": k1_ms, "launches_timed": int(len(k1)),
+                # the same launch priced at the bytes of a kernel that writes every record every tick (round 2's kernel; SURVEY 8d's
+                # per-entity figure for this design): what the time would be worth had the work not been removed
+                "bytes_per_entity_every_record": bpe_all,
+                "frac_at_every_record_bytes": ((w.n * bpe_all) / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if len(k1) else None,
                 "timed_where": "every launch of the steps that follow the timed region directly (timing a launch costs ~12 us of gap per step)",
                 "avg_launch_ms_in_timed_region": float(np.mean(k1_region)) if len(k1_region) else None,
                 "launches_timed_in_timed_region": int(len(k1_region)),
