@@ -926,7 +926,7 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
   if (produceEarly) {
     if (p.producerKind == 1u) {
       // root nudge: link word and x of four tiles are requested together, then written
-      constexpr uint32_t kBatch = 4;
+      constexpr uint32_t kBatch = 6;                      // (a compaction workgroup of two 768-entity spans: all of it in one round trip)
       for (uint32_t base = begin; base < end; base += kBatch * kTile) {
         uint32_t lk[kBatch]; float x[kBatch];
 #pragma unroll
