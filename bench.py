@@ -535,7 +535,7 @@ def main():
                       "added_us_per_step": (e2e_elapsed - elapsed) / args.steps * 1e6,
                       "visible_read_back": int(fr.visible_in_buffer), "draws_read_back": int(fr.draws_in_buffer),
                       "bytes_per_frame": 64 + 8192 * 4 + 6000 * 80,
-                      "what": "tick + k_emit_draws (budget 6000) + staging kernel + one pinned D2H per frame on a copy stream; the host takes frame t-1 while tick t runs"}
+                      "what": "tick with draw emission (budget 6000) and the frame block written by the end-of-tick kernel's compaction role + one pinned D2H per frame on a copy stream; the host takes frame t-1 while tick t runs"}
         t.set_frame_readback(0, 0)
 
     own_elapsed = elapsed

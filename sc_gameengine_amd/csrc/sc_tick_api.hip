@@ -523,14 +523,40 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
   const bool needCompact = (flags & (SC_TICK_XFORM | SC_TICK_CULL)) != 0;
   const bool pairsNow = (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS);
   if (pairsNow && (flags & SC_TICK_RAYS)) launchRayQueries(ds, p, c->rays, c->stream);      // the bins are full, not yet consumed
+  // Draw emission rides in the end-of-tick kernel when the order is the plain one: the compaction role knows every visible
+  // entity's place in the list, i.e. its draw item (emitVisible).  With the frame read-back on (and a budget that fits the block)
+  // the items, the head of the visible list and the header go straight into the block -- no emission kernel, no staging kernel.
+  const uint32_t drawBudget = c->desc.max_draws_budget;
+  const bool stagedEmit = c->rb.bytes && (flags & SC_TICK_DRAWS) && !(flags & SC_TICK_SORT_DRAWS) && drawBudget && drawBudget <= c->rb.maxDraws;
+  const bool foldEmit = needCompact && pairsNow && !(c->variant & (8u | 64u)) && (flags & SC_TICK_CULL) && (flags & SC_TICK_DRAWS) &&
+                        !(flags & SC_TICK_SORT_DRAWS) && (stagedEmit || !c->rb.bytes);
+  bool stagedByEot = false;
   if (needCompact && pairsNow && !(c->variant & 8u)) {
+    TickParams pe = p;
+    hipEvent_t done = nullptr;
+    if (foldEmit) {
+      pe.emitBudget = drawBudget;
+      if (stagedEmit) {
+        ScTickContext::FrameReadback& rb = c->rb;
+        const uint32_t f = (uint32_t)(rb.frames & 1u);
+        if (rb.inFlight[f]) {               // the copy of two frames ago still reads this block? (asked first: a satisfied wait costs a bubble too)
+          if (hipEventQuery(rb.copied[f]) != hipSuccess) hipStreamWaitEvent(c->stream, rb.copied[f], 0);
+          (void)hipGetLastError();
+        }
+        pe.emitMode = 2u; pe.emitTarget = rb.dBlock[f]; pe.emitMaxVisible = rb.maxVisible;
+        pe.emitTickLo = (uint32_t)rb.frames; pe.emitTickHi = (uint32_t)(rb.frames >> 32);
+        done = rb.staged[f];
+        stagedByEot = true;
+      } else { pe.emitMode = 1u; pe.emitTarget = reinterpret_cast<uint32_t*>(c->dDraws); }
+    }
     // both depend only on the fused kernel: one launch, workgroups split by role (timed as K_PAIRS, by the dispatch's own
     // begin / end timestamps like the fused kernel: no marker packets on the queue)
     if (c->profiling && (c->tickIndex % c->profPeriod) == 0) {
       const EventPair ev = takeEvents(c);
-      launchCompactPairs(ds, p, grid, c->stream, ev.a, ev.b);
+      launchCompactPairs(ds, pe, grid, c->stream, ev.a, ev.b);
       c->times[SC_TICK_K_PAIRS].push_back(ev);
-    } else launchCompactPairs(ds, p, grid, c->stream);
+      if (done) hipEventRecord(done, c->stream);
+    } else launchCompactPairs(ds, pe, grid, c->stream, nullptr, done);      // (`staged` rides on the dispatch: its completion signal)
   } else {
     const bool packToo = needCompact && (flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_SPLIT_PAIRS) && !(c->variant & 8u);
     if (packToo) {
@@ -553,11 +579,10 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
       else { Scoped s(c, SC_TICK_K_PAIRS); launchPairs(ds, p, c->stream); }
     }
   }
-  // with the frame read-back on and a plain draw list whose budget fits the block, emission and staging are one launch
-  const uint32_t drawBudget = c->desc.max_draws_budget;
-  const bool stagedEmit = c->rb.bytes && (flags & SC_TICK_DRAWS) && !(flags & SC_TICK_SORT_DRAWS) && drawBudget && drawBudget <= c->rb.maxDraws;
+  // (not folded -- sorted draws, split flows, a budget beyond the block: with the frame read-back on and a plain draw list whose
+  //  budget fits the block, emission and staging are one launch; else emission, then staging)
   c->lastDraws = c->dDraws;
-  if ((flags & SC_TICK_DRAWS) && !stagedEmit) {
+  if ((flags & SC_TICK_DRAWS) && !stagedEmit && !foldEmit) {
     const uint32_t budget = drawBudget;
     if (flags & SC_TICK_SORT_DRAWS) launchSortedDraws(ds, c->sort, budget, (budget && budget < c->n) ? budget : c->n, c->dDraws, c->stream);
     else launchEmitDraws(ds, budget, c->dDraws, c->stream);
@@ -565,12 +590,13 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
   if (c->rb.bytes) {
     ScTickContext::FrameReadback& rb = c->rb;
     const uint32_t f = (uint32_t)(rb.frames & 1u);
-    if (rb.inFlight[f]) {                 // the copy of two frames ago still reads this block? (asked first: a satisfied wait costs a bubble too)
+    if (rb.inFlight[f] && !stagedByEot) {  // the copy of two frames ago still reads this block? (asked first: a satisfied wait costs a bubble too)
       if (hipEventQuery(rb.copied[f]) != hipSuccess) hipStreamWaitEvent(c->stream, rb.copied[f], 0);
       (void)hipGetLastError();
     }
     const uint32_t drawMode = (flags & SC_TICK_DRAWS) ? ((flags & SC_TICK_SORT_DRAWS) ? 2u : 1u) : 0u;
-    if (stagedEmit) {
+    if (stagedByEot) c->lastDraws = rb.dBlock[f] + kFrameHeaderWords + rb.maxVisible;       // the end-of-tick kernel wrote the block
+    else if (stagedEmit) {
       launchEmitDrawsStaged(ds, drawBudget, rb.dBlock[f], rb.maxVisible, rb.frames, c->stream, rb.staged[f]);
       c->lastDraws = rb.dBlock[f] + kFrameHeaderWords + rb.maxVisible;       // what scTickReadDraws returns for this tick
     } else launchStageFrame(ds, rb.dBlock[f], rb.maxVisible, rb.maxDraws, c->dDraws, drawMode, rb.frames, c->stream, rb.staged[f]);

@@ -194,6 +194,13 @@ struct TickParams {
                             // 2 records with a remembered slot are stored there directly (kHome*)
   uint32_t homeReset;       // the pair search leaves binCount / binLayers at homeCount / homeLayers instead of zero
   uint32_t borderRecs;      // border messages: records per ring sector of a side, on average (scTickSetBorderCapacity; kBorderRecsPerBin)
+  // draw emission folded into the end-of-tick kernel's compaction role (RenderPrepStreamingSystem, sc_world_partition.cpp:1306-1329): the
+  // workgroup that places a visible entity in the ordered list knows its position there, i.e. the index of its draw item
+  uint32_t emitMode;        // 0 off, 1 items to emitTarget (DrawItem80[]), 2 the frame read-back block at emitTarget (header, visible head, items)
+  uint32_t emitBudget;      // RenderPrepStreaming's draw budget (0 = none)
+  uint32_t emitMaxVisible;  // mode 2: entries of the visible list the block holds
+  uint32_t emitTickLo, emitTickHi;
+  uint32_t* emitTarget;
   uint32_t cleanStay;       // kHomeUse ticks: an entity whose matrix was not rebuilt leaves its (always written) slots as they are -- they hold
                             // this very record; 0 after anything else changed boxes (bounds / matrix uploads) and when the pair half runs pipelined
   uint32_t lazy;            // kHomeUse ticks: reserved records of bins that cannot produce a pair may be left unwritten (DeviceState::lazyCtl);

@@ -891,6 +891,30 @@ __device__ __forceinline__ uint32_t blockSum(uint32_t v, uint32_t* scratch)
 constexpr uint32_t kCompactWordsMax = kTile;                  // visibility words (64 entities each) one workgroup handles the fast way
 constexpr uint32_t kCompactLdsWords = kCompactWordsMax * 6u;  // per word: vis (2 dwords), culled (2), offsets (2)
 
+// Draw emission inside the compaction (TickParams::emitMode): the entity placed at position `off` of the ordered visible list is
+// draw item `off` -- DrawItem{entity, mesh, material, worldMatrix}, the first `budget` of them (sc_world_partition.cpp:1306-1329)
+// -- and, with the frame read-back on, entry `off` of the block's copy of the list.  Same items as k_emit_draws /
+// k_emit_draws_staged write from the finished list; no launch of their own, no second pass over the list.
+__device__ __forceinline__ void emitVisible(const DeviceState& d, const TickParams& p, uint32_t off, uint32_t j)
+{
+  float4* items = reinterpret_cast<float4*>(p.emitTarget);
+  if (p.emitMode == 2u) {
+    if (off < p.emitMaxVisible) p.emitTarget[kFrameHeaderWords + off] = j;
+    items = reinterpret_cast<float4*>(p.emitTarget + kFrameHeaderWords + p.emitMaxVisible);      // (emitMaxVisible is a multiple of 4: 16-byte aligned)
+  }
+  if (p.emitBudget == 0u || off < p.emitBudget) {
+    const float4 a = ldRow(d, 0, j), b = ldRow(d, 1, j), c = ldRow(d, 2, j);
+    float4* o = items + 5u * (size_t)off;
+    o[0] = make_float4(__uint_as_float(j), __uint_as_float(d.meshId[j]), __uint_as_float(d.materialId[j]), 0.0f);
+    o[1] = make_float4(a.x, b.x, c.x, 0.0f);     // column 0
+    o[2] = make_float4(a.y, b.y, c.y, 0.0f);
+    o[3] = make_float4(a.z, b.z, c.z, 0.0f);
+    o[4] = make_float4(a.w, b.w, c.w, 1.0f);     // translation column
+  }
+}
+
+// (kEmit: an instance of its own -- with the emission code merely present the role ran 1.2 us longer on ticks that emit nothing)
+template <bool kEmit>
 __device__ __forceinline__ void compactBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks, uint32_t group,
                                             uint32_t* scratch, uint32_t* moved, uint32_t* words)
 {
@@ -964,6 +988,15 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
       d.counters[0] = tv;            // CullingStats::visible
       d.counters[1] = tc - tv;       // CullingStats::culled
       d.counters[6] = tc;            // renderablesTotal
+      if (kEmit && p.emitMode) {     // RenderPrepStreaming's counts, and the read-back block's header (k_emit_draws_staged's)
+        const uint32_t emitted = (p.emitBudget > 0u && tv > p.emitBudget) ? p.emitBudget : tv;
+        d.counters[4] = emitted; d.counters[5] = tv - emitted;
+        if (p.emitMode == 2u) {
+          const uint32_t nv = tv < p.emitMaxVisible ? tv : p.emitMaxVisible;
+          const uint32_t h[kFrameHeaderWords] = { tv, tc - tv, tc, emitted, tv - emitted, 0u, p.emitTickLo, p.emitTickHi, nv, emitted, 0, 0, 0, 0, 0, 0 };
+          for (uint32_t k = 0; k < kFrameHeaderWords; ++k) p.emitTarget[k] = h[k];
+        }
+      }
     }
     const unsigned long long below = (1ull << lane) - 1ull;
     if (fast) {
@@ -994,7 +1027,11 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
         const uint32_t wi = (i >> 6) - vBegin;           // this thread's wave-tile
         if (wi < vWords) {
           const unsigned long long m = sVis[wi];
-          if ((m >> lane) & 1ull) d.visibleIdx[sOffV[wi] + (uint32_t)__popcll(m & below)] = i;
+          if ((m >> lane) & 1ull) {
+            const uint32_t off = sOffV[wi] + (uint32_t)__popcll(m & below);
+            d.visibleIdx[off] = i;
+            if (kEmit) emitVisible(d, p, off, i);
+          }
           if (doCulled) {
             const unsigned long long c = sCul[wi];
             if ((c >> lane) & 1ull) d.culledIdx[sOffC[wi] + (uint32_t)__popcll(c & below)] = i;
@@ -1019,7 +1056,11 @@ __device__ __forceinline__ void compactBody(const DeviceState& d, const TickPara
         }
         const unsigned long long mine = (wave == 0) ? m[0] : (wave == 1) ? m[1] : (wave == 2) ? m[2] : m[3];
         const uint32_t i = base + threadIdx.x;
-        if ((mine >> lane) & 1ull) d.visibleIdx[off + (uint32_t)__popcll(mine & below)] = i;
+        if ((mine >> lane) & 1ull) {
+          const uint32_t at = off + (uint32_t)__popcll(mine & below);
+          d.visibleIdx[at] = i;
+          if (kEmit) emitVisible(d, p, at, i);
+        }
         if (doCulled) {
           const unsigned long long cm = (wave == 0) ? c[0] : (wave == 1) ? c[1] : (wave == 2) ? c[2] : c[3];
           if ((cm >> lane) & 1ull) d.culledIdx[coff + (uint32_t)__popcll(cm & below)] = i;
@@ -1050,7 +1091,7 @@ __global__ __launch_bounds__(kTile) void k_compact(const DeviceState d, const Ti
   __shared__ uint32_t scratch[kTile / 64];
   __shared__ uint32_t moved[kMaxSpanWords];
   __shared__ uint32_t words[kCompactLdsWords];
-  compactBody(d, p, blockIdx.x, gridDim.x, group, scratch, moved, words);
+  compactBody<false>(d, p, blockIdx.x, gridDim.x, group, scratch, moved, words);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1708,6 +1749,7 @@ __global__ __launch_bounds__(kTile) void k_gather_pairs(const DeviceState d, con
 }
 
 // compaction and pair search both depend only on the fused kernel: one launch, workgroups split by role
+template <bool kEmit>
 __global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_compact_pairs(const DeviceState d, const TickParams p, uint32_t compactBlocks, uint32_t group)
 {
   __shared__ float4 tile[kTile / 64][2 * kBinCap];
@@ -1718,7 +1760,7 @@ __global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_compact_pairs(const Devic
   __shared__ uint32_t moved[kMaxSpanWords];
   // (a workgroup plays one role: the compaction role borrows the pair role's tile area -- 8 KiB >= kCompactLdsWords dwords)
   static_assert(sizeof(tile) >= kCompactLdsWords * sizeof(uint32_t), "compaction scratch does not fit the pair tiles");
-  if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, group, scratch, moved, reinterpret_cast<uint32_t*>(&tile[0][0]));
+  if (blockIdx.x < compactBlocks) compactBody<kEmit>(d, p, blockIdx.x, compactBlocks, group, scratch, moved, reinterpret_cast<uint32_t*>(&tile[0][0]));
   else pairsBody(d, p, blockIdx.x - compactBlocks, gridDim.x - compactBlocks, tile, pairTab, pairBuf, cellMembers);
 }
 
@@ -1912,7 +1954,7 @@ __global__ __launch_bounds__(kTile) void k_compact_pack(const DeviceState d, con
   __shared__ uint32_t moved[kMaxSpanWords];
   __shared__ uint32_t words[kCompactLdsWords];
   if (blockIdx.x == 0 && (p.flags & kFlagDeferredReset)) resetParity(d, p.resetParity);      // pipelined tiles: next tick's counters
-  if (blockIdx.x < compactBlocks) compactBody(d, p, blockIdx.x, compactBlocks, group, scratch, moved, words);
+  if (blockIdx.x < compactBlocks) compactBody<false>(d, p, blockIdx.x, compactBlocks, group, scratch, moved, words);
   else borderPackBody(d, p, blockIdx.x - compactBlocks);
 }
 
@@ -2448,8 +2490,9 @@ void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t comp
   const uint32_t pairGrid = pairGridFor(p);
   const uint32_t g = compactGroup(p, compactGrid, true);
   const uint32_t blocks = (compactGrid + g - 1) / g;
-  if (evA) hipExtLaunchKernelGGL(k_compact_pairs, dim3(blocks + pairGrid), dim3(kTile), 0, s, evA, evB, 0, d, p, blocks, g);
-  else hipLaunchKernelGGL(k_compact_pairs, dim3(blocks + pairGrid), dim3(kTile), 0, s, d, p, blocks, g);
+  auto kernel = p.emitMode ? k_compact_pairs<true> : k_compact_pairs<false>;      // (draw emission in the compaction role: an instance of its own)
+  if (evA || evB) hipExtLaunchKernelGGL(kernel, dim3(blocks + pairGrid), dim3(kTile), 0, s, evA, evB, 0, d, p, blocks, g);
+  else hipLaunchKernelGGL(kernel, dim3(blocks + pairGrid), dim3(kTile), 0, s, d, p, blocks, g);
 }
 void launchGatherPairs(const DeviceState& d, const TickParams& p, uint32_t parity, uint2* dst, uint32_t* total, hipStream_t s)
 {
