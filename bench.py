@@ -442,6 +442,10 @@ def main():
             if args.graph:
                 args.pipeline = 0      # a captured step is one in-order graph per tick parity (successive launches of a graph cannot overlap)
             tiles.setup_tile(t, rank, grid, uid, pipelined=bool(args.pipeline))
+            # the tiled world's layer vocabulary: every tile of a SynthWorld configuration is generated by the same rules, so the
+            # OR over this tile's colliders IS the world's (config 3: static props only; config 5 / config3dyn: dynamic bodies too,
+            # and then every bin is written as before) -- what lets a pipelined tile leave never-needed bins unwritten
+            t.set_world_layers(w.group, w.mask)
             exchange = ("border AABBs to <=8 neighbour tiles per step: one group of ncclSend/ncclRecv issued by libsc_tick.so on its own "
                         "RCCL communicator" + (", on the pairs stream under the next tick's fused kernel" if args.pipeline else ""))
 

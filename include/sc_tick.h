@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SC_TICK_API_VERSION 5u
+#define SC_TICK_API_VERSION 6u
 #define SC_TICK_MAX_ENTITIES ((1u << 24) - 1u)   /* Entity::INDEX_BITS = 24 (sc_ecs.h:18-20); index 0xFFFFFF is the "no parent" value */
 #define SC_TICK_NO_PARENT (-1)
 
@@ -264,6 +264,13 @@ int scTickGetCommInfo(ScTickContext* ctx, ScTickCommInfo* out);
  * stats[0] remembered slots, [1] of those written on every tick, [2] 1 if the last tick was allowed to leave slots unwritten,
  * [3] learn ticks so far.  Reads the slots back (a few MB): not for the frame loop. */
 int scTickGetBinStats(ScTickContext* ctx, uint32_t stats[4]);
+/* The layer VOCABULARY of the tiled world: the OR of the group words and the OR of the mask words of every collider that exists on
+ * ANY tile, now or later (until the next call; bits 0..15, or 0xFFFFFFFF = all, as scTickUploadLayers).  With it a pipelined tile
+ * (scTickSetPipelined / scTickSetPairsStream) leaves the bins unwritten whose own records can meet nothing the world contains --
+ * static props in a world without dynamic bodies, say -- because nothing will ever read them; without it (known = 0, the default)
+ * a pipelined tile writes every record on every tick.  A contract: a collider outside the declared vocabulary (on this tile or
+ * arriving from a neighbour) may miss pairs in such bins.  In-order flows do not need it (they rebuild unwritten bins on demand). */
+int scTickSetWorldLayers(ScTickContext* ctx, uint32_t group_or, uint32_t mask_or, int known);
 int scTickResetHostTimes(ScTickContext* ctx);
 int scTickTileStep(ScTickContext* ctx, uint32_t flags);
 /* the middle third of scTickTileStep on its own, for hosts that interleave other work: after scTickRun(... | SC_TICK_SPLIT_PAIRS) */

@@ -127,6 +127,7 @@ SYMBOLS = {
     "scTickSetPipelined": (C.c_int, [_CTX, C.c_int]),
     "scTickGetCommInfo": (C.c_int, [_CTX, C.POINTER(CommInfo)]),
     "scTickGetBinStats": (C.c_int, [_CTX, U32P]),
+    "scTickSetWorldLayers": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, C.c_int]),
     "scTickResetHostTimes": (C.c_int, [_CTX]),
     "scTickTileStep": (C.c_int, [_CTX, C.c_uint32]),
     "scTickExchangeBorders": (C.c_int, [_CTX]),

@@ -98,6 +98,7 @@ struct ScTickContext
   bool homeEnabled = true, homeValid = false, homeCountsLive = false;
   bool lazyEnabled = true;                             // lazy records (DeviceState::lazyCtl)
   bool lastTickLazy = false; uint32_t learnTicks = 0;  // scTickGetBinStats
+  bool worldLayersKnown = false; uint32_t worldLayers = 0;   // scTickSetWorldLayers: group bits | mask bits << 16 of every collider of the tiled world
   bool boxesTouched = false;                           // bounds or world matrices were uploaded since the last broadphase tick (TickParams::cleanStay)
   uint64_t homeEpoch = ~0ull; uint32_t homeAge = 0, homePeriod = 64;
   bool capturing = false;                              // enqueueStages runs inside a stream capture
@@ -501,7 +502,7 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     if (p.homeMode == kHomeLearn) {
       // the slots handed out by the fused kernel are the remembered ones (the level kernels' and the neighbours' records reserve
       // behind them on every tick); the other copies of the bins start their next tick from the same counts
-      launchSnapshotHome(ds, c->sectors, c->n, p.binSX, p.binSZ, c->stream);
+      launchSnapshotHome(ds, c->sectors, c->n, p.binSX, p.binSZ, (c->pairsStream && c->worldLayersKnown) ? 1u : 0u, c->worldLayers, c->stream);
       if (c->pairsStream)
         for (uint32_t q = 0; q < c->pipeDepth; ++q) {
           if (q == p.parity) continue;
@@ -1253,7 +1254,10 @@ int scTickRun(ScTickContext* c, uint32_t flags)
     p.homeReset = 1u;
     // lazy records: only while nothing but this tick's own pair search reads the bins, and that search runs before the next
     // tick rewrites the world matrices (it rebuilds unwritten records from them)
-    p.lazy = (p.homeMode == kHomeUse && c->lazyEnabled && !c->pairsStream && !(flags & SC_TICK_RAYS) && !c->sensors) ? 1u : 0u;
+    // (a pipelined pair half cannot rebuild -- the matrices are the next tick's by then -- so there only the bins that nothing in the
+    //  world's declared layer vocabulary can meet stay unwritten: they are never needed)
+    p.lazy = (p.homeMode == kHomeUse && c->lazyEnabled && !(flags & SC_TICK_RAYS) && !c->sensors) ? (!c->pairsStream ? 1u : (c->worldLayersKnown ? 2u : 0u)) : 0u;
+    p.vocab = c->worldLayers;
     c->lastTickLazy = p.lazy != 0u;
     // records of entities that did not move stay as they are, unless something else changed boxes since the last tick
     p.cleanStay = (p.homeMode == kHomeUse && c->lazyEnabled && !c->pairsStream && !c->boxesTouched) ? 1u : 0u;
@@ -2153,6 +2157,20 @@ int scTickSelectTrafficDespawns(ScTickContext* c, const float playerPos[3], uint
   std::partial_sort(order.begin(), order.begin() + toRemove, order.end(), before);
   *count = toRemove;
   for (uint32_t k = 0; k < toRemove && k < capacity && denseIndices; ++k) denseIndices[k] = idx[order[k]];
+  return 1;
+}
+
+int scTickSetWorldLayers(ScTickContext* c, uint32_t groupOr, uint32_t maskOr, int known)
+{
+  if (!c) return 0;
+  if (!bind(c)) return 0;
+  if (known && (((groupOr != 0xFFFFFFFFu) && (groupOr >> 16)) || ((maskOr != 0xFFFFFFFFu) && (maskOr >> 16)))) return fail(c, "group/mask bits above 15 are not supported");
+  const uint32_t v = known ? ((groupOr & 0xFFFFu) | ((maskOr & 0xFFFFu) << 16)) : 0u;
+  if ((known != 0) != c->worldLayersKnown || v != c->worldLayers) {
+    if (!sync(c)) return 0;
+    c->worldLayersKnown = known != 0; c->worldLayers = v;
+    c->homeValid = false;               // the slots' "written on every tick" bits follow the vocabulary
+  }
   return 1;
 }
 

@@ -203,8 +203,11 @@ struct TickParams {
   uint32_t* emitTarget;
   uint32_t cleanStay;       // kHomeUse ticks: an entity whose matrix was not rebuilt leaves its (always written) slots as they are -- they hold
                             // this very record; 0 after anything else changed boxes (bounds / matrix uploads) and when the pair half runs pipelined
-  uint32_t lazy;            // kHomeUse ticks: reserved records of bins that cannot produce a pair may be left unwritten (DeviceState::lazyCtl);
-                            // 0 when something else reads the bins (ray queries, traffic sensors) or the pair half runs pipelined
+  uint32_t lazy;            // kHomeUse ticks: reserved records of bins that cannot produce a pair may be left unwritten (DeviceState::lazyCtl):
+                            // 1 = bins whose own records cannot meet each other, rebuilt on demand (in-order flows); 2 = bins whose records
+                            // can meet nothing in the world's declared vocabulary, never needed (pipelined tiles, scTickSetWorldLayers);
+                            // 0 when something else reads the bins (ray queries, traffic sensors) or neither applies
+  uint32_t vocab;           // lazy 2: group bits | mask bits << 16 of every collider that can exist in the tiled world
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d
 __host__ __device__ inline void borderDir(uint32_t d, int& dx, int& dz) { const uint32_t k = d < 4 ? d : d + 1; dx = (int)(k % 3) - 1; dz = (int)(k / 3) - 1; }
@@ -252,7 +255,7 @@ void launchOccupancy(const DeviceState& d, uint32_t n, const float4* q, uint32_t
 
 // launchers (sc_tick_kernels.hip)
 void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA = nullptr, hipEvent_t evB = nullptr);
-void launchSnapshotHome(const DeviceState& d, uint32_t sectors, uint32_t n, uint32_t binSX, uint32_t binSZ, hipStream_t s);
+void launchSnapshotHome(const DeviceState& d, uint32_t sectors, uint32_t n, uint32_t binSX, uint32_t binSZ, uint32_t vocabMode, uint32_t vocab, hipStream_t s);
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 bool launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s, hipEvent_t done = nullptr);

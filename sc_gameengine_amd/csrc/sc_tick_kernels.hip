@@ -275,6 +275,14 @@ __device__ __forceinline__ void nullRecord(float4& lo, float4& hi, uint32_t id =
 // them.  If a record from elsewhere then makes such a bin admissible after all (a vehicle drives in; a big box appears), the
 // wave that searches the bin rebuilds the owners' records from their world matrices (rebuildHomeRecord: the arithmetic of
 // binEntityWave) -- rare, and only where it is needed.  Ring sectors are always written: the border pack copies them.
+// a summary that passes the "two of these records can meet" test exactly when a record of the bin (summary H) and a record of
+// the world's vocabulary V (which includes the bin's own) can: groups of one side against masks of the other, both ways
+__host__ __device__ __forceinline__ uint32_t layersThatCanMeet(uint32_t H, uint32_t V)
+{
+  V |= H;
+  const bool meet = ((V & 0xFFFFu) & (H >> 16)) != 0u && ((H & 0xFFFFu) & (V >> 16)) != 0u;
+  return meet ? 0xFFFFFFFFu : 0u;
+}
 __device__ __forceinline__ bool binWrittenEveryTick(uint32_t homeLayers, uint32_t sector, uint32_t binSX, uint32_t binSZ)
 {
   const uint32_t gx = sector % binSX, gz = sector / binSX;
@@ -532,7 +540,8 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
   // search learns from lazyCtl[1] what this kernel did
   bool lazyOn = false;
   if (kAabb) {
-    lazyOn = kHome == kHomeUse && p.lazy != 0u && d.lazyCtl[0] == 0u;      // (first needed at the end of the first tile; noted for the pair search below)
+    // (p.lazy 2: the unwritten bins are those nothing in the world can meet -- big boxes included, so no guard)
+    lazyOn = kHome == kHomeUse && (p.lazy == 2u || (p.lazy == 1u && d.lazyCtl[0] == 0u));      // (first needed at the end of the first tile; noted for the pair search below)
   }
 
   for (uint32_t base = begin; base < end; base += kTile) {
@@ -1260,7 +1269,10 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   const uint32_t novf = min(d.counters[ctr + kCtrSpill], p.ovfCap);     // sector overflow list: own boxes and neighbours' border records
   // lazy records: did this tick's fused kernel write every remembered slot?  If not, the slots of a bin whose own records admit
   // no pair hold old records, and a wave that needs such a bin rebuilds them (rebuildHomeRecord)
-  const bool freshAll = !p.homeReset || d.lazyCtl[1] != 0u;
+  // (p.lazy: 0 = the fused kernel wrote everything; 1 = it says what it did -- big boxes make it write everything; 2 = it left
+  //  unwritten what nothing in the world can meet, see k_home_flags)
+  const bool freshAll = !p.homeReset || p.lazy == 0u || (p.lazy == 1u && d.lazyCtl[1] != 0u);
+  const bool vocabMode = p.lazy == 2u;
   if (bid == 0u && threadIdx.x == 0u) d.lazyCtl[0] = nbig;             // (what the next fused kernel goes by)
   float4* T = tile[wave];
   PairSink sink = { pairBuf[wave], 0u, bid % kPairShards };
@@ -1308,8 +1320,11 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       if (p.homeReset) { hc = d.homeCount[mySector]; hl = d.homeLayers[mySector]; hot = (hc & kHomeHot) != 0u; hc &= ~kHomeHot; }
       if (myCount != hc || lay != hl) { d.binCount[mySector] = hc; d.binLayers[mySector] = hl; }
       myHome = hc;
-      myStale = !freshAll && !hot && hc != 0u && ((hl & 0xFFFFu) & (hl >> 16)) == 0u &&
+      const uint32_t hlTest = vocabMode ? layersThatCanMeet(hl, p.vocab) : hl;
+      myStale = !freshAll && !hot && hc != 0u && ((hlTest & 0xFFFFu) & (hlTest >> 16)) == 0u &&
                 !(myGx == 0u || myGz == 0u || myGx + 1u == p.binSX || myGz + 1u == p.binSZ);      // (!binWrittenEveryTick)
+      // vocabulary mode: the bin's own records meet nothing that exists -- without records from elsewhere there is nothing to read
+      if (myStale && vocabMode && myCount <= hc) myCount = 0u;
       if (myCount) {
         // no record of this bin can pass the group/mask filter against another one: nothing to read
         if (nbig == 0u && ((lay & 0xFFFFu) & (lay >> 16)) == 0u) myCount = 0u;      // (a crowded sector's overflow slice is reset by the workgroup that takes it off the queue)
@@ -1337,14 +1352,15 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
         const uint32_t sK = __shfl(mySector, k, 64), hcK = __shfl(myHome, k, 64);
         if (lane < hcK) {
           float4* r = d.bins + 2u * ((size_t)sK * kBinCap + lane);
-          float4 lo = r[0], hi = r[1];
-          rebuildHomeRecord(d, p, sK, lo, hi);
+          float4 lo, hi;
+          if (vocabMode) nullRecord(lo, hi);               // (the owners' records meet nothing: records from elsewhere are searched among themselves)
+          else { lo = r[0]; hi = r[1]; rebuildHomeRecord(d, p, sK, lo, hi); }
           r[0] = lo; r[1] = hi;
         }
       }
       __threadfence();
       // (marked behind the fence: whoever sees the mark -- the workgroup that takes a crowded sector off the queue -- sees the records)
-      if (myStale && myCount != 0u) d.homeCount[mySector] = myHome | kHomeHot;
+      if (!vocabMode && myStale && myCount != 0u) d.homeCount[mySector] = myHome | kHomeHot;
     }
     // what a sector's turn needs from the lane that holds it: index, count, layer summary, grid coordinates -- four
     // cross-lane reads.  (ds_bpermute although the picked lane is wave-uniform: v_readlane measured slower, 27.1 against
@@ -1583,11 +1599,13 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     // lazy records: the bin's remembered slots hold old records -- rebuilt in place (the sweep's wave may have done so already,
     // or be doing it now: same ids, same values)
     const uint32_t hcRaw = freshAll ? kHomeHot : d.homeCount[s];     // (the sweep's wave may have marked the bin hot a moment ago: then it rebuilt it, too)
-    if (!(hcRaw & kHomeHot) && !binWrittenEveryTick(d.homeLayers[s], s, p.binSX, p.binSZ)) {
+    const uint32_t hlS = freshAll ? 0u : d.homeLayers[s];
+    if (!(hcRaw & kHomeHot) && !binWrittenEveryTick(vocabMode ? layersThatCanMeet(hlS, p.vocab) : hlS, s, p.binSX, p.binSZ)) {
       if (wave == 0u && lane < hcRaw) {
         float4* r = d.bins + 2u * ((size_t)s * kBinCap + lane);
-        float4 lo = r[0], hi = r[1];
-        rebuildHomeRecord(d, p, s, lo, hi);
+        float4 lo, hi;
+        if (vocabMode) nullRecord(lo, hi);
+        else { lo = r[0]; hi = r[1]; rebuildHomeRecord(d, p, s, lo, hi); }
         r[0] = lo; r[1] = hi;
       }
       __threadfence();
@@ -2357,7 +2375,11 @@ __global__ __launch_bounds__(kTile) void k_snapshot_home(const DeviceState d, ui
 
 // ... and every remembered slot learns whether its bin is one that is written on every tick (lazy records): a bin whose
 // reserved records can pass the group/mask filter against each other, or a ring sector (the border pack reads those).
-__global__ __launch_bounds__(kTile) void k_home_flags(const DeviceState d, uint32_t n, uint32_t binSX, uint32_t binSZ)
+// With the world's layer VOCABULARY declared (scTickSetWorldLayers) and the pair half pipelined, "written on every tick" means:
+// some record that can exist anywhere in the world could pass the filter against one of the bin's own -- the bins that fail THAT
+// test are never read by anybody, on any tick, so they need no rebuild either (which a pipelined pair half could not do: the
+// owners' matrices are the next tick's by then).
+__global__ __launch_bounds__(kTile) void k_home_flags(const DeviceState d, uint32_t n, uint32_t binSX, uint32_t binSZ, uint32_t vocabMode, uint32_t vocab)
 {
   const uint32_t i = blockIdx.x * kTile + threadIdx.x;
   if (i >= n) return;
@@ -2368,7 +2390,8 @@ __global__ __launch_bounds__(kTile) void k_home_flags(const DeviceState d, uint3
   for (uint32_t k = 0; k < 4u; ++k) {
     if (((hB >> (8u * k)) & 0xFFu) == kNoSlot) continue;
     const uint32_t sec = hA + (k & 1u) + (k >> 1) * binSX;
-    if (binWrittenEveryTick(d.homeLayers[sec], sec, binSX, binSZ)) hB |= kSlotAlways << (8u * k);
+    const uint32_t H = d.homeLayers[sec];
+    if (binWrittenEveryTick(vocabMode ? layersThatCanMeet(H, vocab) : H, sec, binSX, binSZ)) hB |= kSlotAlways << (8u * k);
   }
   d.homeB[i] = hB;
 }
@@ -2376,11 +2399,11 @@ __global__ __launch_bounds__(kTile) void k_home_flags(const DeviceState d, uint3
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-void launchSnapshotHome(const DeviceState& d, uint32_t sectors, uint32_t n, uint32_t binSX, uint32_t binSZ, hipStream_t s)
+void launchSnapshotHome(const DeviceState& d, uint32_t sectors, uint32_t n, uint32_t binSX, uint32_t binSZ, uint32_t vocabMode, uint32_t vocab, hipStream_t s)
 {
   if (!sectors) return;
   hipLaunchKernelGGL(k_snapshot_home, dim3((sectors + kTile - 1) / kTile), dim3(kTile), 0, s, d, sectors);
-  if (n) hipLaunchKernelGGL(k_home_flags, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, binSX, binSZ);
+  if (n) hipLaunchKernelGGL(k_home_flags, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, binSX, binSZ, vocabMode, vocab);
 }
 // `done` (may be null): recorded by the dispatch itself -- the event the copy stream waits for, without a marker packet
 void launchEmitDrawsStaged(const DeviceState& d, uint32_t budget, uint32_t* block, uint32_t maxVisible, uint64_t tick, hipStream_t s, hipEvent_t done)

@@ -410,6 +410,12 @@ class WorldTick:
         self._ok(self.lib.scTickGetCommInfo(self.ctx, C.byref(ci)), "scTickGetCommInfo")
         return {k: (list(getattr(ci, k)) if k == "peer_rank" else getattr(ci, k)) for k, _ in capi.CommInfo._fields_}
 
+    def set_world_layers(self, group, mask, known=True):
+        """the tiled world's layer vocabulary: arrays (or ORs) of the group and mask words of every collider on ANY tile (scTickSetWorldLayers)"""
+        g = int(np.bitwise_or.reduce(np.asarray(group, np.uint32).ravel())) if np.ndim(group) else int(group)
+        m = int(np.bitwise_or.reduce(np.asarray(mask, np.uint32).ravel())) if np.ndim(mask) else int(mask)
+        self._ok(self.lib.scTickSetWorldLayers(self.ctx, g, m, 1 if known else 0), "scTickSetWorldLayers")
+
     def bin_stats(self):
         """how the broadphase bins are filled: remembered slots, those written on every tick, whether the last tick could leave slots unwritten, learn ticks"""
         st = np.zeros(4, np.uint32)

@@ -331,3 +331,79 @@ def test_pipelined_tiles_overlap_pair_search_with_the_next_tick(oracle, grid):
     for t in ticks:
         t.close()
     ow.close()
+
+
+@pytest.mark.parametrize("declare", [True, False])
+def test_pipelined_tiles_leave_unwritten_what_nothing_in_the_world_can_meet(oracle, declare):
+    """scTickSetWorldLayers: with the world's layer vocabulary declared, a PIPELINED tile leaves the bins unwritten whose own
+    records can meet nothing the world contains (here: static props 2/1 in a world whose other bodies are 4/8 and 8/4, which
+    only meet each other) -- nobody will ever read them, so nothing has to be rebuilt either.  Bodies of the two meeting kinds
+    drift through prop-only sectors and across tile borders, big boxes of one kind travel in the messages: the pair set is the
+    whole world's, with the declaration and without it (then every record is written)."""
+    import torch
+    grid, S = (2, 2), (6, 6)
+    w = sw.generate(S[0] * grid[0], S[1] * grid[1], 15, tiles=grid)
+    rng = np.random.default_rng(31)
+    roots = np.flatnonzero((w.parent < 0) & (np.arange(w.n) % 16 != 0))
+    kind = rng.choice(roots, len(roots) // 5, replace=False)
+    a, b = kind[: len(kind) // 2], kind[len(kind) // 2:]
+    w.group[a], w.mask[a] = 4, 8
+    w.group[b], w.mask[b] = 8, 4
+    # the meeting kinds in clusters, so that there are pairs: every b next to some a
+    b = b[: len(a)]
+    w.pos[b] = w.pos[a[: len(b)]] + rng.uniform(-1.5, 1.5, (len(b), 3)).astype(np.float32) * np.float32([1, 0.2, 1])
+    edge = rng.choice(a, len(a) // 4, replace=False)
+    w.pos[edge, 0] = (np.round(w.pos[edge, 0] / (64.0 * S[0])) * 64.0 * S[0] + rng.uniform(-1.0, 1.0, len(edge))).astype(np.float32)
+    big = rng.choice(a, 6, replace=False)
+    w.bmin[big] *= 150.0; w.bmax[big] *= 150.0
+    parts, n = split_world(w, grid, S)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    ticks, bufs, s1, s2 = [], [], [], []
+    for r, p in enumerate(parts):
+        t = WorldTick.from_world(p, broadphase=True, max_pairs=1 << 16)
+        x, y = torch.cuda.Stream(), torch.cuda.Stream()
+        t.set_stream(x.cuda_stream, external=True)
+        t.set_pairs_stream(y.cuda_stream)
+        if declare:
+            t.set_world_layers(w.group, w.mask)
+        t.set_frame_producer(1, 1.3)
+        ticks.append(t); s1.append(x); s2.append(y)
+        bufs.append(tiles.BorderBuffers(t, r, grid, "cuda", pipelined=True))
+    flags = capi.XFORM | capi.BROADPHASE | capi.SPLIT_PAIRS | capi.PRODUCE_NEXT
+    for t in ticks:
+        t.nudge_roots_x(1.3)
+    steps = 9
+    for step in range(steps):
+        q = step % len(bufs[0].sets)
+        for t in ticks:
+            t.run(flags)
+        for r, bb in enumerate(bufs):
+            for d, nb in tiles.neighbours(r, grid).items():
+                s2[nb].wait_stream(s1[r])
+                with torch.cuda.stream(s2[nb]):
+                    bufs[nb].sets[q][3][7 - d].copy_(bb.sets[q][2][d], non_blocking=True)
+        for t in ticks:
+            t.run_pairs()
+    for _ in range(steps):
+        ow.nudge_roots_x(1.3)
+    ow.transform_system()
+    mn, mx = ow.world_aabbs()
+    want = oracle.broadphase_grid(mn, mx, w.group, w.mask, 16.0)
+    got = []
+    for t in ticks:
+        p, total = t.pairs()
+        c = t.counts()
+        assert total == len(p) and c.border_lost == 0 and c.pairs_truncated == 0
+        got.append(tiles.global_pair_ids(p, n))
+        bs = t.bin_stats()
+        assert bs["lazy_last_tick"] == declare
+        if declare:
+            assert 0 < bs["written_every_tick"] < bs["remembered_slots"] * 3 // 4      # prop-only bins stay unwritten
+    got = np.concatenate(got).astype(np.uint64)
+    lo, hi = np.minimum(got[:, 0], got[:, 1]), np.maximum(got[:, 0], got[:, 1])
+    key = np.sort(lo << np.uint64(32) | hi)
+    wkey = want[:, 0].astype(np.uint64) << np.uint64(32) | want[:, 1].astype(np.uint64)
+    assert len(key) == len(np.unique(key))
+    assert np.array_equal(key, wkey), f"{len(np.setdiff1d(wkey, key))} missing, {len(np.setdiff1d(key, wkey))} unexpected of {len(wkey)}"
+    assert len(wkey) > 100
+    torch.cuda.synchronize()

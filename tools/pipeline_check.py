@@ -23,6 +23,7 @@ ap.add_argument("--workload", default="config3")
 ap.add_argument("--graph", type=int, default=0)
 ap.add_argument("--row", type=int, default=0, help="1: centre tile of a 3x1 world (two neighbours, 4 operations per group) instead of 3x3 (eight, 16)")
 ap.add_argument("--only", type=int, default=-1, help="run one flow only: 0 in order, 2..4 pipelined with that depth")
+ap.add_argument("--vocab", type=int, default=1, help="1: declare the world's layer vocabulary (scTickSetWorldLayers), 0: do not")
 args = ap.parse_args()
 
 S = 256
@@ -46,6 +47,8 @@ for pipelined in (0, 2, 3, 4):
         t.set_tile(4, 0xFF); t.set_tile_grid(1, 1, 3, 3)
         t.comm_init(capi.comm_unique_id(), 1, 0, peers=[0] * 8)
     t.set_pipelined(pipelined)
+    if args.vocab:
+        t.set_world_layers(w.group, w.mask)
     t.set_frame_producer(1, 0.01); t.nudge_roots_x(0.01)
     if args.graph:
         t.set_graph_mode(True)

@@ -42,6 +42,10 @@ for seed in range(args.seeds):
     w = sw.generate(S[0] * grid[0], S[1] * grid[1], K, tiles=grid)
     dyn = rng.random(w.n) < float(rng.choice([0.05, 0.3, 1.0]))
     w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    cross = seed % 3 == 1           # a world whose moving bodies are of two kinds that only meet each other (4/8 and 8/4): props meet nothing
+    if cross:
+        k = rng.integers(0, 2, w.n)
+        w.group[dyn] = np.where(k[dyn] == 0, 4, 8).astype(np.uint32); w.mask[dyn] = np.where(k[dyn] == 0, 8, 4).astype(np.uint32)
     roots = np.flatnonzero((w.parent < 0) & (np.arange(w.n) % (K + 1) != 0))
     per_tile = w.n // (grid[0] * grid[1])
     TW, TH = 64.0 * S[0], 64.0 * S[1]
@@ -73,6 +77,9 @@ for seed in range(args.seeds):
     if pipelined:
         for t, s in zip(ticks, streams):
             t.set_pairs_stream(s.cuda_stream)
+    if seed % 2 == 1:               # the world's layer vocabulary declared: pipelined tiles leave never-needed bins unwritten
+        for t in ticks:
+            t.set_world_layers(w.group, w.mask)
     bufs = [tiles.BorderBuffers(t, r, grid, "cuda", pipelined=pipelined) for r, t in enumerate(ticks)]
     nudge = float(rng.choice([0.3, 0.9, 3.0]))
     state = "equal"
