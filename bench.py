@@ -39,8 +39,8 @@ def records_written_frac(t):
     bins that admit no pair unwritten and unchanged records alone ("Records nobody reads")"""
     bs = t.bin_stats()
     if not bs["lazy_last_tick"] or not bs["remembered_slots"]:
-        return 1.0, False
-    return bs["written_every_tick"] / bs["remembered_slots"], True
+        return 1.0, bs["unchanged_records_stay"]
+    return bs["written_every_tick"] / bs["remembered_slots"], bs["unchanged_records_stay"]
 
 
 def algorithmic_bytes_per_entity(child_frac, stages, dirty_frac=1.0, records_frac=1.0, clean_stay=False):

@@ -261,8 +261,8 @@ int scTickGetCommInfo(ScTickContext* ctx, ScTickCommInfo* out);
  * whose own records cannot pass the group/mask filter against each other -- static props only -- are not even written until a
  * record from elsewhere needs them (the pair search then rebuilds them; SC_TICK_VARIANT bit 5 switches that off; ticks with
  * ray queries or traffic sensors, and pipelined tiles, write every record).
- * stats[0] remembered slots, [1] of those written on every tick, [2] 1 if the last tick was allowed to leave slots unwritten,
- * [3] learn ticks so far.  Reads the slots back (a few MB): not for the frame loop. */
+ * stats[0] remembered slots, [1] of those written on every tick, [2] bit 0: the last tick was allowed to leave the other slots
+ * unwritten, bit 1: it left records of entities whose matrix was not rebuilt as they were, [3] learn ticks so far.  Reads the slots back (a few MB): not for the frame loop. */
 int scTickGetBinStats(ScTickContext* ctx, uint32_t stats[4]);
 /* The layer VOCABULARY of the tiled world: the OR of the group words and the OR of the mask words of every collider that exists on
  * ANY tile, now or later (until the next call; bits 0..15, or 0xFFFFFFFF = all, as scTickUploadLayers).  With it a pipelined tile

@@ -97,7 +97,7 @@ struct ScTickContext
   // home slots of the bins (binEntityWave): remembered at a learn tick, used until the world's shape changes or they age
   bool homeEnabled = true, homeValid = false, homeCountsLive = false;
   bool lazyEnabled = true;                             // lazy records (DeviceState::lazyCtl)
-  bool lastTickLazy = false; uint32_t learnTicks = 0;  // scTickGetBinStats
+  bool lastTickLazy = false, lastTickStay = false; uint32_t learnTicks = 0;  // scTickGetBinStats
   bool worldLayersKnown = false; uint32_t worldLayers = 0;   // scTickSetWorldLayers: group bits | mask bits << 16 of every collider of the tiled world
   bool boxesTouched = false;                           // bounds or world matrices were uploaded since the last broadphase tick (TickParams::cleanStay)
   uint64_t homeEpoch = ~0ull; uint32_t homeAge = 0, homePeriod = 64;
@@ -1261,6 +1261,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
     c->lastTickLazy = p.lazy != 0u;
     // records of entities that did not move stay as they are, unless something else changed boxes since the last tick
     p.cleanStay = (p.homeMode == kHomeUse && c->lazyEnabled && !c->pairsStream && !c->boxesTouched) ? 1u : 0u;
+    c->lastTickStay = p.cleanStay != 0u;
     c->boxesTouched = false;
     c->homeCountsLive = true;
   }
@@ -2180,7 +2181,7 @@ int scTickGetBinStats(ScTickContext* c, uint32_t stats[4])
   stats[0] = stats[1] = stats[2] = stats[3] = 0u;
   if (!bind(c)) return 0;
   if (!c->d.homeA || !c->n) return 1;
-  stats[2] = c->lastTickLazy ? 1u : 0u; stats[3] = c->learnTicks;
+  stats[2] = (c->lastTickLazy ? 1u : 0u) | (c->lastTickStay ? 2u : 0u); stats[3] = c->learnTicks;
   if (!c->homeValid) return 1;
   if (!sync(c)) return 0;
   std::vector<uint32_t> a(c->n), b(c->n);

@@ -420,7 +420,8 @@ class WorldTick:
         """how the broadphase bins are filled: remembered slots, those written on every tick, whether the last tick could leave slots unwritten, learn ticks"""
         st = np.zeros(4, np.uint32)
         self._ok(self.lib.scTickGetBinStats(self.ctx, _u(st)), "scTickGetBinStats")
-        return {"remembered_slots": int(st[0]), "written_every_tick": int(st[1]), "lazy_last_tick": bool(st[2]), "learn_ticks": int(st[3])}
+        return {"remembered_slots": int(st[0]), "written_every_tick": int(st[1]), "lazy_last_tick": bool(st[2] & 1),
+                "unchanged_records_stay": bool(st[2] & 2), "learn_ticks": int(st[3])}
 
     def reset_host_times(self):
         self._ok(self.lib.scTickResetHostTimes(self.ctx), "scTickResetHostTimes")
