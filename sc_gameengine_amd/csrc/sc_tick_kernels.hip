@@ -1255,6 +1255,9 @@ __device__ __forceinline__ void rebuildHomeRecord(const DeviceState& d, const Ti
   rmin = lo; rmax = hi;
 }
 
+// (kVocab: the vocabulary form of the lazy records, TickParams::lazy 2 -- an instance of its own, only ever the pairs-stream
+//  kernel's: with its branches merely present the in-order end-of-tick kernel ran 0.6 us (config 3) to 2.4 us (config 5) longer)
+template <bool kVocab>
 __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks,
                                           float4 (*tile)[2 * kBinCap], uint16_t* pairTab, uint2 (*pairBuf)[kWavePairBuf],
                                           unsigned long long (*cellMembers)[kCellWords])
@@ -1271,8 +1274,9 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   // no pair hold old records, and a wave that needs such a bin rebuilds them (rebuildHomeRecord)
   // (p.lazy: 0 = the fused kernel wrote everything; 1 = it says what it did -- big boxes make it write everything; 2 = it left
   //  unwritten what nothing in the world can meet, see k_home_flags)
-  const bool freshAll = !p.homeReset || p.lazy == 0u || (p.lazy == 1u && d.lazyCtl[1] != 0u);
-  const bool vocabMode = p.lazy == 2u;
+  //  (the flag is read unconditionally, up front with the other scalars: behind a test of p.lazy it cost every workgroup a stall)
+  const bool freshAll = kVocab ? false : (!p.homeReset || d.lazyCtl[1] != 0u);
+  constexpr bool vocabMode = kVocab;                   // (the launcher picks the instance by p.lazy)
   if (bid == 0u && threadIdx.x == 0u) d.lazyCtl[0] = nbig;             // (what the next fused kernel goes by)
   float4* T = tile[wave];
   PairSink sink = { pairBuf[wave], 0u, bid % kPairShards };
@@ -1599,8 +1603,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     // lazy records: the bin's remembered slots hold old records -- rebuilt in place (the sweep's wave may have done so already,
     // or be doing it now: same ids, same values)
     const uint32_t hcRaw = freshAll ? kHomeHot : d.homeCount[s];     // (the sweep's wave may have marked the bin hot a moment ago: then it rebuilt it, too)
-    const uint32_t hlS = freshAll ? 0u : d.homeLayers[s];
-    if (!(hcRaw & kHomeHot) && !binWrittenEveryTick(vocabMode ? layersThatCanMeet(hlS, p.vocab) : hlS, s, p.binSX, p.binSZ)) {
+    if (!(hcRaw & kHomeHot) && !binWrittenEveryTick(vocabMode ? layersThatCanMeet(d.homeLayers[s], p.vocab) : d.homeLayers[s], s, p.binSX, p.binSZ)) {
       if (wave == 0u && lane < hcRaw) {
         float4* r = d.bins + 2u * ((size_t)s * kBinCap + lane);
         float4 lo, hi;
@@ -1737,13 +1740,14 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   sinkFlush(d, p, sink);
 }
 
+template <bool kVocab>
 __global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_pairs(const DeviceState d, const TickParams p)
 {
   __shared__ float4 tile[kTile / 64][2 * kBinCap];        // 2 KiB per wave: the bin as an LDS tile
   __shared__ uint16_t pairTab[kPairTabSize];              // q -> (i << 8 | j), 0 <= j < i < 64
   __shared__ uint2 pairBuf[kTile / 64][kWavePairBuf];     // 2 KiB per wave: hits waiting for a flush
   __shared__ unsigned long long cellMembers[kTile / 64][kCellWords];   // per wave: which records touch each of the 4x4 cells, per tile of 64
-  pairsBody(d, p, blockIdx.x, gridDim.x, tile, pairTab, pairBuf, cellMembers);
+  pairsBody<kVocab>(d, p, blockIdx.x, gridDim.x, tile, pairTab, pairBuf, cellMembers);
 }
 
 // read-back helper: concatenates the shards' segments into one list and writes the total found
@@ -1779,7 +1783,7 @@ __global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_compact_pairs(const Devic
   // (a workgroup plays one role: the compaction role borrows the pair role's tile area -- 8 KiB >= kCompactLdsWords dwords)
   static_assert(sizeof(tile) >= kCompactLdsWords * sizeof(uint32_t), "compaction scratch does not fit the pair tiles");
   if (blockIdx.x < compactBlocks) compactBody<kEmit>(d, p, blockIdx.x, compactBlocks, group, scratch, moved, reinterpret_cast<uint32_t*>(&tile[0][0]));
-  else pairsBody(d, p, blockIdx.x - compactBlocks, gridDim.x - compactBlocks, tile, pairTab, pairBuf, cellMembers);
+  else pairsBody<false>(d, p, blockIdx.x - compactBlocks, gridDim.x - compactBlocks, tile, pairTab, pairBuf, cellMembers);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2504,8 +2508,9 @@ static uint32_t pairGridFor(const TickParams& p)
 bool launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s, hipEvent_t done)
 {
   if (!(p.binSX * p.binSZ)) return false;
-  if (done) hipExtLaunchKernelGGL(k_pairs, dim3(pairGridFor(p)), dim3(kTile), 0, s, nullptr, done, 0, d, p);
-  else hipLaunchKernelGGL(k_pairs, dim3(pairGridFor(p)), dim3(kTile), 0, s, d, p);
+  auto kernel = p.lazy == 2u ? k_pairs<true> : k_pairs<false>;
+  if (done) hipExtLaunchKernelGGL(kernel, dim3(pairGridFor(p)), dim3(kTile), 0, s, nullptr, done, 0, d, p);
+  else hipLaunchKernelGGL(kernel, dim3(pairGridFor(p)), dim3(kTile), 0, s, d, p);
   return true;
 }
 void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s, hipEvent_t evA, hipEvent_t evB)
