@@ -23,6 +23,7 @@ ap.add_argument("--workload", default="config3")
 ap.add_argument("--graph", type=int, default=0)
 ap.add_argument("--row", type=int, default=0, help="1: centre tile of a 3x1 world (two neighbours, 4 operations per group) instead of 3x3 (eight, 16)")
 ap.add_argument("--only", type=int, default=-1, help="run one flow only: 0 in order, 2..4 pipelined with that depth")
+ap.add_argument("--border", type=int, default=0, help="scTickSetBorderCapacity: records per ring sector a message holds on average (0 = the default, 16)")
 ap.add_argument("--vocab", type=int, default=1, help="1: declare the world's layer vocabulary (scTickSetWorldLayers), 0: do not")
 args = ap.parse_args()
 
@@ -40,6 +41,8 @@ for pipelined in (0, 2, 3, 4):
         continue
     t = WorldTick.from_world(w, broadphase=True)
     t.set_view_proj(camera_view_proj(w.camera))
+    if args.border:
+        t.set_border_capacity(args.border)
     if args.row:
         t.set_tile(1, 0b00011000); t.set_tile_grid(1, 0, 3, 1)
         t.comm_init(capi.comm_unique_id(), 1, 0, peers=[-1, -1, -1, 0, 0, -1, -1, -1])
