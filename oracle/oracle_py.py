@@ -115,6 +115,8 @@ def lib():
     L.orc_is_occupied.argtypes = [vp, U8P, F32P, C.c_float]
     L.orc_is_occupied.restype = C.c_int
     L.orc_raycast_boxes.argtypes = [C.c_uint32, F32P, F32P, U32P, U32P, C.c_uint32, F32P, F32P, F32P, U32P, C.c_void_p]
+    L.orc_ray_box_probe.argtypes = [F32P, F32P, C.c_float, F32P, F32P, F32P]
+    L.orc_ray_box_probe.restype = C.c_int
     L.orc_lanes_new.restype = vp
     L.orc_lanes_free.argtypes = [vp]
     L.orc_lanes_build_sector.argtypes = [vp, C.c_int32, C.c_int32, C.c_float, U32P]
@@ -185,6 +187,15 @@ def frustum_from_viewproj(vp):
     lib().orc_frustum_from_viewproj(_f(vp), C.byref(fr))
     planes = np.array([[p.n[0], p.n[1], p.n[2], p.d] for p in fr.planes], np.float32)
     return planes, int(fr.valid)
+
+
+def ray_box_probe(origin, direction, tmax, mn, mx):
+    """The oracle's ray-box slab test alone (intersectRayAABB's arithmetic with the far limit `tmax`): (hit, t)."""
+    L = lib()
+    o, dv, a, b = (np.ascontiguousarray(x, np.float32) for x in (origin, direction, mn, mx))
+    t = np.zeros(1, np.float32)
+    hit = L.orc_ray_box_probe(_f(o), _f(dv), np.float32(tmax), _f(a), _f(b), _f(t))
+    return bool(hit), t[0]
 
 
 def raycast_boxes(mn, mx, group, mask, origin, direction, max_dist, ray_mask):

@@ -938,6 +938,15 @@ static int ray_box(const float o[3], const float dir[3], float maxDist, const fl
   return 1;
 }
 
+/* the slab test alone, for pinning it against the reference's own intersectRayAABB (tests/golden/ray_aabb_ref.npz): tmax = 1e30f there */
+int orc_ray_box_probe(const float origin[3], const float dir[3], float tmax, const float mn[3], const float mx[3], float* tOut)
+{
+  int axis; float t = 0.0f;
+  const int hit = ray_box(origin, dir, tmax, mn, mx, &t, &axis);
+  if (hit && tOut) *tOut = t;
+  return hit;
+}
+
 void orc_raycast_boxes(uint32_t n, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
                        uint32_t rays, const float* origin3, const float* dir3, const float* maxDist, const uint32_t* rayMask,
                        OrcRayHit* out)

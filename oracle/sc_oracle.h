@@ -174,6 +174,7 @@ uint64_t orc_broadphase_grid(uint32_t n, const float* min3, const float* max3,
 
 /* ---- ray queries (own spec; see sc_oracle.c): brute force over all boxes, group/mask as uploaded (low 16 bits) ---- */
 typedef struct OrcRayHit { uint32_t hit, id; float distance; float position[3]; float normal[3]; uint32_t layer; uint32_t pad[2]; } OrcRayHit;
+int  orc_ray_box_probe(const float origin[3], const float dir[3], float tmax, const float mn[3], const float mx[3], float* tOut);
 void orc_raycast_boxes(uint32_t n, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
                        uint32_t rays, const float* origin3, const float* dir3, const float* maxDist, const uint32_t* rayMask,
                        OrcRayHit* out);

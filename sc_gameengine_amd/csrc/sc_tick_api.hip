@@ -84,6 +84,7 @@ struct ScTickContext
   TickParams graphParams[kMaxParity]{};
   bool graphWhole[kMaxParity] = {};                    // the captured graph holds the whole tile step (exchange + pair half)
   bool captureWholeStep = false;                       // set by scTickTileStep around its scTickRun
+  bool ownStep = false;                                // scTickTileStep is running: the pair half follows the tick half at once, nothing of the host's in between
   uint64_t topoEpoch = 0, graphEpoch[kMaxParity] = { ~0ull, ~0ull, ~0ull, ~0ull };
   // pipelined tile + graph replay: the pair half (exchange, merge, queries, pair search, snapshot) is a graph of its own,
   // replayed on the pairs stream; the two graphs of a step are ordered by events recorded between them, outside any capture
@@ -97,10 +98,13 @@ struct ScTickContext
   // home slots of the bins (binEntityWave): remembered at a learn tick, used until the world's shape changes or they age
   bool homeEnabled = true, homeValid = false, homeCountsLive = false;
   bool lazyEnabled = true;                             // lazy records (DeviceState::lazyCtl)
+  bool fastPairs = true;                               // ordered home slots: bins without visitors take the pair role's fast path (DeviceState::homeCast)
   bool lastTickLazy = false, lastTickStay = false; uint32_t learnTicks = 0;  // scTickGetBinStats
   bool worldLayersKnown = false; uint32_t worldLayers = 0;   // scTickSetWorldLayers: group bits | mask bits << 16 of every collider of the tiled world
   bool boxesTouched = false;                           // bounds or world matrices were uploaded since the last broadphase tick (TickParams::cleanStay)
   uint64_t homeEpoch = ~0ull; uint32_t homeAge = 0, homePeriod = 64;
+  uint32_t homeXform = 0;                              // SC_TICK_XFORM of the learn tick: entities deeper than the fused kernel's chain are binned by the level
+                                                       // kernels on transforming ticks and by the fused kernel otherwise -- slots learned one way are not valid the other
   bool capturing = false;                              // enqueueStages runs inside a stream capture
   bool packedRides = false;                            // this tick's `packed` event was attached to the compaction + pack dispatch
 
@@ -704,11 +708,23 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
             && dalloc(c, d.ovfIdx, (size_t)kOvfWaves * kOvfPerSector, false) && dalloc(c, d.ovfLo, c->sectors, false) && dalloc(c, d.ovfHi, c->sectors)
             && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, (kMaxParity + 1u) * kPairShards * kShardStride)
             && dalloc(c, c->dPairsOut, c->maxPairs, false) && dalloc(c, c->dPairTotal, 4)
-            && dalloc(c, d.homeA, N, false) && dalloc(c, d.homeB, N, false) && dalloc(c, d.homeCount, c->sectors) && dalloc(c, d.homeLayers, c->sectors) && dalloc(c, d.lazyCtl, 4);
+            && dalloc(c, d.homeA, N, false) && dalloc(c, d.homeB, N, false) && dalloc(c, d.homeCount, c->sectors) && dalloc(c, d.homeLayers, c->sectors) && dalloc(c, d.lazyCtl, 1u + kMaxParity)
+            && dalloc(c, d.homeCast, c->sectors) && dalloc(c, d.homePerm, (size_t)c->sectors * kBinCap);
     if (ok) { e = hipMemset(d.homeA, 0xFF, N * sizeof(uint32_t)); if (e == hipSuccess) e = hipMemset(d.homeB, 0xFF, N * sizeof(uint32_t)); if (e != hipSuccess) ok = fail(c, "hipMemset", e); }
+  }
+  if (ok && c->sectors) {
+    float4* nr = nullptr;
+    ok = dalloc(c, nr, 2);
+    if (ok) {
+      const uint32_t inf = 0x7F800000u, ninf = 0xFF800000u;
+      const uint32_t words[8] = { inf, inf, inf, 0u, ninf, ninf, ninf, 0x00FFFFFFu };      // nullRecord() in sc_tick_kernels.hip
+      ok = h2d(c, nr, words, sizeof words) && sync(c);
+      d.nullRec = nr;
+    }
   }
   if (c->variant & 32u) c->lazyEnabled = false;         // SC_TICK_VARIANT bit 5: every remembered slot is written on every tick (A/B)
   if (c->variant & 2u) c->homeEnabled = false;          // SC_TICK_VARIANT bit 1: every record reserves its slot on every tick (A/B)
+  if (const char* fp = std::getenv("SC_TICK_FAST_PAIRS")) c->fastPairs = std::atoi(fp) != 0;      // 0: every bin goes through the general pair search (A/B)
   if (const char* hp = std::getenv("SC_TICK_HOME_PERIOD")) { const int v = std::atoi(hp); if (v > 0) c->homePeriod = (uint32_t)v; }
   if (ok && c->sectors) { e = hipMemset(d.ovfLo, 0xFF, (size_t)c->sectors * sizeof(uint32_t)); if (e != hipSuccess) ok = fail(c, "hipMemset", e); }
   if (ok) { void* p = nullptr; e = hipMalloc(&p, N * sizeof(ScTickDrawItem)); if (e != hipSuccess) ok = fail(c, "hipMalloc draws", e); else { c->allocs.push_back(p); c->dDraws = p; } }
@@ -1239,7 +1255,9 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   if ((flags & SC_TICK_BROADPHASE) && c->homeEnabled) {
     // home slots: a learn tick when nothing is remembered, the world's shape changed (entities, hierarchy, layers) or the
     // slots have aged; every bin copy must be idle and empty for it (a rare event: the streams are joined here)
-    if (!c->homeValid || c->homeEpoch != c->topoEpoch || c->homeAge >= c->homePeriod) {
+    const uint32_t xf = (c->levelOffsets.size() > 1) ? (flags & SC_TICK_XFORM) : 0u;       // (only worlds with deep levels care)
+    if (!c->homeValid || c->homeEpoch != c->topoEpoch || c->homeAge >= c->homePeriod || c->homeXform != xf) {
+      c->homeXform = xf;
       if (c->pairsStream && !sync(c)) return 0;
       if (c->homeCountsLive) {
         for (uint32_t q = 0; q < (c->pairsStream ? c->pipeDepth : 1u); ++q) {
@@ -1252,11 +1270,16 @@ int scTickRun(ScTickContext* c, uint32_t flags)
       c->homeValid = true; c->homeEpoch = c->topoEpoch; c->homeAge = 0; c->lastTickLearn = true; c->learnTicks++;
     } else { p.homeMode = kHomeUse; c->homeAge++; }
     p.homeReset = 1u;
+    p.fastPairs = c->fastPairs ? 1u : 0u;
     // lazy records: only while nothing but this tick's own pair search reads the bins, and that search runs before the next
     // tick rewrites the world matrices (it rebuilds unwritten records from them)
     // (a pipelined pair half cannot rebuild -- the matrices are the next tick's by then -- so there only the bins that nothing in the
     //  world's declared layer vocabulary can meet stay unwritten: they are never needed)
-    p.lazy = (p.homeMode == kHomeUse && c->lazyEnabled && !(flags & SC_TICK_RAYS) && !c->sensors) ? (!c->pairsStream ? 1u : (c->worldLayersKnown ? 2u : 0u)) : 0u;
+    // (and only while the pair half is this library's to issue: with a caller-owned exchange -- scTickRun(.. | SPLIT_PAIRS), the host's
+    //  transport, scTickRunPairs -- the host may upload matrices, bounds or layers, append or remove entities, or run a transform-only
+    //  tick between the halves, and a rebuild would then read the world of a later moment than tick t's: every record is written)
+    const bool hostBetweenHalves = (flags & SC_TICK_SPLIT_PAIRS) && !c->pairsStream && !c->ownStep;
+    p.lazy = (p.homeMode == kHomeUse && c->lazyEnabled && !(flags & SC_TICK_RAYS) && !c->sensors && !hostBetweenHalves) ? (!c->pairsStream ? 1u : (c->worldLayersKnown ? 2u : 0u)) : 0u;
     p.vocab = c->worldLayers;
     c->lastTickLazy = p.lazy != 0u;
     // records of entities that did not move stay as they are, unless something else changed boxes since the last tick
@@ -1376,6 +1399,8 @@ int scTickSetTile(ScTickContext* c, uint32_t rank, uint32_t neighbourMask)
 {
   if (!c) return 0;
   if (rank > 127u) return fail(c, "rank must be < 128 (7 id bits)");
+  // records in remembered slots carry the rank in their ids, and which slots are written on every tick depends on the ring's ownership
+  if (c->rank != rank || c->neighbourMask != (neighbourMask & 0xFFu)) { c->homeValid = false; c->topoEpoch++; }
   c->rank = rank;
   c->neighbourMask = neighbourMask & 0xFFu;
   return 1;
@@ -1392,6 +1417,7 @@ int scTickSetTileGrid(ScTickContext* c, uint32_t tileX, uint32_t tileZ, uint32_t
     const int x = (int)tileX + dx, z = (int)tileZ + dz;
     if (x >= 0 && z >= 0 && x < (int)tilesX && z < (int)tilesZ) mask |= 1u << d;
   }
+  if (c->neighbourMask != mask) { c->homeValid = false; c->topoEpoch++; }
   c->neighbourMask = mask;
   return 1;
 }
@@ -2386,6 +2412,7 @@ int scTickExchangeBorders(ScTickContext* c)
 int scTickTileStep(ScTickContext* c, uint32_t flags)
 {
   if (!c) return 0;
+  struct Own { ScTickContext* c; explicit Own(ScTickContext* c_) : c(c_) { c->ownStep = true; } ~Own() { c->ownStep = false; } } own(c);
   if (!(flags & SC_TICK_BROADPHASE) || !c->neighbourMask) {                                                                // nothing to exchange
     if (!(flags & SC_TICK_BROADPHASE) || !c->pairsStream) return scTickRun(c, flags & ~(uint32_t)SC_TICK_SPLIT_PAIRS);
     if (!scTickRun(c, flags | SC_TICK_SPLIT_PAIRS)) return 0;                 // a lone pipelined tile: the pair half still runs on its own stream

@@ -105,11 +105,18 @@ struct DeviceState {
   uint32_t* homeB;             // [cap] four 8-bit slots: the copies in sectors homeA + {0, 1, binSX, binSX + 1}; 0xFF = no reservation
   uint32_t* homeCount;         // [sectors] slots of each bin that are reserved: what binCount starts a tick from
   uint32_t* homeLayers;        // [sectors] OR of the reserved records' layer words: what binLayers starts a tick from
+  // Ordered home slots (round 4): at the learn tick the reserved records of every bin are re-numbered -- and moved -- so that the
+  // records that pass the group/mask filter against their own kind ("cast" records: dynamic bodies) come first.  A bin that holds
+  // nothing but its reserved records on a later tick is then searched without classifying anything: the cast records are slots
+  // [0, D), everything else behind them (k_order_home, "fast sectors" in the pair role).
+  uint32_t* homeCast;          // [sectors] bits 0..7: D, cast records among the reserved slots; kCastFast: the rest cannot meet each other
+  const float4* nullRec;       // one null record (nullRecord(): inverted box, layers 0) for lanes that have no bin slot to load
+  uint8_t* homePerm;           // [sectors][kBinCap] learn tick only: slot a reserved record moved to (k_home_flags re-numbers homeB through it)
   // Lazy records (round 3): a bin whose reserved records cannot pass the group/mask filter against each other is read by the
   // pair search only when a record from elsewhere arrives that can -- so its owners do not write it (homeB bit 6 of a slot
   // byte = "write every tick"), and the wave that does need such a bin rebuilds its records from the owners' matrices.
   uint32_t* lazyCtl;           // [0] big boxes of the last pair search (!= 0: the next fused kernel writes every record),
-                               // [1] 1 = the last fused kernel wrote every reserved record (what its pair search goes by)
+                               // [1 + parity] 1 = that tick's fused kernel wrote every reserved record (what its pair search goes by)
   float4* bigList;             // [cap][2] boxes that cannot be binned (too large, outside the rect, bin full)
   float4* spill;               // [ovfCap][2] sector OVERFLOW list: records that found their sector bin full -- this tile's own
                                // (fused kernel) and the neighbours' border records (merge) alike ...
@@ -151,7 +158,7 @@ constexpr float kBigReach = 2.0f;             // sectors around a tile's owned r
 constexpr uint32_t kBinCap = 64;          // one wave lane per record of a bin
 // Pair output is sharded: a wave buffers its hits in LDS and appends them to the segment of its workgroup's
 // shard with one atomic per flush; 64 counters on separate cache lines instead of one hot word.
-constexpr uint32_t kPairShards = 64, kShardStride = 32, kWavePairBuf = 256;
+constexpr uint32_t kPairShards = 64, kShardStride = 32, kWavePairBuf = 192;
 constexpr uint32_t kPrimary = 0x80000000u;
 // counters[]: 0 visible, 1 culled, 4 draws, 5 dropped, 6 renderables; per tick parity q: 8+8q+{0 pairs, 1 big, 2 bin-full}
 constexpr uint32_t kCtrPar = 8, kCtrPairs = 0, kCtrBig = 1, kCtrBinFull = 2, kCtrBorderLost = 3, kCtrBigLocal = 4, kCtrSpill = 5;
@@ -159,6 +166,7 @@ constexpr uint32_t kCtrCrowdTail = 6, kCtrCrowdHead = 7;     // crowded sectors 
 constexpr uint32_t kHomeOff = 0, kHomeLearn = 1, kHomeUse = 2;
 constexpr uint32_t kNoHome = 0xFFFFFFFFu, kNoSlot = 0xFFu;
 constexpr uint32_t kHomeHot = 0x80000000u;                         // homeCount: the bin was rebuilt since the learn tick, its owners write it again
+constexpr uint32_t kCastFast = 0x100u;                            // homeCast: no two of the bin's reserved non-cast records pass the filter against each other
 constexpr uint32_t kSlotMask = 0x3Fu, kSlotAlways = 0x40u;     // a homeB slot byte: slot in the bin, "written on every tick" (lazy records)
 // Tick "parity": which copy of the per-tick broadphase state a tick works on.  The in-order flows alternate between two
 // copies; pipelined tiles rotate through `depth` (2..kMaxParity) copies, so that the pair half of tick t may still run while
@@ -208,6 +216,7 @@ struct TickParams {
                             // can meet nothing in the world's declared vocabulary, never needed (pipelined tiles, scTickSetWorldLayers);
                             // 0 when something else reads the bins (ray queries, traffic sensors) or neither applies
   uint32_t vocab;           // lazy 2: group bits | mask bits << 16 of every collider that can exist in the tiled world
+  uint32_t fastPairs;       // the pair role takes bins that hold nothing but their ordered reserved records through the fast path (homeCast)
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d
 __host__ __device__ inline void borderDir(uint32_t d, int& dx, int& dz) { const uint32_t k = d < 4 ? d : d + 1; dx = (int)(k % 3) - 1; dz = (int)(k / 3) - 1; }

@@ -537,7 +537,7 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
 
   uint32_t visCount = 0, candCount = 0;      // wave-uniform running sums
   // lazy records (binWrittenEveryTick): off while big boxes are about -- they are tested against every bin; the tick's pair
-  // search learns from lazyCtl[1] what this kernel did
+  // search learns from lazyCtl[1 + parity] what this kernel did
   bool lazyOn = false;
   if (kAabb) {
     // (p.lazy 2: the unwritten bins are those nothing in the world can meet -- big boxes included, so no guard)
@@ -635,7 +635,7 @@ __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickPa
     }
   }
 
-  if (kAabb && blockIdx.x == 0 && threadIdx.x == 0) d.lazyCtl[1] = lazyOn ? 0u : 1u;
+  if (kAabb && blockIdx.x == 0 && threadIdx.x == 0) d.lazyCtl[1u + p.parity] = lazyOn ? 0u : 1u;      // (per tick parity: a pipelined tile's pair half of tick t runs under the fused kernel of tick t + 1)
   if (kCull) {
     __shared__ uint32_t sVis[kTile / 64], sCand[kTile / 64];
     if (lane == 0) { sVis[wave] = visCount; sCand[wave] = candCount; }
@@ -1201,9 +1201,15 @@ __device__ __forceinline__ bool ownsSector(const TickParams& p, float gx, float 
 constexpr uint32_t kPairTabSize = kBinCap * (kBinCap - 1) / 2;
 constexpr uint32_t kFineThreshold = 24;      // bins with more records than this use the 4x4 cell grid
 constexpr uint32_t kCellWords = 16u * (1u + kOvfPerSector / 64u);     // 4x4 cell masks for the bin tile and every overflow tile of a sector
-constexpr uint32_t kCastDirect = 2;          // this few cast records are broadcast one after the other (no re-ordering of the bin)
+
 // crowded sectors (more records than the bin holds) wait in a queue of the whole launch; a full queue leaves a sector to the wave that met it
-constexpr uint32_t kCastMax = 20;            // up to this many self-compatible (dynamic) records per bin are broadcast one by one
+
+constexpr uint32_t kTileSlots = kBinCap + 1u; // a wave's LDS tile: the bin's 64 records + one slot that always holds a null record (fast sectors)
+constexpr uint32_t kCandCap = 512;           // fast sectors: (slot, slot) candidates a wave collects before it resolves them (a multiple of 64)
+#ifndef SC_BROADCAST_MAX
+#define SC_BROADCAST_MAX 4
+#endif
+constexpr uint32_t kBroadcastMax = SC_BROADCAST_MAX;   // fast sectors: up to this many sweepers are broadcast from registers, nothing staged in LDS
 
 // pair predicate shared by both search paths: group/mask filter, closed-interval overlap, and "this sector
 // holds the low corner of the intersection" (so the pair is reported from exactly one bin)
@@ -1259,7 +1265,7 @@ __device__ __forceinline__ void rebuildHomeRecord(const DeviceState& d, const Ti
 //  kernel's: with its branches merely present the in-order end-of-tick kernel ran 0.6 us (config 3) to 2.4 us (config 5) longer)
 template <bool kVocab>
 __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams& p, uint32_t bid, uint32_t nblocks,
-                                          float4 (*tile)[2 * kBinCap], uint16_t* pairTab, uint2 (*pairBuf)[kWavePairBuf],
+                                          float4 (*tile)[2 * kTileSlots], uint16_t* pairTab, uint2 (*pairBuf)[kWavePairBuf],
                                           unsigned long long (*cellMembers)[kCellWords])
 {
   const uint32_t lane = threadIdx.x & 63u;
@@ -1275,7 +1281,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   // (p.lazy: 0 = the fused kernel wrote everything; 1 = it says what it did -- big boxes make it write everything; 2 = it left
   //  unwritten what nothing in the world can meet, see k_home_flags)
   //  (the flag is read unconditionally, up front with the other scalars: behind a test of p.lazy it cost every workgroup a stall)
-  const bool freshAll = kVocab ? false : (!p.homeReset || d.lazyCtl[1] != 0u);
+  const bool freshAll = kVocab ? false : (!p.homeReset || d.lazyCtl[1u + p.parity] != 0u);
   constexpr bool vocabMode = kVocab;                   // (the launcher picks the instance by p.lazy)
   if (bid == 0u && threadIdx.x == 0u) d.lazyCtl[0] = nbig;             // (what the next fused kernel goes by)
   float4* T = tile[wave];
@@ -1287,13 +1293,13 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
 
   // broadcast path: with D records to cast, lane l plays (record l / G, partner phase l % G), G = 64 / D; the division by
   // the wave-uniform G is a multiplication by ceil(2^16 / G) (exact for l < 64)
-  __shared__ uint32_t castTab[kCastMax + 1u];
+  __shared__ uint32_t castTab[kBinCap + 1u];
   // crowded sectors (more records than the bin holds) are not searched by the wave that meets them: they go to a queue of
   // the whole launch, and every workgroup, done with its sweep, takes sectors from it, four waves to a sector (see
   // "crowded sectors" below)
   __shared__ uint32_t crowdGathered, crowdItem, crowdLayers;
   if (threadIdx.x == 0) { crowdGathered = 0u; crowdLayers = 0u; }
-  if (threadIdx.x >= 1u && threadIdx.x <= kCastMax) { const uint32_t G = 64u / threadIdx.x; castTab[threadIdx.x] = G | ((65536u / G + 1u) << 8); }
+  if (threadIdx.x >= 1u && threadIdx.x <= kBinCap) { const uint32_t G = 64u / threadIdx.x; castTab[threadIdx.x] = G | ((65536u / G + 1u) << 8); }
 
   // next tick's counter set starts clean (pipelined tiles do this in the end-of-tick kernel on the tick stream instead:
   // there the next tick's fused kernel may already be filling it while this pair search runs)
@@ -1310,7 +1316,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   const uint32_t runLog = p.pairRunLog2, runLen = 1u << runLog, runsPerRound = 64u >> runLog;
   for (uint32_t round = 0; ((round * runsPerRound) * totalWaves + waveGlobal) << runLog < sectors; ++round) {
     const uint32_t mySector = (((round * runsPerRound + (lane >> runLog)) * totalWaves + waveGlobal) << runLog) + ((lane + waveGlobal) & (runLen - 1u));
-    uint32_t myCount = 0, myLay = 0, myHome = 0;
+    uint32_t myCount = 0, myLay = 0, myHome = 0, myCast = 0;
     bool myStale = false;
     const uint32_t myGx = mySector % p.binSX, myGz = mySector / p.binSX;     // once per 64 sectors, not once per sector
     if (mySector < sectors) {
@@ -1322,6 +1328,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       uint32_t hc = 0u, hl = 0u;
       bool hot = false;
       if (p.homeReset) { hc = d.homeCount[mySector]; hl = d.homeLayers[mySector]; hot = (hc & kHomeHot) != 0u; hc &= ~kHomeHot; }
+      if (p.fastPairs) myCast = d.homeCast[mySector];
       if (myCount != hc || lay != hl) { d.binCount[mySector] = hc; d.binLayers[mySector] = hl; }
       myHome = hc;
       const uint32_t hlTest = vocabMode ? layersThatCanMeet(hl, p.vocab) : hl;
@@ -1336,8 +1343,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     }
     const bool myOver = myCount > kBinCap;             // the sector holds more records than its bin: the rest is in the overflow list
     if (myOver) myCount = kBinCap;
-    const unsigned long long work = ballot64(myCount != 0u);
-    if (!work) continue;
+    if (!ballot64(myCount != 0u)) continue;
 
     // a ring sector on a side where a neighbour tile exists belongs to that neighbour: it reports the pairs whose low
     // corner lies there (it received these boxes through the border exchange).  Decided here, once per 64 sectors.
@@ -1347,6 +1353,177 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       if ((dx != 0 && hasNb(p, dx, 0)) || (dz != 0 && hasNb(p, 0, dz))) mine = false;    // nearest tile is not this one
     }
     const unsigned long long oursMask = ballot64(mine);
+    const uint32_t myGxz = myGx | (myGz << 16);
+
+    // ---- fast sectors (round 4).  The reserved records of a bin were put in order at the learn tick (k_order_home): the cast records --
+    // those that pass the filter against their own kind, the dynamic bodies -- are slots [0, D), the rest [D, hc), and no two of the
+    // rest can meet (kCastFast).  Whatever lies behind them, slots [hc, n), are VISITORS: boxes that entered the sector since the learn
+    // tick, border records, the level kernels' entities -- unclassified, and few.  So nothing is classified here: the visitors simply
+    // join the sweeping set -- in LDS the order becomes cast records, visitors, rest -- and every pair with at least one sweeper in it
+    // is tested exactly once, the filter deciding at the end as it always does.  The records go to LDS as they lie (a lane past the
+    // count loads and stages a null record, slot 64 always holds one), lane (c, g) tests sweeper c against the slots S + g, S + g + G,
+    // ... (S sweepers, G = 64 / S), the sweepers meet each other through the triangular table (its first S (S - 1) / 2 entries are
+    // exactly the pairs among slots [0, S)), and a round is ONE 16-byte LDS read and four compares on the xz rectangles, AND-ed as
+    // wave masks.  A touching pair is not followed up in the round -- one lane's hit used to make the whole wave walk the filter, the
+    // low-corner rule and the sink, ~60 instructions, two or three times per sector -- its two slot numbers go to a short list in LDS
+    // and the list is resolved behind the rounds, 64 candidates at a time with every lane busy: the full box test (y included),
+    // filter, ids, low corner (pairHit).  Same predicate, same pair set.
+    const bool myFast = myCount != 0u && mine && (myCast & kCastFast) != 0u && !myOver && !myStale;
+    const unsigned long long fastMask = ballot64(myFast);
+    if (fastMask) {
+      uint16_t* cand = reinterpret_cast<uint16_t*>(cellMembers[wave]);      // (the wave's cell masks: only the general paths use them)
+      // slot 64 of the tile in the fast sectors' layout holds a null record (the general paths use T[0 .. 127] their own way).
+      // Null records are READ, from d.nullRec, not built: eight constants in vector registers across these loops were what
+      // pushed the kernel into scratch -- a lane past a bin's count simply loads the null record instead of a bin slot.
+      if (lane == 0u) {
+        const float4 zl = d.nullRec[0], zh = d.nullRec[1];
+        T[kBinCap] = make_float4(zl.x, zl.z, zh.x, zh.z); T[kTileSlots + kBinCap] = make_float4(zl.y, zh.y, zl.w, zh.w);
+      }
+      unsigned long long restF = fastMask;
+      // One sector's records are in flight while the one before it is swept: `lo` / `hi` hold lane i's bin slot i of the sector
+      // `info` describes (wave-uniform, in scalar registers: n | hc << 8 | D << 16, 0 = no sector left; its grid coordinates).
+      // (Deeper prefetch -- three register sets, loads and waits written by hand because hipcc waits with vmcnt(0) -- was built and
+      //  measured: no gain, the role is held by instruction issue, not by the records' latency; profiles/r04/ab_fast_sectors.log.)
+      float4 lo, hi; uint32_t info, gxzF;
+      auto fetch = [&]() __attribute__((always_inline)) {
+        const bool more = restF != 0ull;
+        const int itF = more ? __ffsll((long long)restF) - 1 : 0;
+        restF &= restF - 1ull;
+        const uint32_t nF = more ? __builtin_amdgcn_readlane(myCount, itF) : 0u, sF = __builtin_amdgcn_readlane(mySector, itF);
+        info = more ? (nF | (__builtin_amdgcn_readlane(myHome, itF) << 8) | ((__builtin_amdgcn_readlane(myCast, itF) & 0xFFu) << 16)) : 0u;
+        gxzF = __builtin_amdgcn_readlane(myGxz, itF);
+        const float4* r = lane < nF ? d.bins + 2u * ((size_t)sF * kBinCap + lane) : d.nullRec;
+        lo = r[0]; hi = r[1];
+      };
+      fetch();
+      while (info) {
+        {
+          const uint32_t n = info & 0xFFu, hc = (info >> 8) & 0xFFu, D = info >> 16, gxz = gxzF;
+          const uint32_t V = n - hc, S = D + V;                      // visitors; sweepers
+          const float secX = (float)(gxz & 0xFFFFu), secZ = (float)(gxz >> 16);
+          // (opaque here: the re-arrangement for the tile must not be moved up to the loads -- hipcc did, and waited for every load
+          //  right behind its issue to shuffle the components, which left nothing in flight under the sweeps)
+          asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(lo.w), "+v"(hi.x), "+v"(hi.y), "+v"(hi.z), "+v"(hi.w));
+          const bool broadcast = S <= kBroadcastMax;
+          const float4 clo = lo, chi = hi;                           // this sector's records; `lo` / `hi` go to the next fetch
+          if (!broadcast) {
+            // the tile in the sweeps' own layout: slot k = (min.x, min.z, max.x, max.z) at T[k], (min.y, max.y, layers, id) at T[65 + k]: a round
+            // reads ONE 16-byte word per lane and tests the xz rectangles (four compares); the y interval waits for the resolve -- boxes
+            // of a city stand on the ground, their y intervals nearly always overlap
+            const uint32_t at = lane + (lane < D ? 0u : (lane < hc ? V : (lane < n ? D - hc : 0u)));      // cast records, visitors, rest
+            T[at] = make_float4(clo.x, clo.z, chi.x, chi.z);
+            T[kTileSlots + at] = make_float4(clo.y, chi.y, clo.w, chi.w);
+          }
+          fetch();                                                   // (the next sector's records are under way during the tests below)
+#ifdef SC_DIAG_NOSWEEP
+          if (false)                                                 // diagnostic build: what fetching and staging the fast sectors' records alone costs
+#endif
+          if (broadcast) {
+            // A handful of sweepers (a lone vehicle among props; one visitor): nothing is staged at all.  Every lane keeps its bin slot's
+            // record in registers, each sweeper's xz rectangle is read into scalar registers (v_readlane) and tested by all lanes at
+            // once -- four compares with a scalar operand, AND-ed as wave masks with the lanes the sweeper has to meet: a cast record
+            // the slots behind it, a visitor the rest and the visitors behind it.  A touch (rare) is followed up on the spot, from registers.
+            for (uint32_t k = 0; k < S; ++k) {
+              const uint32_t sl = k < D ? k : hc + (k - D);
+              unsigned long long meet = ~((2ull << sl) - 1ull);
+              if (k >= D) meet |= ((1ull << hc) - 1ull) & ~((1ull << D) - 1ull);
+              const float x0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(clo.x), sl)), z0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(clo.z), sl));
+              const float x1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(chi.x), sl)), z1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(chi.z), sl));
+              const unsigned long long m = ballot64(x0 <= chi.x) & ballot64(clo.x <= x1) & ballot64(z0 <= chi.z) & ballot64(clo.z <= z1) & meet;
+              if (!m) continue;
+              const float4 smin = make_float4(x0, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(clo.y), sl)), z0, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(clo.w), sl)));
+              const float4 smax = make_float4(x1, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(chi.y), sl)), z1, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(chi.w), sl)));
+              uint32_t ia = 0, ib = 0;
+              const bool hit = ((m >> lane) & 1ull) && pairHit(p, clo, chi, smin, smax, secX, secZ, ia, ib);
+              sinkPush(d, p, sink, hit, ia, ib);
+            }
+            if (nbig) {
+              const bool prim = lane < n && (__float_as_uint(chi.w) & kPrimary);
+              const uint32_t myId = __float_as_uint(chi.w) & ~kPrimary;
+              for (uint32_t b = 0; b < nbig; ++b) {
+                const float4 gmin = d.bigList[2u * (size_t)b], gmax = d.bigList[2u * (size_t)b + 1u];
+                const bool hit = prim && boxesOverlap(clo, chi, gmin, gmax) && filterPass(__float_as_uint(clo.w), __float_as_uint(gmin.w));
+                sinkPush(d, p, sink, hit, myId, __float_as_uint(gmax.w));
+              }
+            }
+          }
+#ifdef SC_DIAG_NOSWEEP
+          if (false)
+#endif
+          if (!broadcast) {
+            const uint32_t gi = __builtin_amdgcn_readfirstlane(castTab[S]), G = gi & 0xFFu;
+            const uint32_t c = (lane * (gi >> 8)) >> 16;
+            const uint32_t cIdx = c < S ? c : kBinCap;               // (idle lanes hold the null record: they touch nothing)
+            __builtin_amdgcn_wave_barrier();
+            const float4 cxz = T[cIdx];
+            // rounds: RA of sweepers against the slots behind them (G slots per sweeper and round), RB of sweepers against each
+            // other (64 table entries per round); taken in windows of as many rounds as the candidate list can hold at worst
+            // (every lane touching in every round) -- one window for a bin of the usual size, and no test of the list's fill
+            // inside the loops
+            const uint32_t npairs = S * (S - 1u) / 2u;
+            const uint32_t RA = ((n - S + G - 1u) * (gi >> 8)) >> 16, RB = (npairs + 63u) >> 6;
+            constexpr uint32_t W = kCandCap / 64u;
+            uint32_t j = S + (lane - c * G);
+            for (uint32_t base = 0; base < RA + RB; base += W) {
+              uint32_t cnt = 0;
+              const uint32_t top = base + W < RA + RB ? base + W : RA + RB;
+              for (uint32_t r = base; r < (top < RA ? top : RA); ++r, j += G) {
+                const uint32_t jj = j < kBinCap ? j : kBinCap;
+                const float4 txz = T[jj];
+                const unsigned long long m = ballot64(cxz.x <= txz.z) & ballot64(txz.x <= cxz.z) & ballot64(cxz.y <= txz.w) & ballot64(txz.y <= cxz.w);
+                if (!m) continue;
+                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, cnt));
+                if ((m >> lane) & 1ull) cand[pos] = (uint16_t)(cIdx | (jj << 8));
+                cnt += (uint32_t)__popcll(m);
+              }
+              for (uint32_t r = (base > RA ? base : RA); r < top; ++r) {
+                const uint32_t q = ((r - RA) << 6) + lane;
+                const uint32_t ij = pairTab[q < npairs ? q : 0u];
+                const uint32_t a = ij >> 8, b = ij & 255u;
+                const float4 axz = T[a], bxz = T[b];
+                const unsigned long long m = ballot64(q < npairs) & ballot64(axz.x <= bxz.z) & ballot64(bxz.x <= axz.z) & ballot64(axz.y <= bxz.w) & ballot64(bxz.y <= axz.w);
+                if (!m) continue;
+                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, cnt));
+                if ((m >> lane) & 1ull) cand[pos] = (uint16_t)(a | (b << 8));
+                cnt += (uint32_t)__popcll(m);
+              }
+              // the touching pairs of the window: the full box test, filter, ids, low corner of the intersection in this sector -- every lane busy
+              __builtin_amdgcn_wave_barrier();
+#ifdef SC_DIAG_NORESOLVE
+              cnt = 0;                                            // diagnostic build: what the sweeps alone cost (no pairs reported)
+#endif
+              for (uint32_t q0 = 0; q0 < cnt; q0 += 64u) {
+                const uint32_t q = q0 + lane;
+                const uint32_t e = q < cnt ? cand[q] : 0u;
+                const uint32_t a = e & 255u, b = e >> 8;
+                const float4 axz = T[a], ay = T[kTileSlots + a], bxz = T[b], by = T[kTileSlots + b];
+                uint32_t ia = 0, ib = 0;
+                const bool hit = q < cnt && pairHit(p, make_float4(axz.x, ay.x, axz.y, ay.z), make_float4(axz.z, ay.y, axz.w, ay.w),
+                                                    make_float4(bxz.x, by.x, bxz.y, by.z), make_float4(bxz.z, by.y, bxz.w, by.w), secX, secZ, ia, ib);
+                sinkPush(d, p, sink, hit, ia, ib);
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+          // big boxes against this bin's primary records (each binned box has exactly one primary copy), as in the general path
+          if (nbig && !broadcast) {
+            const uint32_t at = lane + (lane < D ? 0u : (lane < hc ? V : (lane < n ? D - hc : 0u)));
+            const float4 oxz = T[at], oy = T[kTileSlots + at];
+            const bool prim = lane < n && (__float_as_uint(oy.w) & kPrimary);
+            const uint32_t myId = __float_as_uint(oy.w) & ~kPrimary;
+            for (uint32_t b = 0; b < nbig; ++b) {
+              const float4 gmin = d.bigList[2u * (size_t)b], gmax = d.bigList[2u * (size_t)b + 1u];
+              const bool hit = prim && oxz.x <= gmax.x && gmin.x <= oxz.z && oy.x <= gmax.y && gmin.y <= oy.y && oxz.y <= gmax.z && gmin.z <= oxz.w &&
+                               filterPass(__float_as_uint(oy.z), __float_as_uint(gmin.w));
+              sinkPush(d, p, sink, hit, myId, __float_as_uint(gmax.w));
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+    const unsigned long long work = ballot64(myCount != 0u && !myFast);
+    if (!work) continue;
     // lazy records: bins of unwritten records that have to be read after all (a record from elsewhere made them admissible; a
     // big box is about) are rebuilt in place first -- rare, and outside the loop below
     const unsigned long long staleMask = ballot64(myStale && myCount != 0u);
@@ -1370,7 +1547,6 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     // cross-lane reads.  (ds_bpermute although the picked lane is wave-uniform: v_readlane measured slower, 27.1 against
     // 26.3 us on config3dyn -- a VALU slot each plus SGPR-hazard waits; and recomputing the index from the lane number
     // made the compiler re-load a kernel argument inside this loop: the scalar registers are all taken.)
-    const uint32_t myGxz = myGx | (myGz << 16);
     // software pipeline: records of the next non-empty sector are in flight while this one is tested
     int it = __ffsll((long long)work) - 1;
     uint32_t n = __shfl(myCount, it, 64), gxz = __shfl(myGxz, it, 64), binLay = __shfl(myLay, it, 64);
@@ -1411,81 +1587,11 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       const unsigned long long validMask = ballot64(admissible);
       const bool anyPairs = __popcll(validMask) >= 2;
       const float secX = (float)gx, secZ = (float)gz;
-      // Who can collide at all?  Under Bullet's filter most boxes of a city are static bodies (group 2 / mask 1), which never
-      // pass against each other; the pairs worth testing are (record that passes against its own kind) x (any admissible
-      // record).  So the records that pass against their own layer word -- dynamic bodies -- are broadcast one after the
-      // other from LDS and every lane tests its own record against the broadcast one: D iterations for D dynamic records,
-      // all lanes busy, conflict-free LDS reads, instead of n(n-1)/2 table-driven pairs of which static-static ones only
-      // fail the filter.  It covers every pair unless two records that do NOT pass against their own kind pass against each
-      // other (say 4/8 against 8/4): the OR of those records' layer words tells; then the general paths below run.
-      const bool selfOk = admissible && filterPass(lay, lay);
-      const unsigned long long castMask = ballot64(selfOk);
-      // the other admissible records: when they all carry ONE layer word (the usual case: static props) they cannot pass
-      // against each other -- that word does not pass against itself; only a mix pays for the OR over the lanes
-      const unsigned long long others = ballot64(admissible && !selfOk);
-      bool crossPossible = false;
-      if (others) {
-        const uint32_t first = (uint32_t)__shfl((int)lay, __ffsll((long long)others) - 1, 64);
-        if (ballot64(admissible && !selfOk && lay != first)) {
-          uint32_t rest2 = (admissible && !selfOk) ? lay : 0u;
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) rest2 |= (uint32_t)__shfl_xor((int)rest2, o, 64);
-          crossPossible = ((rest2 & 0xFFFFu) & (rest2 >> 16)) != 0u;
-        }
-      }
-      const bool castPath = (uint32_t)__popcll(castMask) <= kCastMax && !crossPossible;
-      if (anyPairs && castPath) {
-        // The records that can collide at all go to LDS, cast records first: slot = rank among the cast records, or D + rank
-        // among the other admissible ones.  Lane (c, g) then tests cast record c against the slots g, g + G, g + 2G, ...
-        // that are either an earlier cast record (two cast records meet once) or not a cast record: n D / 64 rounds with
-        // all lanes busy, where broadcasting the D records one after the other took D rounds with n lanes busy.
-        const uint32_t D = (uint32_t)__popcll(castMask), nAdm = (uint32_t)__popcll(validMask);
-        if (D && D <= kCastDirect) {
-          // one or two cast records (a lone vehicle among props): staged as they lie, the cast record is broadcast from LDS
-          // and every lane tests the record it already holds in registers
-          T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
-          __builtin_amdgcn_wave_barrier();
-          unsigned long long cm = castMask;
-          while (cm) {
-            const uint32_t c = (uint32_t)__ffsll((long long)cm) - 1u;
-            cm &= cm - 1ull;
-            const float4 tmin = T[2u * c], tmax = T[2u * c + 1u];
-            const bool cand = admissible && (!selfOk || lane < c);      // two cast records meet once
-            if (!ballot64(cand && boxesOverlap(rmin, rmax, tmin, tmax))) continue;
-            uint32_t ia = 0, ib = 0;
-            const bool hit = cand && pairHit(p, rmin, rmax, tmin, tmax, secX, secZ, ia, ib);
-            sinkPush(d, p, sink, hit, ia, ib);
-          }
-        } else if (D) {
-          const unsigned long long below = (1ull << lane) - 1ull;
-          const uint32_t slot = selfOk ? (uint32_t)__popcll(castMask & below) : D + (uint32_t)__popcll(validMask & ~castMask & below);
-          if (admissible) { T[2u * slot] = rmin; T[2u * slot + 1u] = rmax; }
-          const uint32_t gi = castTab[D], G = gi & 0xFFu;
-          const uint32_t c = (lane * (gi >> 8)) >> 16;
-          // lane (c, g) may meet slot j iff j < nLane and j is outside [c, D): one unsigned compare each
-          const uint32_t nLane = c < D ? nAdm : 0u, span = D - c;
-          uint32_t j = lane - c * G;
-          __builtin_amdgcn_wave_barrier();
-          const float4 cmin = T[2u * (c & 63u)], cmax = T[2u * (c & 63u) + 1u];       // (idle lanes read some record; nLane = 0 keeps them out)
-          const uint32_t clay = __float_as_uint(cmin.w), cid = __float_as_uint(cmax.w) & ~kPrimary;
-          for (uint32_t j0 = 0; j0 < nAdm; j0 += G, j += G) {
-            // (a slot index past the bin is held inside the wave's tile; the lane is masked out by j < nLane)
-            const uint32_t jj = j < kBinCap ? j : kBinCap - 1u;
-            const float4 tmin = T[2u * jj], tmax = T[2u * jj + 1u];
-            // mask arithmetic instead of short-circuit branches: 6 + 2 compares, and the wave skips the round on an empty mask
-            const unsigned long long m = ballot64(j < nLane) & ballot64(j - c >= span) &
-                                         ballot64(cmin.x <= tmax.x) & ballot64(tmin.x <= cmax.x) & ballot64(cmin.y <= tmax.y) &
-                                         ballot64(tmin.y <= cmax.y) & ballot64(cmin.z <= tmax.z) & ballot64(tmin.z <= cmax.z);
-            if (!m) continue;
-            const bool touch = (m >> lane) & 1ull;
-            const uint32_t tid = __float_as_uint(tmax.w) & ~kPrimary;
-            const float lx = cmin.x > tmin.x ? cmin.x : tmin.x, lz = cmin.z > tmin.z ? cmin.z : tmin.z;        // as pairHit
-            const bool hit = touch && filterPass(clay, __float_as_uint(tmin.w)) && cid != tid &&
-                             (floorf(lx * p.invSector) - p.binOx) == secX && (floorf(lz * p.invSector) - p.binOz) == secZ;
-            sinkPush(d, p, sink, hit, cid, tid);
-          }
-        }
-      } else if (anyPairs) {
+      // (Round 2's broadcast paths over the records that can collide at all -- dynamic bodies against the rest, lane = (cast record,
+      //  partner phase) -- moved to the fast sectors in round 4, where the bins arrive sorted that way and nothing is classified per
+      //  tick.  What still comes here -- bins whose reserved records can meet across kinds (say 4/8 against 8/4), unwritten bins that
+      //  had to be rebuilt, worlds without remembered slots -- takes the general forms: the triangular table or the 4x4 cell grid.)
+      if (anyPairs) {
         T[2u * lane] = rmin; T[2u * lane + 1u] = rmax;
         __builtin_amdgcn_wave_barrier();
         if (n <= kFineThreshold) {
@@ -1743,7 +1849,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
 template <bool kVocab>
 __global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_pairs(const DeviceState d, const TickParams p)
 {
-  __shared__ float4 tile[kTile / 64][2 * kBinCap];        // 2 KiB per wave: the bin as an LDS tile
+  __shared__ float4 tile[kTile / 64][2 * kTileSlots];     // 2 KiB per wave: the bin as an LDS tile (+ a null record)
   __shared__ uint16_t pairTab[kPairTabSize];              // q -> (i << 8 | j), 0 <= j < i < 64
   __shared__ uint2 pairBuf[kTile / 64][kWavePairBuf];     // 2 KiB per wave: hits waiting for a flush
   __shared__ unsigned long long cellMembers[kTile / 64][kCellWords];   // per wave: which records touch each of the 4x4 cells, per tile of 64
@@ -1774,7 +1880,7 @@ __global__ __launch_bounds__(kTile) void k_gather_pairs(const DeviceState d, con
 template <bool kEmit>
 __global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_compact_pairs(const DeviceState d, const TickParams p, uint32_t compactBlocks, uint32_t group)
 {
-  __shared__ float4 tile[kTile / 64][2 * kBinCap];
+  __shared__ float4 tile[kTile / 64][2 * kTileSlots];
   __shared__ uint16_t pairTab[kPairTabSize];
   __shared__ uint2 pairBuf[kTile / 64][kWavePairBuf];
   __shared__ unsigned long long cellMembers[kTile / 64][kCellWords];
@@ -2377,6 +2483,39 @@ __global__ __launch_bounds__(kTile) void k_snapshot_home(const DeviceState d, ui
   d.homeLayers[s] = d.binLayers[s];
 }
 
+// Ordered home slots (round 4).  The pair search spent most of its instructions per sector on finding out, on every tick, which of
+// a bin's records can collide at all -- filter masks against the bin's layer summary, ballots, ranks, a re-ordered copy in LDS -- although
+// for the records that keep their slots from one learn tick to the next the answer never changes.  So the learn tick sorts it out once:
+// one wave per bin re-numbers the reserved records so that those that pass the group/mask filter against their own kind (dynamic
+// bodies: "cast" records) hold slots [0, D) and everything else follows, MOVES the records accordingly (a record that does not change
+// is not rewritten on later ticks: TickParams::cleanStay), notes D and whether the rest can meet each other (homeCast), and leaves
+// the permutation in homePerm for k_home_flags, which re-numbers the owners' homeB bytes through it.  A bin that holds nothing but
+// its reserved records on a later tick -- count == homeCount, the usual case -- is then searched as it lies ("fast sectors" in pairsBody).
+__global__ __launch_bounds__(kTile) void k_order_home(const DeviceState d, uint32_t sectors)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t s = blockIdx.x * (kTile / 64u) + (threadIdx.x >> 6);
+  if (s >= sectors) return;
+  const uint32_t hc = min(d.homeCount[s], kBinCap);
+  float4 lo, hi; nullRecord(lo, hi);
+  float4* bin = d.bins + 2u * ((size_t)s * kBinCap);
+  if (lane < hc) { lo = bin[2u * lane]; hi = bin[2u * lane + 1u]; }
+  const uint32_t lay = lane < hc ? __float_as_uint(lo.w) : 0u;
+  const bool self = lane < hc && ((lay & 0xFFFFu) & (lay >> 16)) != 0u;       // filterPass(lay, lay)
+  const unsigned long long castMask = ballot64(self), restMask = ballot64(lane < hc && !self);
+  uint32_t rest = (lane < hc && !self) ? lay : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) rest |= (uint32_t)__shfl_xor((int)rest, o, 64);
+  const bool cross = ((rest & 0xFFFFu) & (rest >> 16)) != 0u;                // two of the other records may pass against each other
+  const uint32_t D = (uint32_t)__popcll(castMask);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const uint32_t slot = self ? (uint32_t)__popcll(castMask & below) : D + (uint32_t)__popcll(restMask & below);
+  if (lane < hc) d.homePerm[(size_t)s * kBinCap + lane] = (uint8_t)slot;
+  // (every lane's record is in registers before any lane stores: the stores wait for the loads of the whole wave)
+  if (ballot64(lane < hc && slot != lane)) { if (lane < hc) { bin[2u * slot] = lo; bin[2u * slot + 1u] = hi; } }
+  if (lane == 0) d.homeCast[s] = D | (cross ? 0u : kCastFast);
+}
+
 // ... and every remembered slot learns whether its bin is one that is written on every tick (lazy records): a bin whose
 // reserved records can pass the group/mask filter against each other, or a ring sector (the border pack reads those).
 // With the world's layer VOCABULARY declared (scTickSetWorldLayers) and the pair half pipelined, "written on every tick" means:
@@ -2392,8 +2531,11 @@ __global__ __launch_bounds__(kTile) void k_home_flags(const DeviceState d, uint3
   uint32_t hB = d.homeB[i];
 #pragma unroll
   for (uint32_t k = 0; k < 4u; ++k) {
-    if (((hB >> (8u * k)) & 0xFFu) == kNoSlot) continue;
+    const uint32_t byte = (hB >> (8u * k)) & 0xFFu;
+    if (byte == kNoSlot) continue;
     const uint32_t sec = hA + (k & 1u) + (k >> 1) * binSX;
+    // the slot the record was moved to when its bin was put in order (k_order_home)
+    hB = (hB & ~(0xFFu << (8u * k))) | ((uint32_t)d.homePerm[(size_t)sec * kBinCap + (byte & kSlotMask)] << (8u * k));
     const uint32_t H = d.homeLayers[sec];
     if (binWrittenEveryTick(vocabMode ? layersThatCanMeet(H, vocab) : H, sec, binSX, binSZ)) hB |= kSlotAlways << (8u * k);
   }
@@ -2407,6 +2549,7 @@ void launchSnapshotHome(const DeviceState& d, uint32_t sectors, uint32_t n, uint
 {
   if (!sectors) return;
   hipLaunchKernelGGL(k_snapshot_home, dim3((sectors + kTile - 1) / kTile), dim3(kTile), 0, s, d, sectors);
+  hipLaunchKernelGGL(k_order_home, dim3((sectors + kTile / 64u - 1) / (kTile / 64u)), dim3(kTile), 0, s, d, sectors);
   if (n) hipLaunchKernelGGL(k_home_flags, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, binSX, binSZ, vocabMode, vocab);
 }
 // `done` (may be null): recorded by the dispatch itself -- the event the copy stream waits for, without a marker packet

@@ -199,3 +199,34 @@ def test_occupancy_queries_match_is_occupied_world(oracle):
     assert (t.occupied(p, np.full(5, 0.1, np.float32), np.full(5, 4, np.uint32)) == 1).all()
     assert t.lib.scTickQueryOccupied(t.ctx, 300, None, None, None, None) == 0
     t.close(); ow.close()
+
+
+def test_ray_queries_against_the_reference_intersectRayAABB_cases():
+    """The reference's own answers (tests/golden/ray_aabb_ref.npz, group b: sc::editor::intersectRayAABB compiled unmodified,
+    oracle/make_golden_rays.py) through scTickSetRayQueries: case i is one box in sector i of a row of 512 sectors and one ray
+    near it, with a far limit of 64 m that keeps every ray away from the other cases' boxes (tests/test_oracle_pinned.py shows
+    that the limit does not change an answer).  The device normalises the raw direction itself; the golden direction is that
+    normalisation in float32.  Hit flags and ids equal, entry distances equal as bit patterns."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ray_aabb_ref.npz"))
+    mn, mx = g["b_min"], g["b_max"]
+    n = len(mn)
+    zeros = np.zeros((n, 3), np.float32)
+    w = sw.SynthWorld(pos=zeros.copy(), rot=zeros.copy(), scale=np.ones((n, 3), np.float32), parent=np.full(n, -1, np.int32),
+                      bmin=mn.copy(), bmax=mx.copy(), has_mesh=np.ones(n, np.uint8), has_bounds=np.ones(n, np.uint8),
+                      mesh=np.zeros(n, np.uint32), material=np.zeros(n, np.uint32),
+                      group=np.ones(n, np.uint32), mask=np.full(n, 0xFFFFFFFF, np.uint32),
+                      sector_of=np.zeros((n, 2), np.int32), origin=(0, 0), sectors=(n, 1))
+    t = WorldTick.from_world(w, broadphase=True)
+    t.set_ray_queries(g["b_origin"], g["b_dir_raw"], np.full(n, 64.0, np.float32), np.full(n, 0xFFFFFFFF, np.uint32))
+    for flags in (FLAGS, FLAGS):                      # the learn tick, then a tick on remembered (ordered) slots
+        t.run(flags)
+        gmn, gmx = t.world_aabbs()
+        assert np.array_equal(gmn.view(np.uint32), mn.view(np.uint32)) and np.array_equal(gmx.view(np.uint32), mx.view(np.uint32))
+        got = t.ray_hits()
+        assert np.array_equal(got["hit"], g["b_hit"].astype(np.uint32))
+        hit = got["hit"] == 1
+        assert np.array_equal(got["id"][hit], np.flatnonzero(hit).astype(np.uint32))
+        assert np.array_equal(got["distance"][hit].view(np.uint32), g["b_t"][hit].view(np.uint32))
+    assert 300 < hit.sum() < n
+    t.close()

@@ -40,7 +40,11 @@ flags = capi.FULL | (0 if args.separate_producer else capi.PRODUCE_NEXT)
 
 ctxs = {}
 for path in args.libs:
-    lib_path, _, variant = path.partition("@")            # "lib.so@48": SC_TICK_VARIANT for this context (tuning knobs)
+    path_env, _, envs = path.partition("#")               # "lib.so#SC_TICK_FAST_PAIRS=0,SC_TICK_HOME_PERIOD=8": environment for this context's creation
+    for kv in filter(None, envs.split(",")):
+        k, _, v = kv.partition("=")
+        os.environ[k] = v
+    lib_path, _, variant = path_env.partition("@")        # "lib.so@48": SC_TICK_VARIANT for this context (tuning knobs)
     variant, _, spans = variant.partition(":")            # "lib.so@0:4096": SC_TICK_SPANS too (workgroups of the fused kernel)
     os.environ["SC_TICK_VARIANT"] = variant or "0"
     if spans:
@@ -50,6 +54,8 @@ for path in args.libs:
     capi._LIB = None
     capi.LIB_PATH = os.path.abspath(lib_path)
     t = WorldTick.from_world(w, broadphase=True)
+    for kv in filter(None, envs.split(",")):
+        os.environ.pop(kv.partition("=")[0], None)
     t.set_view_proj(vp)
     t.set_frame_producer(kind, param)
     (t.advance_movers if kind == 2 else t.nudge_roots_x)(param)
@@ -79,7 +85,7 @@ vis = {p: int(t.counts().visible) for p, t in ctxs.items()}
 prs = {p: int(t.counts().pairs) for p, t in ctxs.items()}
 for path in args.libs:
     r = res[path]
-    print(json.dumps({"lib": os.path.basename(path.partition("@")[0]) + ("@" + path.partition("@")[2] if "@" in path else ""), "workload": args.workload,
+    print(json.dumps({"lib": os.path.basename(path.partition("#")[0].partition("@")[0]) + path[len(path.partition("#")[0].partition("@")[0]):], "workload": args.workload,
                       "step_us_median": round(float(np.median(r["step_us"])), 2), "step_us_min": round(float(np.min(r["step_us"])), 2),
                       "k_xform_cull_us": round(float(np.median(r["k1_us"])), 2), "end_of_tick_us": round(float(np.median(r["eot_us"])), 2) if r["eot_us"] else None,
                       "gap_us": round(float(np.median(r["step_us"])) - float(np.median(r["k1_us"])) - (float(np.median(r["eot_us"])) if r["eot_us"] else 0.0), 2),
