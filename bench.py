@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (vendor peak); the copy ceiling is measured below
-PROFILE_ROUND = "r03"          # profiles/<round>/pmc_traffic_<workload>.json: the PMC passes the `traffic` fields are read from
+PROFILE_ROUND = "r04"          # profiles/<round>/pmc_traffic_<workload>.json: the PMC passes the `traffic` fields are read from
 TILE_SECTORS = 256
 PROPS = 15
 
@@ -83,6 +83,7 @@ def pmc_traffic(stages, entities_per_gpu, workload="config3", kernel="k_xform_cu
     FETCH_SIZE and WRITE_SIZE collected in separate passes and calibrated on known-byte copy kernels of the same
     access widths (FETCH_SIZE under-counts 2x on gfx950).  None when no profile of this exact workload is committed."""
     for path in (os.path.join(ROOT, "profiles", PROFILE_ROUND, f"pmc_traffic_{workload}.json"),
+                 os.path.join(ROOT, "profiles", "r03", f"pmc_traffic_{workload}.json"),
                  os.path.join(ROOT, "profiles", "r02", f"pmc_traffic_{workload}.json"),
                  os.path.join(ROOT, "profiles", "pmc_traffic.json")):
         try:
@@ -94,8 +95,12 @@ def pmc_traffic(stages, entities_per_gpu, workload="config3", kernel="k_xform_cu
             continue
         v = d.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
         if v is not None:
+            PMC_SOURCES[kernel] = os.path.relpath(path, ROOT)
             return v
     return None
+
+
+PMC_SOURCES = {}      # kernel -> the committed profile file its `traffic` figure was replayed from (it is NOT measured by this run)
 
 
 def copy_ceiling_gbs(torch, device):
@@ -139,6 +144,18 @@ def make_world(args, rank, grid):
     cam["pos"][2] = np.float32(float(tz * SZ) * 64.0 / 2)
     w.camera = cam
     return w, SX, SZ
+
+
+def host_cpu_model():
+    """the host CPU's model name ("print the host CPU model and core count")"""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 class OracleLeg:
@@ -210,7 +227,7 @@ class OracleLeg:
         self.oracle.lib().orc_jobs_init(0)
         med = float(np.median(times))
         n = self.world.n
-        return {"value": n / med, "unit": "entities/s", "cores": workers + 1, "kind": "port",
+        return {"value": n / med, "unit": "entities/s", "cores": workers + 1, "kind": "port", "host_cpu": host_cpu_model(),
                 "threading": "JobSystem::Dispatch restated: per-worker 1024-slot rings, round-robin enqueue, inline when every ring is full, stealing workers, helping waiter (sc_jobs.cpp:247-372)" if workers else "no job system: groups run in order on the caller",
                 "sample": f"same world ({n} entities), {warm} warm-up + {ticks} timed ticks, "
                           f"{'all roots nudged' if self.vel is None else 'movers advanced'} each tick, "
@@ -490,11 +507,13 @@ def main():
     # reported; the roofline uses the every-launch pass.
     sample = args.sample if args.sample > 0 else (8 if args.steps > 32 else max(args.steps // 2, 1))
     t.set_profiling(0 if args.profile_run else sample)
+    learn_before = t.bin_stats()["learn_ticks"] if (flags & capi.BROADPHASE) else 0       # (a read-back: outside the timed region)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    learn_in_region = (t.bin_stats()["learn_ticks"] - learn_before) if (flags & capi.BROADPHASE) else 0
     k1_region = t.kernel_times_ms(capi.K_XFORM_CULL)
     kp_region = t.kernel_times_ms(capi.K_PAIRS)
     t.set_profiling(0 if args.profile_run else 1)
@@ -561,8 +580,10 @@ def main():
                 got, total = t.pairs()
                 gate = tile_pair_gate(args, rank, grid, ticks_done[0], got, total)
                 parity.update(gate)
-                parity["border_lost"] = int(t.counts().border_lost)
-                parity["ok"] = bool(parity["ok"] and gate["pairs_equal"] and parity["border_lost"] == 0)
+                cnt_now = t.counts()
+                parity["border_lost"] = int(cnt_now.border_lost)
+                parity["vocabulary_violations"] = int(cnt_now.vocabulary_violations)      # a neighbour's record outside the declared layer vocabulary
+                parity["ok"] = bool(parity["ok"] and gate["pairs_equal"] and parity["border_lost"] == 0 and parity["vocabulary_violations"] == 0)
             ok = torch.tensor([1 if parity["ok"] else 0], dtype=torch.int32, device=ctl_device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             parity["all_ranks_ok"] = bool(int(ok.item()))
@@ -573,11 +594,42 @@ def main():
                 dist.destroy_process_group()
             sys.exit(3)
 
+    # ---- result assembly (N > 1): the global visible list = the ranks' lists in rank order, each at the offset its rank gets from
+    # the all-gathered counts (the library's own communicator: scTickGatherVisibleCounts; the host's control plane in the one-GPU
+    # rehearsal).  Rank 0 checks the assembled list against the ranks' ORACLE lists assembled the same way.
+    visible_assembly = None
+    if world_size > 1 and "cull" in stages:
+        off, total, ids = tiles.global_visible(t, rank, w.n)
+        mine_vis = {"rank": rank, "offset": off, "total": total, "ids": ids.tolist(),
+                    "oracle_ids": (leg.ow.visible().astype(np.uint64) + np.uint64(rank * w.n)).tolist() if leg is not None else None}
+        boxv = [None] * world_size
+        dist.all_gather_object(boxv, mine_vis)
+        if rank == 0:
+            whole = np.full(total, np.uint64(0xFFFFFFFFFFFFFFFF))
+            for m in boxv:
+                whole[m["offset"]:m["offset"] + len(m["ids"])] = np.asarray(m["ids"], np.uint64)
+            visible_assembly = {"visible_total": int(total), "offsets": [int(m["offset"]) for m in boxv],
+                                "totals_agree": all(m["total"] == total for m in boxv),
+                                "every_slot_filled": bool((whole != np.uint64(0xFFFFFFFFFFFFFFFF)).all())}
+            if leg is not None:
+                want = np.concatenate([np.asarray(m["oracle_ids"], np.uint64) for m in boxv]) if total else np.zeros(0, np.uint64)
+                visible_assembly["equals_oracle_concatenation"] = bool(len(want) == total and np.array_equal(whole, want))
+            bad = not (visible_assembly["totals_agree"] and visible_assembly["every_slot_filled"] and visible_assembly.get("equals_oracle_concatenation", True))
+            if bad:
+                print(f"GLOBAL VISIBLE LIST MISMATCH: {json.dumps(visible_assembly)}", file=sys.stderr)
+        okv = torch.tensor([0 if (rank == 0 and bad) else 1], dtype=torch.int32, device=ctl_device)
+        dist.all_reduce(okv, op=dist.ReduceOp.MIN)
+        if not int(okv.item()):
+            t.close()
+            dist.destroy_process_group()
+            sys.exit(3)
+
     # ---- per-rank diagnostics (N > 1): what the first scaling curve will have to be read with ----
     per_rank = None
     if world_size > 1:
         ci = t.comm_info() if borders is None else {}
-        mine = {"rank": rank, "border_lost": int(counts.border_lost), "pairs": int(counts.pairs), "visible": int(counts.visible),
+        mine = {"rank": rank, "border_lost": int(counts.border_lost), "vocabulary_violations": int(counts.vocabulary_violations),
+                "pairs": int(counts.pairs), "visible": int(counts.visible),
                 "ms_per_step_own_clock": own_elapsed / args.steps * 1e3,
                 "tick_chain_us": {"k_xform_cull": float(np.mean(k1)) * 1e3 if len(k1) else None,
                                   "compaction_and_pack": float(np.mean(k2)) * 1e3 if len(k2) else None},
@@ -631,8 +683,15 @@ def main():
                 "resident": "device SoA authoritative; no per-step host transfer",
                 "control_plane": args.control if world_size > 1 else None,
                 "rehearsal_same_device": bool(args.same_device),
+                # the bins' remembered slots are relearned every `period` broadphase ticks (SC_TICK_HOME_PERIOD, default 64): that tick
+                # reserves every slot with atomics again and runs three small kernels behind the fused one (slot counts, the bins'
+                # cast-first order, the slots' flags) -- about 25 us more than an ordinary tick at 1M entities (profiles/r04:
+                # the k_xform_cull<..., 1u> row and k_snapshot_home / k_order_home / k_home_flags), i.e. ~0.4 us per step amortised
+                "learn_tick": {"period": int(os.environ.get("SC_TICK_HOME_PERIOD", "64")), "learn_ticks_inside_the_timed_region": int(learn_in_region),
+                               "timed_steps": args.steps},
             },
             "parity_in_run": parity,
+            "visible_assembly": visible_assembly,
             "per_rank": per_rank,
             "end_to_end": end_to_end,
             "roofline": {
@@ -640,6 +699,8 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": pmc_traffic(stages, w.n, args.workload),
+                "traffic_source": (f"replayed from {PMC_SOURCES['k_xform_cull']} (rocprofv3 --pmc passes of an earlier session; not a measurement of this run)"
+                                   if "k_xform_cull" in PMC_SOURCES else None),
                 "bytes_per_entity": bpe, "records_written_frac": rec_frac, "avg_launch_ms": k1_ms, "launches_timed": int(len(k1)),
                 # the same launch priced at the bytes of a kernel that writes every record every tick (round 2's kernel; SURVEY 8d's
                 # per-entity figure for this design): what the time would be worth had the work not been removed
@@ -654,6 +715,7 @@ def main():
                     "avg_launch_ms_in_timed_region": float(np.mean(kp_region)) if len(kp_region) else None,
                     "achieved": eot_achieved, "frac": (eot_achieved / HBM_PEAK_GBS) if eot_achieved else None,
                     "traffic": pmc_traffic(stages, w.n, args.workload, "k_compact_pairs"),
+                    "traffic_source": (f"replayed from {PMC_SOURCES['k_compact_pairs']}" if "k_compact_pairs" in PMC_SOURCES else None),
                     "timing": "begin / end timestamps of the dispatch itself (hipExtLaunchKernelGGL events), as for the fused kernel",
                 },
                 "other_kernels_ms": {"k_compact": float(np.mean(k2)) if len(k2) else None,

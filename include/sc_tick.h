@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SC_TICK_API_VERSION 6u
+#define SC_TICK_API_VERSION 7u
 #define SC_TICK_MAX_ENTITIES ((1u << 24) - 1u)   /* Entity::INDEX_BITS = 24 (sc_ecs.h:18-20); index 0xFFFFFF is the "no parent" value */
 #define SC_TICK_NO_PARENT (-1)
 
@@ -96,6 +96,10 @@ typedef struct ScTickCounts    /* CullingStats (sc_world_partition.h:334-339) + 
                                   (scTickSetBorderCapacity), big boxes reaching beyond the eight neighbouring tiles, a sector with more
                                   than 64 + 1024 boxes; non-zero means pairs may be missing */
   uint32_t relinks;            /* whole-world hierarchy re-links (O(entities) on the host) this context has done so far */
+  uint32_t vocabulary_violations;  /* with scTickSetWorldLayers(known): border records and big boxes that ARRIVED from a neighbour with group or
+                                      mask bits outside the declared vocabulary this tick -- the neighbour broke the contract, pairs in bins
+                                      this tile leaves unwritten may be missing; 0 otherwise.  (This tile's own layers cannot leave the
+                                      vocabulary: scTickUploadLayers / scTickAppendEntities refuse them.) */
 } ScTickCounts;
 
 typedef struct ScTickDrawItem  /* DrawItem, sc_ecs.h:159-165: 80 bytes, model at offset 16, column-major */
@@ -254,6 +258,16 @@ typedef struct ScTickCommInfo
   double   host_tick_half_us, host_pair_half_us;
 } ScTickCommInfo;
 int scTickGetCommInfo(ScTickContext* ctx, ScTickCommInfo* out);
+/* Result assembly at N > 1: the global visible list is the concatenation of the tiles' lists in rank order --
+ * entities are created tile-major, so that IS the order of the reference's serial compaction over the whole world
+ * (src/engine/world/sc_world_partition.cpp:1273-1280) -- and each rank copies its slice to the host at its own offset.  This call
+ * is the one tiny collective that needs: an all-gather of the ranks' visible counts of the last tick over the context's
+ * communicator (ncclAllGather of one uint32 per rank; every rank must call it, after the same tick).  counts_out (may be NULL)
+ * receives min(world_size, capacity) counts; *offset_out = the sum of the counts of the ranks before this one = where this rank's
+ * scTickReadVisible slice starts in the global list (its ids are dense indices of the tile: add rank * entities-per-tile for
+ * global dense indices); *total_out = the length of the global list.  Without a communicator (a 1x1 grid) the tile is the world:
+ * offset 0, total = its own count.  Synchronises the context (a read-back call, like scTickReadVisible). */
+int scTickGatherVisibleCounts(ScTickContext* ctx, uint32_t* counts_out, uint32_t capacity, uint64_t* offset_out, uint64_t* total_out);
 
 /* Broadphase bins, how they are filled (diagnostics; the pair set never depends on any of it).  Records keep the bin slot they
  * reserved at the last "learn" tick while their box stays in its sector (no reservation, i.e. no atomic, on the ticks in
@@ -268,8 +282,11 @@ int scTickGetBinStats(ScTickContext* ctx, uint32_t stats[4]);
  * ANY tile, now or later (until the next call; bits 0..15, or 0xFFFFFFFF = all, as scTickUploadLayers).  With it a pipelined tile
  * (scTickSetPipelined / scTickSetPairsStream) leaves the bins unwritten whose own records can meet nothing the world contains --
  * static props in a world without dynamic bodies, say -- because nothing will ever read them; without it (known = 0, the default)
- * a pipelined tile writes every record on every tick.  A contract: a collider outside the declared vocabulary (on this tile or
- * arriving from a neighbour) may miss pairs in such bins.  In-order flows do not need it (they rebuild unwritten bins on demand). */
+ * a pipelined tile writes every record on every tick.  A contract, and a checked one: while a vocabulary is declared,
+ * scTickUploadLayers / scTickAppendEntities FAIL for a group or mask word outside it (declare the wider vocabulary first), a call
+ * that narrows the vocabulary below the layers already uploaded fails too, and a record or big box that arrives from a neighbour
+ * with bits outside it is counted in ScTickCounts::vocabulary_violations (bench.py's N > 1 gate requires 0).  In-order flows do not
+ * need the declaration (they rebuild unwritten bins on demand). */
 int scTickSetWorldLayers(ScTickContext* ctx, uint32_t group_or, uint32_t mask_or, int known);
 int scTickResetHostTimes(ScTickContext* ctx);
 int scTickTileStep(ScTickContext* ctx, uint32_t flags);

@@ -35,7 +35,8 @@ class ContextDesc(C.Structure):
 class Counts(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "entities", "renderables_total", "visible", "culled", "pairs", "pairs_truncated",
-        "draws_emitted", "draws_dropped", "max_depth", "unreachable", "bin_overflow", "big_boxes", "draws_sorted", "border_lost", "relinks")]
+        "draws_emitted", "draws_dropped", "max_depth", "unreachable", "bin_overflow", "big_boxes", "draws_sorted", "border_lost", "relinks",
+        "vocabulary_violations")]
 
 
 class DrawItem(C.Structure):
@@ -126,6 +127,7 @@ SYMBOLS = {
     "scTickCommDestroy": (C.c_int, [_CTX]),
     "scTickSetPipelined": (C.c_int, [_CTX, C.c_int]),
     "scTickGetCommInfo": (C.c_int, [_CTX, C.POINTER(CommInfo)]),
+    "scTickGatherVisibleCounts": (C.c_int, [_CTX, U32P, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "scTickGetBinStats": (C.c_int, [_CTX, U32P]),
     "scTickSetWorldLayers": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, C.c_int]),
     "scTickResetHostTimes": (C.c_int, [_CTX]),

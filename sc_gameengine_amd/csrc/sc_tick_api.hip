@@ -41,6 +41,7 @@ struct ScTickContext
 
   // host mirrors needed to (re)build link words
   std::vector<int32_t> hParent;
+  std::vector<uint32_t> hLayers;     // group | mask << 16 as uploaded (scTickUploadLayers), for the world-vocabulary contract
   std::vector<uint8_t> hFlags;       // bit0 has mesh, bit1 has bounds, bits 2..4 rotation about X/Y/Z trivial (sin 0, cos 1)
   std::vector<uint32_t> hChildren;   // direct children per entity (valid while !linksStale)
   // child lists in dense-index space (-1 = none), valid while !linksStale: a despawn patches exactly the links that
@@ -150,6 +151,7 @@ struct ScTickContext
   uint32_t* ownBorder[kMaxParity][8][2] = {};   // [parity][direction][send, recv]
   double hostAcc[2] = { 0.0, 0.0 }; uint64_t hostSteps = 0;     // scTickTileStep: host time issuing the tick half / the exchange + pair half
   hipStream_t ownPairsStream = nullptr;
+  uint32_t* dGather = nullptr; uint32_t gatherCap = 0;          // scTickGatherVisibleCounts: one count per rank
 };
 
 namespace {
@@ -708,7 +710,7 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
             && dalloc(c, d.ovfIdx, (size_t)kOvfWaves * kOvfPerSector, false) && dalloc(c, d.ovfLo, c->sectors, false) && dalloc(c, d.ovfHi, c->sectors)
             && dalloc(c, d.pairs, c->maxPairs, false) && dalloc(c, d.pairShardCount, (kMaxParity + 1u) * kPairShards * kShardStride)
             && dalloc(c, c->dPairsOut, c->maxPairs, false) && dalloc(c, c->dPairTotal, 4)
-            && dalloc(c, d.homeA, N, false) && dalloc(c, d.homeB, N, false) && dalloc(c, d.homeCount, c->sectors) && dalloc(c, d.homeLayers, c->sectors) && dalloc(c, d.lazyCtl, 1u + kMaxParity)
+            && dalloc(c, d.homeA, N, false) && dalloc(c, d.homeB, N, false) && dalloc(c, d.homeCount, c->sectors) && dalloc(c, d.homeLayers, c->sectors) && dalloc(c, d.lazyCtl, 1u + 2u * kMaxParity)
             && dalloc(c, d.homeCast, c->sectors) && dalloc(c, d.homePerm, (size_t)c->sectors * kBinCap);
     if (ok) { e = hipMemset(d.homeA, 0xFF, N * sizeof(uint32_t)); if (e == hipSuccess) e = hipMemset(d.homeB, 0xFF, N * sizeof(uint32_t)); if (e != hipSuccess) ok = fail(c, "hipMemset", e); }
   }
@@ -863,8 +865,14 @@ int scTickUploadLayers(ScTickContext* c, uint32_t first, uint32_t count, const u
     const uint32_t g = group[i], m = mask[i];
     if ((g != 0xFFFFFFFFu && (g >> 16)) || (m != 0xFFFFFFFFu && (m >> 16))) return fail(c, "group/mask bits above 15 are not supported");
     packed[i] = (g & 0xFFFFu) | ((m & 0xFFFFu) << 16);
+    // the declared layer vocabulary of the tiled world is a contract (scTickSetWorldLayers): a collider outside it could meet bins that
+    // this or another tile leaves unwritten for good -- refused here instead of missing pairs silently there
+    if (c->worldLayersKnown && (packed[i] & ~c->worldLayers))
+      return fail(c, "layers outside the declared world vocabulary (scTickSetWorldLayers): declare the wider vocabulary on every tile first");
   }
   if (!h2d(c, c->d.layers + first, packed.data(), (size_t)count * 4u)) return 0;
+  if (c->hLayers.size() < (size_t)first + count) c->hLayers.resize((size_t)first + count, 0u);
+  std::copy(packed.begin(), packed.end(), c->hLayers.begin() + first);      // (host mirror: what a later, narrower vocabulary is checked against)
   c->homeValid = false;                 // the bins' remembered layer summaries are behind
   return sync(c) ? 1 : 0;
 }
@@ -1003,6 +1011,8 @@ int scTickRemoveEntities(ScTickContext* c, const uint32_t* idx, uint32_t count, 
     if (!h2d(c, c->dIdx, src.data(), (size_t)moves * 4u) || !h2d(c, c->dIdx + moves, dst.data(), (size_t)moves * 4u)) return 0;
     launchMoveEntities(c->d, c->dIdx, c->dIdx + moves, moves, c->stream);
     if (!sync(c)) return 0;                          // the scratch buffer is reused for the parent patches below
+    for (uint32_t k = 0; k < moves; ++k)             // (the layer words' host mirror moves along: sources lie beyond every target)
+      if (src[k] < c->hLayers.size()) { if (c->hLayers.size() <= dst[k]) c->hLayers.resize((size_t)dst[k] + 1u, 0u); c->hLayers[dst[k]] = c->hLayers[src[k]]; }
   }
 
   std::vector<uint32_t> patch;                       // (entity, new parent) pairs for the device link words
@@ -1281,6 +1291,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
     const bool hostBetweenHalves = (flags & SC_TICK_SPLIT_PAIRS) && !c->pairsStream && !c->ownStep;
     p.lazy = (p.homeMode == kHomeUse && c->lazyEnabled && !(flags & SC_TICK_RAYS) && !c->sensors && !hostBetweenHalves) ? (!c->pairsStream ? 1u : (c->worldLayersKnown ? 2u : 0u)) : 0u;
     p.vocab = c->worldLayers;
+    p.vocabKnown = c->worldLayersKnown ? 1u : 0u;
     c->lastTickLazy = p.lazy != 0u;
     // records of entities that did not move stay as they are, unless something else changed boxes since the last tick
     p.cleanStay = (p.homeMode == kHomeUse && c->lazyEnabled && !c->pairsStream && !c->boxesTouched) ? 1u : 0u;
@@ -1648,6 +1659,11 @@ int scTickGetCounts(ScTickContext* c, ScTickCounts* out)
   out->bin_overflow = bp[kCtrSpill];                 // length of the sector overflow list (own boxes + border records that landed in a full bin)
   out->big_boxes = (c->lastFlags & SC_TICK_SPLIT_PAIRS) ? bp[kCtrBigLocal] : bp[kCtrBig];
   out->border_lost = bp[kCtrBorderLost];
+  if (c->sectors) {
+    uint32_t lc[1u + 2u * kMaxParity] = {};
+    if (!d2h(c, lc, c->d.lazyCtl, sizeof lc) || !sync(c)) return 0;
+    out->vocabulary_violations = lc[1u + kMaxParity + resultSlot];
+  }
   out->draws_emitted = k[4];
   out->draws_dropped = k[5];
   out->draws_sorted = (c->lastFlags & SC_TICK_SORT_DRAWS) ? k[kCtrDrawsSorted] : 0u;
@@ -2193,6 +2209,11 @@ int scTickSetWorldLayers(ScTickContext* c, uint32_t groupOr, uint32_t maskOr, in
   if (!bind(c)) return 0;
   if (known && (((groupOr != 0xFFFFFFFFu) && (groupOr >> 16)) || ((maskOr != 0xFFFFFFFFu) && (maskOr >> 16)))) return fail(c, "group/mask bits above 15 are not supported");
   const uint32_t v = known ? ((groupOr & 0xFFFFu) | ((maskOr & 0xFFFFu) << 16)) : 0u;
+  if (known) {                                        // the contract holds for what is already here, too
+    const size_t upto = std::min<size_t>(c->hLayers.size(), c->n);
+    for (size_t i = 0; i < upto; ++i)
+      if ((c->hFlags[i] & 2u) && (c->hLayers[i] & ~v)) return fail(c, "the vocabulary does not cover the layers already uploaded to this tile");
+  }
   if ((known != 0) != c->worldLayersKnown || v != c->worldLayers) {
     if (!sync(c)) return 0;
     c->worldLayersKnown = known != 0; c->worldLayers = v;
@@ -2334,6 +2355,33 @@ int scTickGetCommInfo(ScTickContext* c, ScTickCommInfo* out)
   out->host_steps = c->hostSteps;
   out->host_tick_half_us = c->hostSteps ? c->hostAcc[0] / (double)c->hostSteps : 0.0;
   out->host_pair_half_us = c->hostSteps ? c->hostAcc[1] / (double)c->hostSteps : 0.0;
+  return 1;
+}
+
+int scTickGatherVisibleCounts(ScTickContext* c, uint32_t* countsOut, uint32_t capacity, uint64_t* offsetOut, uint64_t* totalOut)
+{
+  if (!c || !offsetOut || !totalOut) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !sync(c)) return 0;                      // both streams idle: the collective below is the communicator's only operation in flight
+  const uint32_t ranks = c->comm ? c->commSize : 1u;
+  std::vector<uint32_t> counts(ranks, 0u);
+  if (!c->comm) {
+    if (!d2h(c, counts.data(), c->d.counters, sizeof(uint32_t)) || !sync(c)) return 0;
+  } else {
+    const RcclApi* r = needRccl(c);
+    if (!r) return 0;
+    if (c->gatherCap < ranks) {
+      dfree(c, c->dGather); c->dGather = nullptr; c->gatherCap = 0;
+      if (!dalloc(c, c->dGather, ranks)) return 0;
+      c->gatherCap = ranks;
+    }
+    if (!ncclOk(c, r, r->AllGather(c->d.counters, c->dGather, 1, ncclUint32, c->comm, c->stream), "ncclAllGather (visible counts)")) return 0;
+    if (!d2h(c, counts.data(), c->dGather, (size_t)ranks * sizeof(uint32_t)) || !sync(c)) return 0;
+  }
+  uint64_t before = 0, total = 0;
+  const uint32_t me = c->comm ? c->commRank : 0u;
+  for (uint32_t k = 0; k < ranks; ++k) { if (k < me) before += counts[k]; total += counts[k]; }
+  if (countsOut) for (uint32_t k = 0; k < ranks && k < capacity; ++k) countsOut[k] = counts[k];
+  *offsetOut = before; *totalOut = total;
   return 1;
 }
 

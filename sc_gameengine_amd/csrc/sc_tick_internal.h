@@ -116,7 +116,8 @@ struct DeviceState {
   // pair search only when a record from elsewhere arrives that can -- so its owners do not write it (homeB bit 6 of a slot
   // byte = "write every tick"), and the wave that does need such a bin rebuilds its records from the owners' matrices.
   uint32_t* lazyCtl;           // [0] big boxes of the last pair search (!= 0: the next fused kernel writes every record),
-                               // [1 + parity] 1 = that tick's fused kernel wrote every reserved record (what its pair search goes by)
+                               // [1 + parity] 1 = that tick's fused kernel wrote every reserved record (what its pair search goes by),
+                               // [1 + kMaxParity + parity] records / big boxes that arrived from a neighbour outside the declared layer vocabulary
   float4* bigList;             // [cap][2] boxes that cannot be binned (too large, outside the rect, bin full)
   float4* spill;               // [ovfCap][2] sector OVERFLOW list: records that found their sector bin full -- this tile's own
                                // (fused kernel) and the neighbours' border records (merge) alike ...
@@ -216,6 +217,7 @@ struct TickParams {
                             // can meet nothing in the world's declared vocabulary, never needed (pipelined tiles, scTickSetWorldLayers);
                             // 0 when something else reads the bins (ray queries, traffic sensors) or neither applies
   uint32_t vocab;           // lazy 2: group bits | mask bits << 16 of every collider that can exist in the tiled world
+  uint32_t vocabKnown;      // scTickSetWorldLayers declared the world's layer vocabulary (`vocab`): the border merge counts arrivals outside it
   uint32_t fastPairs;       // the pair role takes bins that hold nothing but their ordered reserved records through the fast path (homeCast)
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d

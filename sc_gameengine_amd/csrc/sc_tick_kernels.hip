@@ -1171,6 +1171,7 @@ __device__ __forceinline__ void resetOtherParity(const DeviceState& d, const Tic
 {
   if (bid == 0 && threadIdx.x < 8) d.counters[kCtrPar + 8u * (p.parity ^ 1u) + threadIdx.x] = 0u;
   if (bid == 0 && threadIdx.x < kPairShards) d.pairShardCount[((p.parity ^ 1u) * kPairShards + threadIdx.x) * kShardStride] = 0u;
+  if (bid == 0 && threadIdx.x == 0) d.lazyCtl[1u + kMaxParity + (p.parity ^ 1u)] = 0u;
   (void)nblocks;
 }
 
@@ -1183,6 +1184,7 @@ __device__ __forceinline__ void resetParity(const DeviceState& d, uint32_t q)
 {
   if (threadIdx.x < 8) d.counters[kCtrPar + 8u * q + threadIdx.x] = 0u;
   if (threadIdx.x < kPairShards) d.pairShardCount[(q * kPairShards + threadIdx.x) * kShardStride] = 0u;
+  if (threadIdx.x == 0) d.lazyCtl[1u + kMaxParity + q] = 0u;
 }
 __global__ __launch_bounds__(kTile) void k_reset_parity(const DeviceState d, uint32_t q)
 {
@@ -1368,6 +1370,10 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     // low-corner rule and the sink, ~60 instructions, two or three times per sector -- its two slot numbers go to a short list in LDS
     // and the list is resolved behind the rounds, 64 candidates at a time with every lane busy: the full box test (y included),
     // filter, ids, low corner (pairHit).  Same predicate, same pair set.
+    // (Tried on top and dropped, profiles/r04/ab_sweeper_lanes_lost.log: LANE = SWEEPER across all fast sectors of the round -- a prefix
+    //  sum numbers the sweepers, 64 are taken at a time, each lane walks its sector's slots straight from the bins, nothing staged, no
+    //  per-sector set-up at all.  Correct -- 103 parity tests green -- and slow: config 5 90 us against 40, config3dyn 30 against 27: a
+    //  slot step is eight dword loads per lane through the vector memory pipe, and that pipe, not instruction issue, then sets the pace.)
     const bool myFast = myCount != 0u && mine && (myCast & kCastFast) != 0u && !myOver && !myStale;
     const unsigned long long fastMask = ballot64(myFast);
     if (fastMask) {
@@ -2139,6 +2145,8 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
       place(sector, slot0 + r, q0 + (slot0 + r - firstOver), lo, hi);
     }
     if (lay) atomicOr(&d.binLayers[sector], lay);
+    // the declared layer vocabulary is a contract between the tiles (scTickSetWorldLayers): what arrives outside it is counted, never silent
+    if (p.vocabKnown && (lay & ~p.vocab)) atomicAdd(&d.lazyCtl[1u + kMaxParity + p.parity], 1u);
   };
   // crowded landing sectors: the wave lands them one after the other, a record per lane and round
   auto landCrowded = [&](uint32_t l, uint32_t off, uint32_t c, bool mine) __attribute__((always_inline)) {
@@ -2162,6 +2170,7 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) lay |= (uint32_t)__shfl_xor((int)lay, o, 64);
       if (lane == 0 && lay) atomicOr(&d.binLayers[sector], lay);
+      if (lane == 0 && p.vocabKnown && (lay & ~p.vocab)) atomicAdd(&d.lazyCtl[1u + kMaxParity + p.parity], 1u);
     }
   };
   // Two passes over the message's bins: the first lands the usual ones -- up to kSerial records, each bin by its own thread --,
@@ -2206,7 +2215,10 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
   __syncthreads();
   const uint32_t at = sOff[0];
   const float4* src = reinterpret_cast<const float4*>(big + 2);
-  for (uint32_t r = threadIdx.x; r < 2u * m; r += kTile) if (at + r / 2u < p.bigCap) d.bigList[2u * (size_t)at + r] = src[r];
+  for (uint32_t r = threadIdx.x; r < 2u * m; r += kTile) {
+    if (at + r / 2u < p.bigCap) d.bigList[2u * (size_t)at + r] = src[r];
+    if (p.vocabKnown && !(r & 1u) && (__float_as_uint(src[r].w) & ~p.vocab)) atomicAdd(&d.lazyCtl[1u + kMaxParity + p.parity], 1u);      // (big boxes too)
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -42,6 +42,7 @@ void bindOnce()
     { (void**)&gApi.CommAbort, "ncclCommAbort" }, { (void**)&gApi.CommGetAsyncError, "ncclCommGetAsyncError" },
     { (void**)&gApi.GetErrorString, "ncclGetErrorString" }, { (void**)&gApi.GroupStart, "ncclGroupStart" },
     { (void**)&gApi.GroupEnd, "ncclGroupEnd" }, { (void**)&gApi.Send, "ncclSend" }, { (void**)&gApi.Recv, "ncclRecv" },
+    { (void**)&gApi.AllGather, "ncclAllGather" },
   };
   for (const Sym& s : syms) {
     *s.slot = dlsym(h, s.name);

@@ -21,6 +21,7 @@ struct RcclApi {
   ncclResult_t (*GroupEnd)();
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);      // the visible counts ("one tiny all-gather")
 };
 
 // nullptr when librccl cannot be opened or lacks a symbol; *why receives the reason

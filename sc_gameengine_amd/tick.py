@@ -404,6 +404,15 @@ class WorldTick:
         """False / 0 = off, True / 1 = on (default depth 4), 2..4 = on with that many copies of the per-tick broadphase state"""
         self._ok(self.lib.scTickSetPipelined(self.ctx, int(on)), "scTickSetPipelined")
 
+    def gather_visible_counts(self, max_ranks=128):
+        """Every rank's visible count of the last tick (one all-gather over the library's communicator; every rank must call),
+        this rank's offset in the global visible list and the list's length: (counts, offset, total).  SURVEY 8e, result assembly."""
+        counts = np.zeros(max_ranks, np.uint32)
+        off, tot = C.c_uint64(), C.c_uint64()
+        self._ok(self.lib.scTickGatherVisibleCounts(self.ctx, counts.ctypes.data_as(capi.U32P), max_ranks, C.byref(off), C.byref(tot)), "scTickGatherVisibleCounts")
+        ranks = max(self.comm_info()["world_size"], 1)
+        return counts[:ranks].copy(), int(off.value), int(tot.value)
+
     def comm_info(self):
         """the exchange as the library sees it (communicator, peers, operations per group, host time per half of a step) as a dict"""
         ci = capi.CommInfo()

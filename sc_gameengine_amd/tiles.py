@@ -127,6 +127,35 @@ def global_pair_ids(pairs, entities_per_rank):
     return ((p >> np.uint64(24)) & np.uint64(0x7F)) * np.uint64(entities_per_rank) + (p & np.uint64(0xFFFFFF))
 
 
+def visible_offsets(counts, rank):
+    """Result assembly: where rank `rank`'s visible list starts in the global list, and the global list's length, from
+    every rank's visible count.  Tiles are created in rank order and entities tile-major, so the concatenation of the tiles' lists
+    in rank order is the reference's own order (its serial compaction over the whole pool, sc_world_partition.cpp:1273-1280)."""
+    c = np.asarray(counts, np.uint64)
+    return int(c[:rank].sum()), int(c.sum())
+
+
+def global_visible(tick, rank, entities_per_rank, group=None):
+    """This rank's slice of the global visible list: (offset, total, global dense indices).  The one collective is the all-gather of
+    the visible counts: over the library's own communicator when the context has one (scTickGatherVisibleCounts), else over the
+    host's control plane (torch.distributed, any backend; e.g. the one-GPU rehearsal), else the tile is the world."""
+    vis = np.asarray(tick.visible(), np.uint64)
+    ids = vis + np.uint64(rank) * np.uint64(entities_per_rank)
+    if tick.comm_info()["has_communicator"]:
+        _, off, total = tick.gather_visible_counts()
+        return off, total, ids
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        import torch
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        mine = torch.tensor([len(vis)], dtype=torch.int64, device=dev)
+        box = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(box, mine, group=group)
+        off, total = visible_offsets([int(b.item()) for b in box], rank)
+        return off, total, ids
+    return 0, len(ids), ids
+
+
 def rendezvous_unique_id(rank, make_id, group=None):
     """The one thing the host's own channel has to carry: rank 0's 128-byte communicator id, to every rank.
     Here the channel is torch.distributed (any backend: the payload is a CPU object broadcast); `make_id` is called on

@@ -112,6 +112,15 @@ int main(int argc, char** argv)
   if (!ok(scTickReadVisible(ctx, vis.data(), n, &nv), "read visible")) return 1;
   REQUIRE(nv == cs->visibleLen, "visible count %u vs oracle %u", nv, cs->visibleLen);
   REQUIRE(std::memcmp(vis.data(), cs->visible, (size_t)nv * 4u) == 0, "visible list differs from the oracle's");
+  // result assembly: every rank's visible count over the library's communicator -> this rank's offset in the global
+  // list (tiles in rank order, entities tile-major: the concatenation is the reference's compaction order) and the list's length
+  std::vector<uint32_t> counts((size_t)world, 0u);
+  uint64_t offset = 0, totalVisible = 0;
+  if (!ok(scTickGatherVisibleCounts(ctx, counts.data(), (uint32_t)world, &offset, &totalVisible), "scTickGatherVisibleCounts")) return 1;
+  REQUIRE(counts[(size_t)rank] == nv, "the gathered count of this rank is %u, its list holds %u", counts[(size_t)rank], nv);
+  uint64_t before = 0, sum = 0;
+  for (int r = 0; r < world; ++r) { if (r < rank) before += counts[(size_t)r]; sum += counts[(size_t)r]; }
+  REQUIRE(offset == before && totalVisible == sum, "offset %llu / total %llu do not follow from the counts", (unsigned long long)offset, (unsigned long long)totalVisible);
   std::vector<float> got(16 * (size_t)n), want(16 * (size_t)n);
   if (!ok(scTickReadWorldMatrices(ctx, 0, n, got.data()), "read matrices")) return 1;
   orc_read_world_matrices(ow, want.data());
@@ -121,8 +130,8 @@ int main(int argc, char** argv)
   ScTickCounts c{};
   scTickGetCounts(ctx, &c);
   REQUIRE(c.border_lost == 0, "border_lost %u", c.border_lost);
-  std::printf("{\"rank\": %d, \"world_size\": %d, \"entities\": %u, \"steps\": %d, \"us_per_step\": %.2f, \"host_issue_us\": %.2f, \"visible\": %u, \"pairs\": %u}\n",
-              rank, world, n, steps, total / steps, issued / steps, nv, c.pairs);
+  std::printf("{\"rank\": %d, \"world_size\": %d, \"entities\": %u, \"steps\": %d, \"us_per_step\": %.2f, \"host_issue_us\": %.2f, \"visible\": %u, \"visible_offset\": %llu, \"visible_total\": %llu, \"pairs\": %u}\n",
+              rank, world, n, steps, total / steps, issued / steps, nv, (unsigned long long)offset, (unsigned long long)totalVisible, c.pairs);
   std::printf("all checks passed\n");
   orc_culling_state_free(cs); orc_world_free(ow);
   scTickCommDestroy(ctx);

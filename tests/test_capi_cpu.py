@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/sc_tick.h but not exported"
         assert n in capi.SYMBOLS, f"{n} declared but not bound in capi.SYMBOLS"
     assert sorted(capi.SYMBOLS) == names          # and nothing is bound that the header does not declare
-    assert lib.scTickGetApiVersion() == 6
+    assert lib.scTickGetApiVersion() == 7
 
 
 def test_null_tolerance_and_no_cpu_fallback():

@@ -30,3 +30,7 @@ def test_two_rank_rehearsal_line_has_pair_gate_and_per_rank_block():
     pr = d["per_rank"]
     assert [x["rank"] for x in pr] == [0, 1] and all(x["border_lost"] == 0 for x in pr)
     assert d["value"] > 0 and d["config"]["entities_total"] == 2 * 8 * 16 * 32
+    # result assembly: the ranks' visible lists at their offsets are the concatenation of the ranks' oracle lists
+    va = d["visible_assembly"]
+    assert va["totals_agree"] and va["every_slot_filled"] and va["equals_oracle_concatenation"]
+    assert va["visible_total"] == sum(x["visible"] for x in pr) and va["offsets"] == [0, pr[0]["visible"]]

@@ -472,3 +472,48 @@ def test_records_of_boxes_that_did_not_move_stay_in_their_slots(oracle, monkeypa
         seen += total
     assert seen > 1000
     t.close(); ow.close()
+
+
+def test_a_host_that_works_between_the_halves_of_a_split_tick_does_not_change_its_pairs(oracle, monkeypatch):
+    """include/sc_tick.h offers the split flow -- scTickRun(.. | SC_TICK_SPLIT_PAIRS), the caller's own exchange, scTickRunPairs -- to
+    hosts that "interleave other work".  With lazy records the pair half would rebuild unwritten bins from the world matrices,
+    bounds and layers as they stand when it RUNS; a host that uploads matrices or changes bounds in between would then change
+    tick t's pair set.  So the library writes every record when the host owns
+    the gap (the pair half reads tick t's snapshot only): dynamic bodies jump into prop-only sectors every tick, the host
+    scrambles the world between the halves, and the pairs are still the oracle's pairs of tick t."""
+    monkeypatch.setenv("SC_TICK_HOME_PERIOD", "1000")
+    w, dyn = _static_city_with_wanderers(6000, 50, seed=23)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    t = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 18)
+    rng = np.random.default_rng(29)
+    flags = FLAGS | capi.SPLIT_PAIRS
+    seen = 0
+    for k in range(8):
+        pos = t.positions()
+        if k:
+            pos[dyn] = rng.uniform(-430, 430, (len(dyn), 3)).astype(np.float32) * np.float32([1, 0.01, 1])
+            ow.set_local_positions(np.arange(w.n, dtype=np.uint32), pos)
+            t.upload_positions(0, pos)
+        ow.transform_system(); t.run(flags)
+        mn, mx = ow.world_aabbs()
+        gmn, gmx = t.world_aabbs()
+        assert np.array_equal(gmn, mn) and np.array_equal(gmx, mx)
+        want = oracle.broadphase_grid(mn, mx, w.group, w.mask, 64.0)
+        assert not t.bin_stats()["lazy_last_tick"]                      # the host owns the gap: nothing is left to a rebuild
+        # ---- the host's "other work" between the halves: none of it belongs to tick t
+        t.sync()
+        m = t.world_matrices()
+        m[:, 12:15] += rng.uniform(-300, 300, (w.n, 3)).astype(np.float32)          # every box somewhere else
+        t.upload_world_matrices(0, m)
+        if k % 2:
+            t.upload_bounds(0, w.bmin * np.float32(3.0), w.bmax * np.float32(3.0), w.has_bounds)
+        t.run_pairs()
+        got, total = t.pairs()
+        assert total == len(want), f"tick {k}: {total} pairs, oracle {len(want)}"
+        assert np.array_equal(sorted_pairs(got), want), f"tick {k}"
+        seen += total
+        # ---- and back: the world as the oracle has it
+        t.upload_bounds(0, w.bmin, w.bmax, w.has_bounds)
+        t.upload_positions(0, pos); t.mark_dirty(0, w.n)
+    assert seen > 100
+    t.close(); ow.close()

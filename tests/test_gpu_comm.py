@@ -92,6 +92,10 @@ def test_rccl_loopback_equals_device_copy_loopback(pipelined, graph):
             ka, kb = keys(a), keys(b)
             assert np.array_equal(ka, kb), f"step {step}: {len(ka)} vs {len(kb)} pairs"
             assert np.array_equal(a.visible(), b.visible())
+            # result assembly: the visible counts all-gathered over the library's own communicator (here: one rank)
+            counts, off, total = a.gather_visible_counts()
+            assert counts.tolist() == [len(a.visible())] and off == 0 and total == len(a.visible())
+            assert tiles.global_visible(a, 0, w.n)[1] == total
             ca, cb = a.counts(), b.counts()
             assert (ca.big_boxes, ca.border_lost, ca.bin_overflow) == (cb.big_boxes, cb.border_lost, cb.bin_overflow)
             assert ca.big_boxes >= 6 and len(ka) > 100

@@ -407,3 +407,104 @@ def test_pipelined_tiles_leave_unwritten_what_nothing_in_the_world_can_meet(orac
     assert np.array_equal(key, wkey), f"{len(np.setdiff1d(wkey, key))} missing, {len(np.setdiff1d(key, wkey))} unexpected of {len(wkey)}"
     assert len(wkey) > 100
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("grid", [(2, 2), (4, 2)])
+def test_global_visible_list_is_the_concatenation_of_the_tiles_lists(oracle, grid):
+    """SURVEY 8e, result assembly (north_star: "bit-exact visibility lists at 1, 2, 4 and 8 GPUs"): with the frustum shared, the
+    tiles' visible lists, each shifted by rank * entities-per-tile and placed at the offset its rank gets from the all-gathered
+    counts, are the WHOLE world's visible list in the reference's order -- the oracle's CullingSystem over the whole pool
+    (sc_world_partition.cpp:1273-1280); tile-major creation is what makes the concatenation the serial compaction's order."""
+    from sc_gameengine_amd.tick import camera_view_proj
+    S = (6, 6)
+    w = sw.generate(S[0] * grid[0], S[1] * grid[1], 15, tiles=grid)
+    w.has_mesh[::7] = 0                                             # some entities are no candidates; some have no bounds (always visible)
+    w.has_bounds[5::11] = 0
+    cam = sw.default_camera(float(S[0] * grid[0]) * 64.0)
+    cam["pos"][2] = np.float32(float(S[1] * grid[1]) * 64.0 / 2)
+    w.camera = cam
+    vp = camera_view_proj(cam)
+    parts, n = split_world(w, grid, S)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    ticks = [WorldTick.from_world(p, broadphase=False) for p in parts]
+    for t in ticks:
+        t.set_view_proj(vp)
+    for step in range(3):
+        if step:
+            ow.nudge_roots_x(1.7)
+            for t in ticks:
+                t.nudge_roots_x(1.7)
+        ow.transform_system()
+        ow.culling_system(view_proj=vp)
+        want = ow.visible().astype(np.uint64)
+        for t in ticks:
+            t.run(capi.XFORM | capi.CULL)
+        lists = [t.visible() for t in ticks]
+        counts = [len(v) for v in lists]
+        whole = np.full(sum(counts), np.uint64(0xFFFFFFFFFFFFFFFF))
+        for r, t in enumerate(ticks):
+            c1, off1, tot1 = t.gather_visible_counts()             # no communicator: the tile reports itself as the world
+            assert (c1.tolist(), off1, tot1) == ([counts[r]], 0, counts[r])
+            off, total = tiles.visible_offsets(counts, r)
+            assert total == len(want)
+            whole[off:off + counts[r]] = lists[r].astype(np.uint64) + np.uint64(r * n)
+        assert np.array_equal(whole, want)
+        assert min(counts) >= 0 and sum(1 for c in counts if c) >= 2 and 50 < len(want) < w.n      # several tiles really contribute
+    for t in ticks:
+        t.close()
+    ow.close()
+
+
+def test_world_layer_vocabulary_is_a_checked_contract(oracle):
+    """scTickSetWorldLayers is what lets a pipelined tile leave bins unwritten for good, so a collider outside the declared words
+    would miss pairs silently.  It is checked instead: (1) uploading or appending layers outside the vocabulary fails, (2) a
+    vocabulary that does not cover what the tile already holds fails, (3) records and big boxes that ARRIVE from a neighbour
+    outside the vocabulary are counted in ScTickCounts::vocabulary_violations."""
+    import torch
+    from sc_gameengine_amd.capi import ScTickError
+    grid, S = (2, 1), (4, 4)
+    w = sw.generate(S[0] * grid[0], S[1] * grid[1], 15, tiles=grid)              # static props only: group 2 / mask 1
+    rng = np.random.default_rng(5)
+    roots = np.flatnonzero((w.parent < 0) & (np.arange(w.n) % 16 != 0))
+    edge = rng.choice(roots, len(roots) // 6, replace=False)                   # props straddling the shared edge: border records both ways
+    w.pos[edge, 0] = (64.0 * S[0] + rng.uniform(-1.0, 1.0, len(edge))).astype(np.float32)
+    parts, n = split_world(w, grid, S)
+    ticks = [WorldTick.from_world(p, broadphase=True, capacity=n + 8) for p in parts]
+    bufs = [tiles.BorderBuffers(t, r, grid, "cuda") for r, t in enumerate(ticks)]
+    a, b = ticks
+    # (2) a vocabulary narrower than the tile's own layers is refused
+    with pytest.raises(ScTickError, match="does not cover"):
+        a.set_world_layers(4, 8)
+    a.set_world_layers(2, 1)
+    # (1) a dynamic body (group 1 / mask all) in a world declared static-only is refused, on upload and on append
+    with pytest.raises(ScTickError, match="vocabulary"):
+        a.upload_layers(3, np.array([1], np.uint32), np.array([0xFFFFFFFF], np.uint32))
+    with pytest.raises(ScTickError, match="vocabulary"):
+        a.append_entities(np.zeros((1, 3), np.float32), np.zeros((1, 3), np.float32), np.ones((1, 3), np.float32),
+                          group=np.array([4], np.uint32), mask=np.array([8], np.uint32))
+    assert a.counts().entities == n                                             # (the refused append left nothing behind)
+    a.upload_layers(3, np.array([2], np.uint32), np.array([1], np.uint32))      # inside the vocabulary: fine
+    # (3) the neighbour never declared anything and carries 4/8 bodies on the shared edge: its border records break tile a's contract
+    k = edge[edge >= n][:5] - n
+    assert len(k) == 5
+    b.upload_layers(int(k[0]), np.array([4], np.uint32), np.array([8], np.uint32))
+    flags = capi.XFORM | capi.BROADPHASE | capi.SPLIT_PAIRS
+    seen = []
+    for step in range(2):
+        for t in ticks:
+            t.run(flags)
+        for t in ticks:
+            t.sync()
+        for r, bb in enumerate(bufs):
+            for d, nb in tiles.neighbours(r, grid).items():
+                bufs[nb].recv[7 - d].copy_(bb.send[d])
+        torch.cuda.synchronize()
+        for t in ticks:
+            t.run_pairs()
+        seen.append((a.counts().vocabulary_violations, b.counts().vocabulary_violations))
+        if step == 0:
+            b.upload_layers(int(k[0]), np.array([2], np.uint32), np.array([1], np.uint32))      # the neighbour mends its ways
+    assert seen[0][0] >= 1 and seen[0][1] == 0, seen        # counted on the tile whose contract was broken; b declared nothing
+    assert seen[1] == (0, 0), seen                          # per tick: gone once the record is inside the vocabulary again
+    for t in ticks:
+        t.close()

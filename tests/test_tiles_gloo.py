@@ -117,3 +117,66 @@ def test_communicator_id_rendezvous_over_gloo():
 
 def test_rendezvous_without_a_process_group_is_local():
     assert tiles.rendezvous_unique_id(0, lambda: bytes(128)) == bytes(128)
+
+
+class _FakeTick:
+    """what tiles.global_visible needs of a context, without a GPU: a visible list and no communicator"""
+    def __init__(self, vis):
+        self._vis = np.asarray(vis, np.uint32)
+
+    def visible(self):
+        return self._vis
+
+    def comm_info(self):
+        return {"has_communicator": 0, "world_size": 0}
+
+
+def _visible_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_per = 1000
+        rng = np.random.default_rng(7)                        # every rank draws the same world: rank r's tile sees lists[r]
+        lists = [np.sort(rng.choice(n_per, size=int(rng.integers(0, 40)), replace=False)).astype(np.uint32) for _ in range(world)]
+        off, total, ids = tiles.global_visible(_FakeTick(lists[rank]), rank, n_per)
+        want = np.concatenate([lists[r].astype(np.uint64) + r * n_per for r in range(world)])
+        assert total == len(want) and off == sum(len(lists[r]) for r in range(rank))
+        assert np.array_equal(want[off:off + len(ids)], ids)          # the rank's slice sits at its offset of the whole-world list
+        # rank 0 assembles the whole list from the slices, each placed at its own offset
+        box = [None] * world
+        dist.all_gather_object(box, (off, ids.tolist()))
+        if rank == 0:
+            whole = np.zeros(total, np.uint64)
+            for o, part in box:
+                whole[o:o + len(part)] = part
+            assert np.array_equal(whole, want)
+        out.put((rank, "ok"))
+    except Exception as e:                                   # noqa: BLE001
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_global_visible_list_assembly_over_gloo(world):
+    """SURVEY 8e, result assembly: all-gather of the ranks' visible counts -> offsets -> every rank's slice, with global dense
+    indices, at its own offset of the whole-world list (tile-major order = the reference's compaction order)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_visible_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_visible_offsets():
+    assert tiles.visible_offsets([5, 0, 7, 2], 0) == (0, 14)
+    assert tiles.visible_offsets([5, 0, 7, 2], 2) == (5, 14)
+    assert tiles.visible_offsets([5, 0, 7, 2], 3) == (12, 14)

@@ -4,8 +4,8 @@
 A default bench.py run launches the tick in four passes -- warm-up, the timed region (every n-th step also takes dispatch
 timestamps), the every-launch-timed pass, the end-to-end pass (draw emission + overlapped read-back) -- and rocprofv3's
 --stats summary blends them.  This splits the trace by launch index of the fused kernel (the counts are known from the
-command line) and prints each kernel's average duration per pass, so that 168 B x N / (timed-region average) can be checked
-against the line's `roofline.frac` from tracked files alone.
+command line) and prints each kernel's average duration per pass, so that (the line's own bytes per entity) x N / (timed-region average)
+can be checked against the line's `roofline.frac` from tracked files alone (--bench-line: the figure is read from the line).
     python tools/trace_passes.py <trace dir> --warmup W --steps K [--every 64] > profiles/r03/config3_kernel_passes.json"""
 import argparse
 import csv
@@ -19,10 +19,17 @@ ap.add_argument("dir")
 ap.add_argument("--warmup", type=int, required=True)
 ap.add_argument("--steps", type=int, required=True)
 ap.add_argument("--every", type=int, default=None, help="launches of the every-launch pass (default min(steps, 64))")
-ap.add_argument("--bytes-per-entity", type=float, default=168.0)
+ap.add_argument("--bytes-per-entity", type=float, default=None, help="algorithmic bytes per entity of the fused kernel; default: roofline.bytes_per_entity of --bench-line")
+ap.add_argument("--bench-line", default=None, help="the JSON line bench.py printed in the traced run (or a file holding it): the figure the roofline is priced at comes from there")
 ap.add_argument("--entities", type=int, default=1048576)
 args = ap.parse_args()
 every = min(args.steps, 64) if args.every is None else args.every
+if args.bytes_per_entity is None:
+    if not args.bench_line:
+        ap.error("give --bench-line (the run's own line: its roofline.bytes_per_entity is what the kernel is priced at) or --bytes-per-entity")
+    text = open(args.bench_line).read() if os.path.exists(args.bench_line) else args.bench_line
+    line = next(ln for ln in reversed(text.splitlines()) if ln.startswith("{"))
+    args.bytes_per_entity = float(json.loads(line)["roofline"]["bytes_per_entity"])
 
 rows = []
 for f in glob.glob(os.path.join(args.dir, "**", "*kernel_trace.csv"), recursive=True):
