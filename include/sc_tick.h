@@ -365,10 +365,22 @@ int scTickReadTrafficAgents(ScTickContext* ctx, uint32_t first, uint32_t count, 
  * is absent; an agent's own box never answers).  Order in a frame: rays from the poses of frame t against the boxes of frame
  * t, then the step to frame t+1 -- what the reference does (the ray sees Bullet's world as the last physics step left it).
  * On a tiled world the rays see the tile's own boxes only (they are cast before the border exchange); the brake of a run
- * without SC_TICK_BROADPHASE is the last one computed.  One pair of values per context (the reference's per-entity
- * TrafficSensors component falls back to exactly these defaults).  Needs agents (scTickUploadTrafficAgents) and a tile rectangle. */
+ * without SC_TICK_BROADPHASE is the last one computed.  front_ray_length / safe_distance here are every agent's values until
+ * scTickUploadTrafficSensors gives some agents their own (the reference's per-entity TrafficSensors component falls back to exactly
+ * these defaults).  Needs agents (scTickUploadTrafficAgents) and a tile rectangle. */
 int scTickSetTrafficSensors(ScTickContext* ctx, int enable, float front_ray_length, float safe_distance);
 int scTickReadTrafficBrakes(ScTickContext* ctx, uint32_t first, uint32_t count, float* obstacle_brake);
+/* Per-agent TrafficSensors (src/engine/traffic/sc_traffic_common.h:46-53; the AI reads frontRayLength / safeDistance of the agent's own
+ * component, sc_traffic_ai.cpp:306-308): scTickSetTrafficSensors gives every entity the two defaults, scTickUploadTrafficSensors
+ * overrides them for a range (they travel with their entity through scTickRemoveEntities).  What the AI leaves in the component
+ * (:339-345, read by the debug state :420-421, :479-480) comes back through scTickReadTrafficSensors: lastHitDistance -- the hit's
+ * distance, or the agent's ray length without a hit -- and lastHitType -- 0 None, 2 Vehicle, 3 World; own spec like the rays:
+ * Vehicle = the hit entity is a vehicle by its mover kind (a traffic agent, or a kind-1 mover: what carries a VehicleComponent,
+ * :327); a box that arrived from a neighbour tile has no mover kind on this tile and counts as a vehicle when its group has the
+ * dynamic bit; Self (1) does not occur because an agent's own box never answers.  Values of agents that are not OnRails, or
+ * before the first ray tick, are 0. */
+int scTickUploadTrafficSensors(ScTickContext* ctx, uint32_t first, uint32_t count, const float* front_ray_length, const float* safe_distance);
+int scTickReadTrafficSensors(ScTickContext* ctx, uint32_t first, uint32_t count, float* last_hit_distance, uint8_t* last_hit_type);
 /* TrafficDebugState::speedMultiplier (sc_traffic_ai.cpp:297-298); 1 by default */
 int scTickSetTrafficSpeedMultiplier(ScTickContext* ctx, float multiplier);
 /* TrafficLODSystem's tier selection (src/engine/traffic/sc_traffic_lod.cpp:269-274 threshold repair, :303-307 xz distance to

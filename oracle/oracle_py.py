@@ -129,6 +129,7 @@ def lib():
     L.orc_traffic_ai_onrails.argtypes = [vp, vp, U8P, U32P, F32P, F32P, U8P, F32P, C.c_float, C.c_float]
     L.orc_traffic_ai_onrails_braked.argtypes = [vp, vp, U8P, U32P, F32P, F32P, U8P, F32P, F32P, C.c_float, C.c_float]
     L.orc_traffic_front_ray_brakes.argtypes = [vp, F32P, F32P, U32P, U32P, U8P, U8P, C.c_float, C.c_float, F32P]
+    L.orc_traffic_front_ray_sensors.argtypes = [vp, F32P, F32P, U32P, U32P, U8P, U8P, U8P, F32P, F32P, F32P, F32P, U8P]
     L.orc_lanes_query_nearest.argtypes = [vp, F32P, U32P, F32P]
     L.orc_lanes_query_nearest.restype = C.c_int
     L.orc_traffic_lod_despawns.argtypes = [vp, U8P, U8P, F32P, C.c_uint32, U32P]
@@ -425,6 +426,21 @@ class OracleWorld:
         self.L.orc_traffic_front_ray_brakes(self.w, _f(a), _f(b), _u(g), _u(m), ia.ctypes.data_as(U8P), md.ctypes.data_as(U8P),
                                             float(ray_len), float(safe), _f(out))
         return out
+
+    def traffic_front_ray_sensors(self, mn, mx, group, mask, is_agent, mode, is_vehicle, ray_len=None, safe=None):
+        """(obstacleBrake, lastHitDistance, lastHitType) of every OnRails agent with per-agent TrafficSensors values
+        (arrays per entity, None = the defaults 20 m / 10 m; sc_traffic_common.h:46-53, sc_traffic_ai.cpp:306-345, own spec);
+        is_vehicle: the entities that carry a VehicleComponent (hit kind Vehicle, else World)"""
+        ia, md = np.ascontiguousarray(is_agent, np.uint8), np.ascontiguousarray(mode, np.uint8)
+        iv = np.ascontiguousarray(is_vehicle, np.uint8)
+        a, b = _c32(mn), _c32(mx)
+        g, m = np.ascontiguousarray(group, np.uint32), np.ascontiguousarray(mask, np.uint32)
+        rl = None if ray_len is None else _c32(ray_len)
+        sf = None if safe is None else _c32(safe)
+        brake, dist, typ = np.zeros(len(ia), np.float32), np.zeros(len(ia), np.float32), np.zeros(len(ia), np.uint8)
+        self.L.orc_traffic_front_ray_sensors(self.w, _f(a), _f(b), _u(g), _u(m), ia.ctypes.data_as(U8P), md.ctypes.data_as(U8P), iv.ctypes.data_as(U8P),
+                                             None if rl is None else _f(rl), None if sf is None else _f(sf), _f(brake), _f(dist), typ.ctypes.data_as(U8P))
+        return brake, dist, typ
 
     def traffic_ai_onrails_braked(self, lanes, is_agent, lane_id, lane_s, target_speed, mode, look_ahead, brake, dt, speed_multiplier=1.0):
         """as traffic_ai_onrails, with the agents' obstacle brakes (None = 0); agents without a lane take the nearest one first"""

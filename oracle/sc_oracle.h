@@ -210,6 +210,9 @@ int      orc_lanes_query_nearest(const OrcLaneGraph* g, const float pos[3], uint
 /* one agent's front ray against the world AABBs (own spec) and the brake it yields, sc_traffic_ai.cpp:300-345 */
 float    orc_traffic_front_ray_brake(uint32_t n, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
                                      uint32_t self, const float pos[3], float sinYaw, float cosYaw, float rayLen, float safe);
+void     orc_traffic_front_ray_sensors(OrcWorld* w, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
+                                       const uint8_t* isAgent, const uint8_t* mode, const uint8_t* isVehicle, const float* rayLen, const float* safe,
+                                       float* brakeOut, float* hitDistOut, uint8_t* hitTypeOut);
 void     orc_traffic_front_ray_brakes(OrcWorld* w, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
                                       const uint8_t* isAgent, const uint8_t* mode, float rayLen, float safe, float* brakeOut);
 /* mode / desired: 0 Physics, 1 Kinematic, 2 OnRails (sc_traffic_common.h:11-16); counts[3] after the caps (sc_traffic_lod.cpp:323-417) */

@@ -269,18 +269,18 @@ static float clampf(float v, float lo, float hi)          /* std::max(lo, std::m
  * (host libm), origin 1.7 m ahead and 0.6 m up, PhysicsWorld::raycast(origin, forward, rayLen, 1u).  The agent's own box
  * never answers (Bullet does not report a convex shape the ray starts inside, and the reference ignores a self hit anyway,
  * :322-325, :336).  brake = clamp01((safe - d) / safe) for a hit closer than `safe` (:336-339). */
-float orc_traffic_front_ray_brake(uint32_t n, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
-                                  uint32_t self, const float pos[3], float sinYaw, float cosYaw, float rayLen, float safe)
+/* the ray itself: 1 = something was hit; *tOut the entry distance, *idxOut the box (lowest index among equal distances) */
+static int front_ray_cast(uint32_t n, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
+                          uint32_t self, const float pos[3], float sinYaw, float cosYaw, float rayLen, float* tOut, uint32_t* idxOut)
 {
   float forward[3] = { sinYaw, 0.0f, cosYaw };
   normalize3(forward);
   const float origin[3] = { pos[0] + forward[0] * 1.7f, pos[1] + 0.6f, pos[2] + forward[2] * 1.7f };
-  /* one ray through orc_raycast_boxes' arithmetic, the agent's own box left out */
   const float lenSq = forward[0] * forward[0] + forward[1] * forward[1] + forward[2] * forward[2];
-  if (!(lenSq > 1e-6f) || !(rayLen >= 0.0f)) return 0.0f;
+  if (!(lenSq > 1e-6f) || !(rayLen >= 0.0f)) return 0;
   const float invLen = 1.0f / sqrtf(lenSq);
   const float dir[3] = { forward[0] * invLen, forward[1] * invLen, forward[2] * invLen };
-  float best = INFINITY; int hit = 0;
+  float best = INFINITY; int hit = 0; uint32_t who = 0;
   for (uint32_t i = 0; i < n; ++i) {
     if (i == self) continue;
     if (!(min3[3 * i] <= max3[3 * i])) continue;
@@ -298,10 +298,46 @@ float orc_traffic_front_ray_brake(uint32_t n, const float* min3, const float* ma
         if (tmin > tmax) ok = 0;
       }
     }
-    if (ok && tmin < best) { best = tmin; hit = 1; }
+    if (ok && tmin < best) { best = tmin; hit = 1; who = i; }
   }
-  if (hit && safe > 1e-3f && best < safe) return clampf((safe - best) / safe, 0.0f, 1.0f);
+  *tOut = best; *idxOut = who;
+  return hit;
+}
+
+float orc_traffic_front_ray_brake(uint32_t n, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
+                                  uint32_t self, const float pos[3], float sinYaw, float cosYaw, float rayLen, float safe)
+{
+  float t; uint32_t who;
+  if (front_ray_cast(n, min3, max3, group, mask, self, pos, sinYaw, cosYaw, rayLen, &t, &who) && safe > 1e-3f && t < safe)
+    return clampf((safe - t) / safe, 0.0f, 1.0f);
   return 0.0f;
+}
+
+/* Per-agent TrafficSensors (sc_traffic_common.h:46-53) and what the AI leaves in them (sc_traffic_ai.cpp:306-308, :317-345): every
+ * OnRails agent casts with ITS frontRayLength and brakes by ITS safeDistance (rayLen / safe per entity; NULL = the defaults 20 / 10
+ * of :307-308), and lastHitDistance / lastHitType are written back: the hit's distance and Vehicle (2) or World (3), or the ray's
+ * length and None (0) without a hit.  "The hit entity carries a VehicleComponent or VehicleRuntime" (:327) is isVehicle[] here
+ * (traffic agents and SynthWorld's vehicle movers); Self (1) cannot occur -- an agent's own box never answers (own spec, as the
+ * rays themselves: Bullet is absent). */
+void orc_traffic_front_ray_sensors(OrcWorld* w, const float* min3, const float* max3, const uint32_t* group, const uint32_t* mask,
+                                   const uint8_t* isAgent, const uint8_t* mode, const uint8_t* isVehicle, const float* rayLen, const float* safe,
+                                   float* brakeOut, float* hitDistOut, uint8_t* hitTypeOut)
+{
+  const OrcTransform* d = orc_transform_dense_data(w);
+  const uint32_t n = orc_transform_count(w);
+  for (uint32_t i = 0; i < n; ++i) {
+    brakeOut[i] = 0.0f; hitDistOut[i] = 0.0f; hitTypeOut[i] = 0u;
+    if (!isAgent[i] || mode[i] != 2u) continue;
+    const float len = rayLen ? rayLen[i] : 20.0f, sf = safe ? safe[i] : 10.0f;
+    const float sy = sinf(d[i].localRot[1]), cy = cosf(d[i].localRot[1]);
+    float t; uint32_t who;
+    hitDistOut[i] = len;
+    if (front_ray_cast(n, min3, max3, group, mask, i, d[i].localPos, sy, cy, len, &t, &who)) {
+      hitDistOut[i] = t;
+      hitTypeOut[i] = isVehicle[who] ? 2u : 3u;
+      if (sf > 1e-3f && t < sf) brakeOut[i] = clampf((sf - t) / sf, 0.0f, 1.0f);
+    }
+  }
 }
 
 /* Every OnRails agent's brake for one step (the rays of sc_traffic_ai.cpp:300-345 against the world as it stands): sin / cos of

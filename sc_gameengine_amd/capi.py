@@ -146,6 +146,8 @@ SYMBOLS = {
     "scTickSetTrafficSpeedMultiplier": (C.c_int, [_CTX, C.c_float]),
     "scTickSetTrafficSensors": (C.c_int, [_CTX, C.c_int, C.c_float, C.c_float]),
     "scTickReadTrafficBrakes": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P]),
+    "scTickUploadTrafficSensors": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P, F32P]),
+    "scTickReadTrafficSensors": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, F32P, U8P]),
     "scTickSelectTrafficTiers": (C.c_int, [_CTX, F32P, C.POINTER(TierParams), C.POINTER(TierCounts)]),
     "scTickSelectTrafficDespawns": (C.c_int, [_CTX, F32P, C.c_uint32, U32P, C.c_uint32, U32P]),
     "scTickSetViewProj": (C.c_int, [_CTX, F32P]),

@@ -525,7 +525,7 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     }
   }
   // the traffic AI's obstacle rays (scTickSetTrafficSensors): against this tick's boxes, before the frame producer moves the agents
-  if ((flags & SC_TICK_BROADPHASE) && c->sensors && ds.aLane) launchAgentFrontRays(ds, p, c->sensorRay, c->sensorSafe, c->stream);
+  if ((flags & SC_TICK_BROADPHASE) && c->sensors && ds.aLane) launchAgentFrontRays(ds, p, c->stream);
   if ((flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_DENSE_AABBS)) launchDenseAabbs(ds, c->n, c->stream);   // read-back aid, off the hot path
   const bool needCompact = (flags & (SC_TICK_XFORM | SC_TICK_CULL)) != 0;
   const bool pairsNow = (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS);
@@ -2076,14 +2076,41 @@ int scTickSetTrafficSensors(ScTickContext* c, int enable, float frontRayLength, 
     if (!c->d.aLane) return fail(c, "no traffic agents uploaded");
     if (!c->sectors) return fail(c, "the obstacle rays read the broadphase bins: the context has no tile rectangle");
     if (!(frontRayLength >= 0.0f) || !(safeDistance >= 0.0f)) return fail(c, "ray length and safe distance must be >= 0");
-    if (!c->d.aBrake && (!dalloc(c, c->d.aBrake, c->cap) || !dalloc(c, c->d.agentList, c->cap, false) || !dalloc(c, c->d.agentCount, 4))) return 0;
+    if (!c->d.aBrake && (!dalloc(c, c->d.aBrake, c->cap) || !dalloc(c, c->d.agentList, c->cap, false) || !dalloc(c, c->d.agentCount, 4) ||
+                         !dalloc(c, c->d.aRayLen, c->cap) || !dalloc(c, c->d.aSafe, c->cap) || !dalloc(c, c->d.aHitDist, c->cap) || !dalloc(c, c->d.aHitType, c->cap))) return 0;
     c->sensorRay = frontRayLength; c->sensorSafe = safeDistance;
+    launchFillSensors(c->d, 0, c->cap, frontRayLength, safeDistance, c->stream);        // every agent's TrafficSensors = these defaults until scTickUploadTrafficSensors says otherwise
+    if (!sync(c)) return 0;
   } else if (c->d.aBrake) {
     HIP_OK(c, hipMemsetAsync(c->d.aBrake, 0, (size_t)c->cap * sizeof(float), c->stream));      // no sensors: brake 0 from here on
     if (!sync(c)) return 0;
   }
   c->sensors = enable != 0;
   dropGraph(c); dropPairGraph(c); c->topoEpoch++;
+  return 1;
+}
+
+int scTickUploadTrafficSensors(ScTickContext* c, uint32_t first, uint32_t count, const float* frontRayLength, const float* safeDistance)
+{
+  if (!c || !frontRayLength || !safeDistance) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!c->d.aRayLen) return fail(c, "scTickSetTrafficSensors first");
+  for (uint32_t i = 0; i < count; ++i)
+    if (!(frontRayLength[i] >= 0.0f) || !(safeDistance[i] >= 0.0f)) return fail(c, "ray length and safe distance must be >= 0");
+  if (!count) return 1;
+  return h2d(c, c->d.aRayLen + first, frontRayLength, (size_t)count * 4u) && h2d(c, c->d.aSafe + first, safeDistance, (size_t)count * 4u) && sync(c) ? 1 : 0;
+}
+
+int scTickReadTrafficSensors(ScTickContext* c, uint32_t first, uint32_t count, float* lastHitDistance, uint8_t* lastHitType)
+{
+  if (!c || !lastHitDistance || !lastHitType) return c ? fail(c, "null argument") : 0;
+  if (!bind(c) || !rangeOk(c, first, count)) return 0;
+  if (!c->d.aHitDist) return fail(c, "scTickSetTrafficSensors first");
+  if (!count) return 1;
+  if (!joinPairs(c)) return 0;                            // (on a tiled world the rays are cast in the pair half)
+  std::vector<uint32_t> typ(count);
+  if (!d2h(c, lastHitDistance, c->d.aHitDist + first, (size_t)count * 4u) || !d2h(c, typ.data(), c->d.aHitType + first, (size_t)count * 4u) || !sync(c)) return 0;
+  for (uint32_t i = 0; i < count; ++i) lastHitType[i] = (uint8_t)typ[i];
   return 1;
 }
 

@@ -135,6 +135,9 @@ struct DeviceState {
   LaneGraphDev lanes;
   uint32_t* aLane; float* aS; float* aSpeed; uint32_t* aMode; float* aLook; uint32_t* aDesired;
   float* aBrake;               // obstacleBrake per agent from its front ray (sc_traffic_ai.cpp:300-345); nullptr = no sensors: brake 0
+  // per-agent TrafficSensors (sc_traffic_common.h:46-53): frontRayLength / safeDistance per entity, and what the AI leaves in them (lastHitDistance,
+  // lastHitType: 0 none, 2 vehicle, 3 world); allocated with aBrake
+  float* aRayLen; float* aSafe; float* aHitDist; uint32_t* aHitType;
   uint32_t* agentList;         // dense indices of the OnRails agents, rebuilt every tick that casts their rays
   uint32_t* agentCount;
   uint32_t* tierCounts;        // [0..2] desired tiers, [3] entries in tierNear
@@ -260,7 +263,8 @@ struct RayQueryState {
   uint32_t count;
 };
 void launchRayQueries(const DeviceState& d, const TickParams& p, const RayQueryState& q, hipStream_t s);
-void launchAgentFrontRays(const DeviceState& d, const TickParams& p, float rayLen, float safe, hipStream_t s);
+void launchAgentFrontRays(const DeviceState& d, const TickParams& p, hipStream_t s);
+void launchFillSensors(const DeviceState& d, uint32_t first, uint32_t count, float rayLen, float safe, hipStream_t s);
 constexpr uint32_t kMaxOccupancyQueries = 256;
 void launchOccupancy(const DeviceState& d, uint32_t n, const float4* q, uint32_t count, uint32_t* blocked, hipStream_t s);
 

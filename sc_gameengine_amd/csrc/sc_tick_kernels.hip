@@ -2375,7 +2375,7 @@ __global__ __launch_bounds__(kTile) void k_gather_rows(const DeviceState d, cons
 // Swap-remove relocations (ComponentPool::remove, sc_ecs.h:240-262, applied to every per-entity array at
 // once): entity src[k] moves to slot dst[k].  The host guarantees every src lies at or beyond the new
 // entity count and every dst below it, so no slot is both read and written.  One thread per (move, array).
-constexpr uint32_t kMoveSlots = 40;     // 22 streams, 3 matrix rows, the dirty bit, 7 mover arrays, 5 traffic-agent arrays (+ idle)
+constexpr uint32_t kMoveSlots = 40;     // 22 streams, 3 matrix rows, the dirty bit, 7 mover arrays, 5 traffic-agent arrays, 2 sensor arrays
 __global__ __launch_bounds__(kTile) void k_move_entities(const DeviceState d, const uint32_t* __restrict__ src,
                                                          const uint32_t* __restrict__ dst, uint32_t moves)
 {
@@ -2402,6 +2402,9 @@ __global__ __launch_bounds__(kTile) void k_move_entities(const DeviceState d, co
   } else if (d.aLane && slot >= kStreamCount + 11u && slot < kStreamCount + 16u) {
     uint32_t* arrays[5] = { d.aLane, reinterpret_cast<uint32_t*>(d.aS), reinterpret_cast<uint32_t*>(d.aSpeed), d.aMode, reinterpret_cast<uint32_t*>(d.aLook) };
     uint32_t* a = arrays[slot - kStreamCount - 11u];
+    a[to] = a[from];
+  } else if (d.aRayLen && slot >= kStreamCount + 16u && slot < kStreamCount + 18u) {      // per-agent TrafficSensors values travel with their entity
+    float* a = slot == kStreamCount + 16u ? d.aRayLen : d.aSafe;
     a[to] = a[from];
   }
 }

@@ -174,7 +174,18 @@ __global__ __launch_bounds__(kTile) void k_list_onrails_agents(const DeviceState
   if (agent) d.agentList[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
 }
 
-__global__ __launch_bounds__(kTile) void k_agent_front_rays(const DeviceState d, const TickParams p, float rayLen, float safe)
+__global__ __launch_bounds__(kTile) void k_fill_sensors(const DeviceState d, uint32_t first, uint32_t count, float rayLen, float safe)
+{
+  const uint32_t t = blockIdx.x * kTile + threadIdx.x;
+  if (t < count) { d.aRayLen[first + t] = rayLen; d.aSafe[first + t] = safe; }
+}
+
+// (per-agent TrafficSensors: every agent casts with its own frontRayLength and brakes by its own safeDistance, :306-308; the
+//  hit's distance and kind are left for the host as lastHitDistance / lastHitType, :339-345 -- Vehicle when the hit entity is a
+//  vehicle by its mover kind (a traffic agent or a SynthWorld vehicle: what carries a VehicleComponent, :327), World otherwise;
+//  a box that arrived from a neighbour tile has no mover kind here: Vehicle when its group has the dynamic bit; without a hit the
+//  ray's length and None)
+__global__ __launch_bounds__(kTile) void k_agent_front_rays(const DeviceState d, const TickParams p)
 {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t count = *d.agentCount;
@@ -185,6 +196,7 @@ __global__ __launch_bounds__(kTile) void k_agent_front_rays(const DeviceState d,
     const float len = sqrtf(forward[0] * forward[0] + forward[1] * forward[1] + forward[2] * forward[2]);      // normalize3, :38-48
     if (len > 1e-6f) { const float inv = 1.0f / len; forward[0] *= inv; forward[1] *= inv; forward[2] *= inv; }
     const float origin[3] = { d.px[i] + forward[0] * 1.7f, d.py[i] + 0.6f, d.pz[i] + forward[2] * 1.7f };       // :311-315
+    const float rayLen = d.aRayLen[i], safe = d.aSafe[i];            // :306-308
     const WaveRay w = castRayWave(d, p, origin, forward, rayLen, 1u, i | p.rankBits);
     float brake = 0.0f;
     if (w.hit && safe > 1e-3f && w.t < safe) {
@@ -192,7 +204,17 @@ __global__ __launch_bounds__(kTile) void k_agent_front_rays(const DeviceState d,
       const float m = (1.0f < v) ? 1.0f : v;
       brake = (0.0f < m) ? m : 0.0f;
     }
-    if (lane == 0) d.aBrake[i] = brake;
+    if (lane == 0) {
+      d.aBrake[i] = brake;
+      d.aHitDist[i] = w.hit ? w.t : rayLen;                           // :319-322, :341-345
+      uint32_t kind = 0u;
+      if (w.hit) {
+        const bool own = (w.id & 0x7F000000u) == p.rankBits;
+        const uint32_t mk = own ? d.moverKind[w.id & 0x00FFFFFFu] : 0u;
+        kind = own ? ((mk == 1u || mk == kMoverTraffic) ? 2u : 3u) : ((w.layer & 1u) ? 2u : 3u);
+      }
+      d.aHitType[i] = kind;
+    }
   }
 }
 
@@ -227,13 +249,19 @@ void launchOccupancy(const DeviceState& d, uint32_t n, const float4* q, uint32_t
   hipLaunchKernelGGL(k_occupancy, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, q, count, blocked);
 }
 
-void launchAgentFrontRays(const DeviceState& d, const TickParams& p, float rayLen, float safe, hipStream_t s)
+void launchFillSensors(const DeviceState& d, uint32_t first, uint32_t count, float rayLen, float safe, hipStream_t s)
+{
+  if (!count || !d.aRayLen) return;
+  hipLaunchKernelGGL(k_fill_sensors, dim3((count + kTile - 1) / kTile), dim3(kTile), 0, s, d, first, count, rayLen, safe);
+}
+
+void launchAgentFrontRays(const DeviceState& d, const TickParams& p, hipStream_t s)
 {
   if (!p.n || !d.aLane || !d.aBrake) return;
   hipMemsetAsync(d.agentCount, 0, sizeof(uint32_t), s);
   hipLaunchKernelGGL(k_list_onrails_agents, dim3((p.n + kTile - 1) / kTile), dim3(kTile), 0, s, d, p.n);
   const uint32_t blocks = std::min((p.n + 3u) / 4u, 8192u);          // (a wave per agent, wave-strided over the list the kernel above wrote)
-  hipLaunchKernelGGL(k_agent_front_rays, dim3(std::max(blocks, 1u)), dim3(kTile), 0, s, d, p, rayLen, safe);
+  hipLaunchKernelGGL(k_agent_front_rays, dim3(std::max(blocks, 1u)), dim3(kTile), 0, s, d, p);
 }
 
 void launchRayQueries(const DeviceState& d, const TickParams& p, const RayQueryState& q, hipStream_t s)

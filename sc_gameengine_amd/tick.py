@@ -318,6 +318,18 @@ class WorldTick:
         """the traffic AI's obstacle ray per OnRails agent, cast in every run with BROADPHASE; its brake scales the next on-rails step"""
         self._ok(self.lib.scTickSetTrafficSensors(self.ctx, 1 if on else 0, float(front_ray_length), float(safe_distance)), "scTickSetTrafficSensors")
 
+    def upload_traffic_sensors(self, first, front_ray_length, safe_distance):
+        """per-agent TrafficSensors::frontRayLength / safeDistance for the entities first .. first + len - 1"""
+        rl, sf = _c32(front_ray_length).reshape(-1), _c32(safe_distance).reshape(-1)
+        assert len(rl) == len(sf)
+        self._ok(self.lib.scTickUploadTrafficSensors(self.ctx, first, len(rl), _f(rl), _f(sf)), "scTickUploadTrafficSensors")
+
+    def traffic_sensors(self):
+        """(lastHitDistance, lastHitType) per entity as the last ray tick left them (0 none, 2 vehicle, 3 world)"""
+        dist, typ = np.zeros(self.n, np.float32), np.zeros(self.n, np.uint8)
+        self._ok(self.lib.scTickReadTrafficSensors(self.ctx, 0, self.n, _f(dist), typ.ctypes.data_as(capi.U8P)), "scTickReadTrafficSensors")
+        return dist, typ
+
     def traffic_brakes(self):
         out = np.zeros(self.n, np.float32)
         self._ok(self.lib.scTickReadTrafficBrakes(self.ctx, 0, self.n, _f(out)), "scTickReadTrafficBrakes")

@@ -256,3 +256,47 @@ def test_total_cap_picks_the_farthest_onrails_first_then_kinematic_then_physics(
             tiers = st["mode"][got]
             assert (np.diff((2 - tiers.astype(np.int32))) >= 0).all()      # OnRails (2) block, then Kinematic (1), then Physics (0)
     t.close(); ow.close(); ol.close()
+
+
+def test_per_agent_traffic_sensors_and_what_the_ai_leaves_in_them_40_ticks(oracle):
+    """TrafficSensors is a per-entity component (sc_traffic_common.h:46-53): the AI casts each agent's ray with ITS frontRayLength,
+    brakes by ITS safeDistance (sc_traffic_ai.cpp:306-308), and writes lastHitDistance / lastHitType back (:339-345).  Here a third of
+    the agents see 35 m and keep 18 m, a third 8 m and 3 m, the rest the defaults.  The rays meet vehicles (Vehicle) and
+    pedestrians (dynamic bodies that are no vehicles: World).  Brakes, hit distances and hit kinds as bit patterns against the
+    oracle on every checked tick."""
+    w = laned_world(14, 12, seed=33)
+    a = w.is_agent.astype(bool)
+    w.scale[a, 1] = np.float32(2.0)
+    is_vehicle = (a | (w.mover_kind == 1)).astype(np.uint8)
+    ow, ol, st = oracle_side(oracle, w)
+    vp = camera_view_proj(w.camera)
+    t = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 20)
+    t.set_view_proj(vp)
+    t.set_traffic_sensors(True)
+    idx = np.flatnonzero(a)
+    ray = np.full(w.n, 20.0, np.float32); safe = np.full(w.n, 10.0, np.float32)
+    ray[idx[0::3]], safe[idx[0::3]] = 35.0, 18.0
+    ray[idx[1::3]], safe[idx[1::3]] = 8.0, 3.0
+    t.upload_traffic_sensors(0, ray, safe)
+    seen_types, differ = set(), 0
+    for k in range(40):
+        ow.transform_system(); ow.culling_system(view_proj=vp)
+        mn, mx = ow.world_aabbs()
+        brake, dist, typ = ow.traffic_front_ray_sensors(mn[:w.n], mx[:w.n], w.group, w.mask, w.is_agent, st["mode"], is_vehicle, ray, safe)
+        default_brake = ow.traffic_front_ray_brakes(mn[:w.n], mx[:w.n], w.group, w.mask, w.is_agent, st["mode"])
+        differ += int((default_brake[a] != brake[a]).sum())
+        ow.traffic_ai_onrails_braked(ol, w.is_agent, st["lane"], st["s"], st["speed"], st["mode"], st["look"], brake, DT)
+        ow.advance_movers(w.mover_kind, st["vel"], w.mover_lo, w.mover_hi, DT)
+        t.run(capi.FULL)
+        if k % 8 == 7 or k < 2:
+            onr = a & (st["mode"] == 2)
+            gd, gt = t.traffic_sensors()
+            assert np.array_equal(bits(t.traffic_brakes()[onr]), bits(brake[onr])), f"tick {k}"
+            assert np.array_equal(bits(gd[onr]), bits(dist[onr])) and np.array_equal(gt[onr], typ[onr]), f"tick {k}"
+            assert (dist[onr][typ[onr] == 0] == ray[onr][typ[onr] == 0]).all()          # no hit: the agent's own ray length
+            seen_types |= set(np.unique(typ[onr]).tolist())
+        t.advance_movers(DT)
+        if k % 8 == 7:
+            assert_agents_equal(t, w, st, ow)
+    assert {0, 2, 3} <= seen_types and differ > 50             # misses, vehicles and pedestrians all occur, and the per-agent values really change brakes
+    t.close(); ow.close(); ol.close()
