@@ -364,7 +364,14 @@ int scTickReadTrafficAgents(ScTickContext* ctx, uint32_t first, uint32_t count, 
  * queries below the candidates are the WORLD AABBS of the broadphase with the collision layers as uploaded (own spec: Bullet
  * is absent; an agent's own box never answers).  Order in a frame: rays from the poses of frame t against the boxes of frame
  * t, then the step to frame t+1 -- what the reference does (the ray sees Bullet's world as the last physics step left it).
- * On a tiled world the rays see the tile's own boxes only (they are cast before the border exchange); the brake of a run
+ * On a TILED world the reference's ray would see the whole world, so with sensors on (switch them on before the border buffers exist:
+ * scTickBindBorderBuffers* / scTickCommInit, on every tile) the border messages carry a halo section -- the sender's core-edge
+ * records, a full bin per cell in fixed slots -- that lands in the receiver's ring bins, and an in-order step (scTickTileStep without
+ * scTickSetPipelined, or the caller-owned split flow) casts the rays in the PAIR half, behind the merge: an agent within a ray's
+ * length (at most one sector) of the tile edge brakes for a vehicle on the neighbour tile, exactly as the whole world's agents would.
+ * With the step fused into the end-of-tick kernel (SC_TICK_PRODUCE_NEXT) the next frame is produced in the tick half, BEFORE these
+ * rays: the brake then acts one tick later -- the reference's own ordering against Bullet's last step.  A PIPELINED tile keeps
+ * the rays in the tick half and sees its own boxes only (its pair half runs under the next tick).  The brake of a run
  * without SC_TICK_BROADPHASE is the last one computed.  front_ray_length / safe_distance here are every agent's values until
  * scTickUploadTrafficSensors gives some agents their own (the reference's per-entity TrafficSensors component falls back to exactly
  * these defaults).  Needs agents (scTickUploadTrafficAgents) and a tile rectangle. */

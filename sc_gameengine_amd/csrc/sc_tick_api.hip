@@ -119,6 +119,7 @@ struct ScTickContext
   uint32_t producerKind = 0; float producerParam = 0.0f;      // part of the frame when set (scTickSetFrameProducer)
   float trafficMult = 1.0f;                                   // TrafficDebugState::speedMultiplier (sc_traffic_common.h:63)
   bool sensors = false; float sensorRay = 20.0f, sensorSafe = 10.0f;   // TrafficSensors defaults (sc_traffic_ai.cpp:307-309)
+  bool halo = false;                                                    // border messages carry the halo section (sensors were on when the tile got its neighbours)
   void* laneAllocs[6] = {};                                   // device copies of the lane graph (scTickSetLaneGraph)
   uint2* dTierPatch = nullptr;                                // tier selection: the few modes the caps changed
   bool pairsPending = false;
@@ -457,6 +458,7 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.bigCap = c->cap + 8u * kBorderBigCap;
   p.pairRunLog2 = pairRunLog2(p.binSX * p.binSZ);
   p.borderRecs = c->borderRecs;
+  p.halo = c->halo ? 1u : 0u;
   p.tileX = c->tileX; p.tileZ = c->tileZ; p.tilesX = c->tilesX; p.tilesZ = c->tilesZ;
 }
 
@@ -482,6 +484,14 @@ void publishPacked(ScTickContext* c, const TickParams& p)
   if (!c->packedRides) hipEventRecord(c->packed[p.parity], c->stream);
   c->packedRides = false;
   hipStreamWaitEvent(c->pairsStream, c->packed[p.parity], 0);
+}
+
+// Obstacle rays on a tiled world (sc_traffic_ai.cpp:300-345: the reference's ray sees the whole physics world): with neighbours, the halo
+// section in the messages and an in-order step, the rays are cast in the PAIR half behind the merge.  A pipelined tile keeps them in
+// the tick half (its own boxes only): the pair half of tick t runs under tick t + 1, whose frame producer reads the brakes.
+bool raysInPairHalf(const ScTickContext* c, uint32_t flags)
+{
+  return c->sensors && c->halo && c->neighbourMask && !c->pairsStream && (flags & SC_TICK_SPLIT_PAIRS) && (flags & SC_TICK_BROADPHASE);
 }
 
 // the tick's launches on c->stream, nothing else: safe inside a stream capture (the callers put waitParityFree before
@@ -525,7 +535,12 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     }
   }
   // the traffic AI's obstacle rays (scTickSetTrafficSensors): against this tick's boxes, before the frame producer moves the agents
-  if ((flags & SC_TICK_BROADPHASE) && c->sensors && ds.aLane) launchAgentFrontRays(ds, p, c->stream);
+  // (a tile with neighbours, stepped in order: the rays are cast in the pair half, behind the merge, where the neighbours' boxes are in
+  //  the bins too -- raysInPairHalf(); here the agents are only listed with their rays as this frame has them)
+  if ((flags & SC_TICK_BROADPHASE) && c->sensors && ds.aLane) {
+    if (raysInPairHalf(c, flags)) launchAgentRaySnapshot(ds, p, c->stream);
+    else launchAgentFrontRays(ds, p, c->stream);
+  }
   if ((flags & SC_TICK_BROADPHASE) && (flags & SC_TICK_DENSE_AABBS)) launchDenseAabbs(ds, c->n, c->stream);   // read-back aid, off the hot path
   const bool needCompact = (flags & (SC_TICK_XFORM | SC_TICK_CULL)) != 0;
   const bool pairsNow = (flags & SC_TICK_BROADPHASE) && !(flags & SC_TICK_SPLIT_PAIRS);
@@ -1232,6 +1247,7 @@ static bool enqueuePairHalf(ScTickContext* c, const TickParams& pp, hipStream_t 
   const DeviceState ds = stateFor(c, pp.parity);
   launchBorderMerge(ds, pp, ps);
   if (pp.flags & SC_TICK_RAYS) launchRayQueries(ds, pp, c->rays, ps);   // sees the neighbours' border boxes too
+  if (raysInPairHalf(c, pp.flags) && ds.aLane) launchAgentFrontRaysFromSnapshot(ds, pp, ps);      // ... and so do the agents' obstacle rays
   return launchPairs(ds, pp, ps, done);
 }
 
@@ -1436,7 +1452,7 @@ int scTickSetTileGrid(ScTickContext* c, uint32_t tileX, uint32_t tileZ, uint32_t
 uint32_t scTickBorderBytes(ScTickContext* c, uint32_t dir)
 {
   if (!c || dir > 7u || !c->desc.tile_sectors_x) return 0;
-  return borderWords(dir, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs) * 4u;
+  return borderWords(dir, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs, c->halo ? 1u : 0u) * 4u;
 }
 
 int scTickSetBorderCapacity(ScTickContext* c, uint32_t recordsPerRingSector)
@@ -2078,12 +2094,23 @@ int scTickSetTrafficSensors(ScTickContext* c, int enable, float frontRayLength, 
     if (!(frontRayLength >= 0.0f) || !(safeDistance >= 0.0f)) return fail(c, "ray length and safe distance must be >= 0");
     if (!c->d.aBrake && (!dalloc(c, c->d.aBrake, c->cap) || !dalloc(c, c->d.agentList, c->cap, false) || !dalloc(c, c->d.agentCount, 4) ||
                          !dalloc(c, c->d.aRayLen, c->cap) || !dalloc(c, c->d.aSafe, c->cap) || !dalloc(c, c->d.aHitDist, c->cap) || !dalloc(c, c->d.aHitType, c->cap))) return 0;
+    if (!c->d.agentRays && !dalloc(c, c->d.agentRays, 2u * (size_t)c->cap, false)) return 0;
     c->sensorRay = frontRayLength; c->sensorSafe = safeDistance;
     launchFillSensors(c->d, 0, c->cap, frontRayLength, safeDistance, c->stream);        // every agent's TrafficSensors = these defaults until scTickUploadTrafficSensors says otherwise
     if (!sync(c)) return 0;
   } else if (c->d.aBrake) {
     HIP_OK(c, hipMemsetAsync(c->d.aBrake, 0, (size_t)c->cap * sizeof(float), c->stream));      // no sensors: brake 0 from here on
     if (!sync(c)) return 0;
+  }
+  // On a tiled world an agent near a tile edge has to see the neighbour's boxes: the border messages then carry the halo section (the
+  // sender's core-edge records), which changes their size -- so the sensors must be switched before the message buffers exist
+  // (scTickBindBorderBuffers* / scTickCommInit), on every tile alike.
+  const bool wantHalo = enable != 0;
+  if (wantHalo != c->halo) {
+    bool bound = c->comm != nullptr;
+    for (uint32_t d = 0; d < 8 && !bound; ++d) bound = c->d.borderSend[d] || c->d.borderRecv[d];
+    if (bound) return fail(c, "on a tile with border buffers or a communicator the traffic sensors cannot be switched any more: the messages' halo section changes their size (call scTickSetTrafficSensors before scTickBindBorderBuffers / scTickCommInit, on every tile)");
+    c->halo = wantHalo;
   }
   c->sensors = enable != 0;
   dropGraph(c); dropPairGraph(c); c->topoEpoch++;
@@ -2356,7 +2383,7 @@ int scTickCommInit(ScTickContext* c, const uint8_t id[SC_TICK_COMM_ID_BYTES], ui
   for (uint32_t q = 0; q < kMaxParity; ++q)
     for (uint32_t d = 0; d < 8; ++d) {
       if (!((c->neighbourMask >> d) & 1u)) continue;
-      const size_t words = borderWords(d, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs);
+      const size_t words = borderWords(d, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs, c->halo ? 1u : 0u);
       for (int k = 0; k < 2; ++k) if (!c->ownBorder[q][d][k] && !dalloc(c, c->ownBorder[q][d][k], words)) return 0;
       if (q == 0) { c->d.borderSend[d] = c->ownBorder[0][d][0]; c->d.borderRecv[d] = c->ownBorder[0][d][1]; }
       else { c->alt[q - 1u].borderSend[d] = c->ownBorder[q][d][0]; c->alt[q - 1u].borderRecv[d] = c->ownBorder[q][d][1]; }
@@ -2376,7 +2403,7 @@ int scTickGetCommInfo(ScTickContext* c, ScTickCommInfo* out)
     out->peer_rank[d] = ((c->neighbourMask >> d) & 1u) ? c->peer[d] : -1;
     if (!((c->neighbourMask >> d) & 1u) || !c->sectors) continue;
     out->operations_per_group += 2u;                                   // one ncclSend + one ncclRecv per neighbour
-    out->bytes_sent_per_step += (uint64_t)borderWords(d, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs) * 4u;
+    out->bytes_sent_per_step += (uint64_t)borderWords(d, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs, c->halo ? 1u : 0u) * 4u;
   }
   if (c->comm) { std::string why; if (const RcclApi* r = rccl(&why)) { int v = 0; if (r->GetVersion(&v) == ncclSuccess) out->rccl_version = (uint32_t)v; } }
   out->host_steps = c->hostSteps;
@@ -2463,11 +2490,11 @@ static int exchangeBorders(ScTickContext* c, uint32_t parity, hipStream_t s, boo
   for (int d = 0; d < 8 && res == ncclSuccess; ++d) {
     if (!((c->neighbourMask >> d) & 1u)) continue;
     if (!ds.borderSend[d] || !ds.borderRecv[d]) { r->GroupEnd(); return fail(c, "border buffers are not bound"); }
-    res = r->Send(ds.borderSend[d], (size_t)borderWords((uint32_t)d, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs), ncclUint32, c->peer[d], c->comm, s);
+    res = r->Send(ds.borderSend[d], (size_t)borderWords((uint32_t)d, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs, c->halo ? 1u : 0u), ncclUint32, c->peer[d], c->comm, s);
   }
   for (int d = 7; d >= 0 && res == ncclSuccess; --d) {
     if (!((c->neighbourMask >> d) & 1u)) continue;
-    res = r->Recv(ds.borderRecv[d], (size_t)borderWords((uint32_t)d, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs), ncclUint32, c->peer[d], c->comm, s);
+    res = r->Recv(ds.borderRecv[d], (size_t)borderWords((uint32_t)d, c->desc.tile_sectors_x, c->desc.tile_sectors_z, c->borderRecs, c->halo ? 1u : 0u), ncclUint32, c->peer[d], c->comm, s);
   }
   const ncclResult_t end = r->GroupEnd();
   if (!ncclOk(c, r, res, "ncclSend/ncclRecv")) return 0;

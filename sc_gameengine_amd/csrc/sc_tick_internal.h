@@ -138,6 +138,8 @@ struct DeviceState {
   // per-agent TrafficSensors (sc_traffic_common.h:46-53): frontRayLength / safeDistance per entity, and what the AI leaves in them (lastHitDistance,
   // lastHitType: 0 none, 2 vehicle, 3 world); allocated with aBrake
   float* aRayLen; float* aSafe; float* aHitDist; uint32_t* aHitType;
+  float4* agentRays;           // [cap][2] with the rays cast in the PAIR half (tiled, in order): (origin xyz, ray length) (forward x, forward z, safe distance, -)
+                               // of every listed agent as the tick half found them -- the frame producer may have moved the agents on by then
   uint32_t* agentList;         // dense indices of the OnRails agents, rebuilt every tick that casts their rays
   uint32_t* agentCount;
   uint32_t* tierCounts;        // [0..2] desired tiers, [3] entries in tierNear
@@ -220,6 +222,7 @@ struct TickParams {
                             // can meet nothing in the world's declared vocabulary, never needed (pipelined tiles, scTickSetWorldLayers);
                             // 0 when something else reads the bins (ray queries, traffic sensors) or neither applies
   uint32_t vocab;           // lazy 2: group bits | mask bits << 16 of every collider that can exist in the tiled world
+  uint32_t halo;            // border messages carry the halo section (traffic sensors on a tiled world): the neighbours' core-edge records land in the ring bins
   uint32_t vocabKnown;      // scTickSetWorldLayers declared the world's layer vocabulary (`vocab`): the border merge counts arrivals outside it
   uint32_t fastPairs;       // the pair role takes bins that hold nothing but their ordered reserved records through the fast path (homeCast)
 };
@@ -234,7 +237,13 @@ __host__ __device__ inline bool hasNb(const TickParams& p, int dx, int dz) { ret
 constexpr uint32_t kSectorRecMax = 64u + kOvfPerSector;      // what one sector can hold at all: its bin + its share of the overflow list
 __host__ __device__ inline uint32_t borderRecCap(uint32_t L, uint32_t recs) { return L * recs > kSectorRecMax ? L * recs : kSectorRecMax; }
 __host__ __device__ inline uint32_t borderBinWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ, uint32_t recs) { const uint32_t L = borderLen(d, coreSX, coreSZ); return kBorderHeader + L + borderRecCap(L, recs) * 8u; }
-__host__ __device__ inline uint32_t borderWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ, uint32_t recs) { return borderBinWords(d, coreSX, coreSZ, recs) + kBorderBigWords; }
+// The HALO section (round 4, traffic sensors on a tiled world): behind the big boxes, the records of the sender's CORE-EDGE sectors along that
+// side -- what an obstacle ray cast from the receiver's edge needs to see in the neighbour's territory (sc_traffic_ai.cpp:300-345: the
+// reference's ray sees the whole physics world).  Fixed slots: cell l owns kBinCap records at a fixed offset, so neither pack nor
+// merge needs a prefix scan.  Layout: [L counts][L x kBinCap records of 8 words].  Present only when both tiles run with sensors.
+__host__ __device__ inline uint32_t borderHaloWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ) { const uint32_t L = borderLen(d, coreSX, coreSZ); return L + L * kBinCap * 8u; }
+__host__ __device__ inline uint32_t borderWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ, uint32_t recs, uint32_t halo = 0u)
+{ return borderBinWords(d, coreSX, coreSZ, recs) + kBorderBigWords + (halo ? borderHaloWords(d, coreSX, coreSZ) : 0u); }
 constexpr uint32_t kFlagHasDeep = 1u << 16;   // write recomp bits for the level kernels
 constexpr uint32_t kFlagDeferredReset = 1u << 17;   // pipelined tiles: a pair kernel never clears the other parity's counters / big bits; a small kernel
                                                     // behind it on the pairs stream snapshots the results and clears its OWN parity
@@ -264,6 +273,8 @@ struct RayQueryState {
 };
 void launchRayQueries(const DeviceState& d, const TickParams& p, const RayQueryState& q, hipStream_t s);
 void launchAgentFrontRays(const DeviceState& d, const TickParams& p, hipStream_t s);
+void launchAgentRaySnapshot(const DeviceState& d, const TickParams& p, hipStream_t s);         // tick half: list the agents, note their rays
+void launchAgentFrontRaysFromSnapshot(const DeviceState& d, const TickParams& p, hipStream_t s); // pair half, behind the merge: cast them
 void launchFillSensors(const DeviceState& d, uint32_t first, uint32_t count, float rayLen, float safe, hipStream_t s);
 constexpr uint32_t kMaxOccupancyQueries = 256;
 void launchOccupancy(const DeviceState& d, uint32_t n, const float4* q, uint32_t count, uint32_t* blocked, hipStream_t s);

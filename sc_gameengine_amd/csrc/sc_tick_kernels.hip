@@ -2074,6 +2074,30 @@ __device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickP
     big[0] = bigCount < kBorderBigCap ? bigCount : kBorderBigCap; big[1] = bigLost;
     d.counters[ctr + kCtrBigLocal] = nLocal;
   }
+  // ---- halo section (traffic sensors on a tiled world): the records of this tile's CORE-EDGE sectors along this side, cell l in
+  // its own kBinCap slots -- no scan, every load independent of every count.  A wave takes a cell at a time (the records of a
+  // bin are one coalesced read); what a crowded sector keeps in the overflow list does not travel and is counted.
+  if (p.halo) {
+    uint32_t* halo = big + kBorderBigWords;
+    float4* hrec = reinterpret_cast<float4*>(halo + L);
+    const uint32_t wv = threadIdx.x >> 6;
+    for (uint32_t l = wv; l < L; l += kTile / 64u) {
+      // the core-edge cell next to ring cell l of this side: where a message from that neighbour lands (landingCell); the end
+      // cells of a side message lie outside the core
+      const bool core = (dx != 0 && dz != 0) || (l >= 1u && l + 2u <= L);
+      uint32_t cnt = 0;
+      if (core) {
+        const uint32_t cell = landingCell(p, dx, dz, l);
+        cnt = d.binCount[cell];
+        if (cnt > kBinCap) { if (lane == 0u) atomicAdd(&d.counters[ctr + kCtrBorderLost], cnt - kBinCap); cnt = kBinCap; }
+        if (lane < cnt) {
+          const float4* src = d.bins + 2u * ((size_t)cell * kBinCap + lane);
+          hrec[2u * ((size_t)l * kBinCap + lane)] = src[0]; hrec[2u * ((size_t)l * kBinCap + lane) + 1u] = src[1];
+        }
+      }
+      if (lane == 0u) halo[l] = cnt;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kTile) void k_border_pack(const DeviceState d, const TickParams p)
@@ -2218,6 +2242,31 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
   for (uint32_t r = threadIdx.x; r < 2u * m; r += kTile) {
     if (at + r / 2u < p.bigCap) d.bigList[2u * (size_t)at + r] = src[r];
     if (p.vocabKnown && !(r & 1u) && (__float_as_uint(src[r].w) & ~p.vocab)) atomicAdd(&d.lazyCtl[1u + kMaxParity + p.parity], 1u);      // (big boxes too)
+  }
+  // ---- halo section: the neighbour's core-edge records land in THIS tile's ring cells on that side, behind the tile's own boxes that
+  // reach out there.  Ring sectors on a side with a neighbour are not this tile's to search (the pair search skips them), the border
+  // pack of the next tick runs before anything lands again, and the pair search leaves every bin's counter at its remembered value:
+  // the records exist for this tick's ray queries and obstacle rays only.
+  if (p.halo) {
+    const uint32_t* halo = big + kBorderBigWords;
+    const float4* hrec = reinterpret_cast<const float4*>(halo + L);
+    const uint32_t wv = threadIdx.x >> 6;
+    for (uint32_t l = wv; l < L; l += kTile / 64u) {
+      const uint32_t cnt = min(halo[l], kBinCap);
+      if (!cnt) continue;
+      bool send;
+      const uint32_t cell = ringCell(p, dx, dz, l, &send);
+      uint32_t slot0 = 0;
+      if (lane == 0u) slot0 = atomicAdd(&d.binCount[cell], cnt);
+      slot0 = __shfl(slot0, 0, 64);
+      if (lane < cnt) {
+        if (slot0 + lane < kBinCap) {
+          float4* dst = d.bins + 2u * ((size_t)cell * kBinCap + slot0 + lane);
+          dst[0] = hrec[2u * ((size_t)l * kBinCap + lane)]; dst[1] = hrec[2u * ((size_t)l * kBinCap + lane) + 1u];
+        }
+      }
+      if (lane == 0u && slot0 + cnt > kBinCap) atomicAdd(&d.counters[ctr + kCtrBorderLost], slot0 + cnt - (slot0 < kBinCap ? kBinCap : slot0));
+    }
   }
 }
 

@@ -174,6 +174,62 @@ __global__ __launch_bounds__(kTile) void k_list_onrails_agents(const DeviceState
   if (agent) d.agentList[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
 }
 
+// Tiled world, in-order step: the rays are cast in the PAIR half, behind the border merge, so that an agent near a tile edge sees the
+// neighbour tile's boxes too (the halo section of the border messages puts them in the ring bins).  The tick half only lists the agents
+// and notes each one's ray as it stands -- the frame producer fused into the end-of-tick kernel moves the agents on before the pair
+// half runs.  Same arithmetic as k_agent_front_rays.
+__global__ __launch_bounds__(kTile) void k_list_onrails_agents_with_rays(const DeviceState d, uint32_t n)
+{
+  const uint32_t i = blockIdx.x * kTile + threadIdx.x;
+  const bool agent = i < n && d.moverKind[i] == kMoverTraffic && d.aMode[i] == kTierOnRails;
+  const unsigned long long m = ballot64(agent);
+  if (!m) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(d.agentCount, (uint32_t)__popcll(m));
+  base = __shfl(base, 0, 64);
+  if (agent) {
+    const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    d.agentList[k] = i;
+    float forward[3] = { d.rsy[i], 0.0f, d.rcy[i] };
+    const float len = sqrtf(forward[0] * forward[0] + forward[1] * forward[1] + forward[2] * forward[2]);
+    if (len > 1e-6f) { const float inv = 1.0f / len; forward[0] *= inv; forward[1] *= inv; forward[2] *= inv; }
+    d.agentRays[2u * k] = make_float4(d.px[i] + forward[0] * 1.7f, d.py[i] + 0.6f, d.pz[i] + forward[2] * 1.7f, d.aRayLen[i]);
+    d.agentRays[2u * k + 1u] = make_float4(forward[0], forward[2], d.aSafe[i], 0.0f);
+  }
+}
+
+__global__ __launch_bounds__(kTile) void k_agent_front_rays_from_snapshot(const DeviceState d, const TickParams p)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t count = *d.agentCount;
+  const uint32_t waves = gridDim.x * (kTile / 64u);
+  for (uint32_t k = blockIdx.x * (kTile / 64u) + (threadIdx.x >> 6); k < count; k += waves) {
+    const uint32_t i = d.agentList[k];
+    const float4 a = d.agentRays[2u * k], b = d.agentRays[2u * k + 1u];
+    const float origin[3] = { a.x, a.y, a.z }, forward[3] = { b.x, 0.0f, b.y };
+    const float rayLen = a.w, safe = b.z;
+    const WaveRay w = castRayWave(d, p, origin, forward, rayLen, 1u, i | p.rankBits);
+    float brake = 0.0f;
+    if (w.hit && safe > 1e-3f && w.t < safe) {
+      const float v = (safe - w.t) / safe;
+      const float m = (1.0f < v) ? 1.0f : v;
+      brake = (0.0f < m) ? m : 0.0f;
+    }
+    if (lane == 0) {
+      d.aBrake[i] = brake;
+      d.aHitDist[i] = w.hit ? w.t : rayLen;
+      uint32_t kind = 0u;
+      if (w.hit) {
+        const bool own = (w.id & 0x7F000000u) == p.rankBits;
+        const uint32_t mk = own ? d.moverKind[w.id & 0x00FFFFFFu] : 0u;
+        kind = own ? ((mk == 1u || mk == kMoverTraffic) ? 2u : 3u) : ((w.layer & 1u) ? 2u : 3u);
+      }
+      d.aHitType[i] = kind;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kTile) void k_fill_sensors(const DeviceState d, uint32_t first, uint32_t count, float rayLen, float safe)
 {
   const uint32_t t = blockIdx.x * kTile + threadIdx.x;
@@ -262,6 +318,19 @@ void launchAgentFrontRays(const DeviceState& d, const TickParams& p, hipStream_t
   hipLaunchKernelGGL(k_list_onrails_agents, dim3((p.n + kTile - 1) / kTile), dim3(kTile), 0, s, d, p.n);
   const uint32_t blocks = std::min((p.n + 3u) / 4u, 8192u);          // (a wave per agent, wave-strided over the list the kernel above wrote)
   hipLaunchKernelGGL(k_agent_front_rays, dim3(std::max(blocks, 1u)), dim3(kTile), 0, s, d, p);
+}
+
+void launchAgentRaySnapshot(const DeviceState& d, const TickParams& p, hipStream_t s)
+{
+  if (!p.n || !d.aLane || !d.aBrake || !d.agentRays) return;
+  hipMemsetAsync(d.agentCount, 0, sizeof(uint32_t), s);
+  hipLaunchKernelGGL(k_list_onrails_agents_with_rays, dim3((p.n + kTile - 1) / kTile), dim3(kTile), 0, s, d, p.n);
+}
+void launchAgentFrontRaysFromSnapshot(const DeviceState& d, const TickParams& p, hipStream_t s)
+{
+  if (!p.n || !d.aLane || !d.aBrake || !d.agentRays) return;
+  const uint32_t blocks = std::min((p.n + 3u) / 4u, 8192u);
+  hipLaunchKernelGGL(k_agent_front_rays_from_snapshot, dim3(std::max(blocks, 1u)), dim3(kTile), 0, s, d, p);
 }
 
 void launchRayQueries(const DeviceState& d, const TickParams& p, const RayQueryState& q, hipStream_t s)

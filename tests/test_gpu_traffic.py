@@ -300,3 +300,106 @@ def test_per_agent_traffic_sensors_and_what_the_ai_leaves_in_them_40_ticks(oracl
             assert_agents_equal(t, w, st, ow)
     assert {0, 2, 3} <= seen_types and differ > 50             # misses, vehicles and pedestrians all occur, and the per-agent values really change brakes
     t.close(); ow.close(); ol.close()
+
+
+def _split_laned(w, grid, S):
+    """a laned config-5 world generated tile-major -> one SynthWorld per tile (movers, agents and the whole lane graph included)"""
+    from sc_gameengine_amd import tiles
+    n = w.n // (grid[0] * grid[1])
+    parts = []
+    for r in range(grid[0] * grid[1]):
+        sl = slice(r * n, (r + 1) * n)
+        tx, tz = tiles.tile_of(r, grid)
+        parent = w.parent[sl].copy()
+        parent[parent >= 0] -= r * n
+        p = sw.SynthWorld(pos=w.pos[sl].copy(), rot=w.rot[sl].copy(), scale=w.scale[sl].copy(), parent=parent, bmin=w.bmin[sl], bmax=w.bmax[sl],
+                          has_mesh=w.has_mesh[sl], has_bounds=w.has_bounds[sl], mesh=w.mesh[sl], material=w.material[sl],
+                          group=w.group[sl], mask=w.mask[sl], sector_of=w.sector_of[sl],
+                          origin=(w.origin[0] + tx * S[0], w.origin[1] + tz * S[1]), sectors=S, camera=w.camera,
+                          mover_kind=w.mover_kind[sl], mover_vel=w.mover_vel[sl].copy(), mover_lo=w.mover_lo[sl], mover_hi=w.mover_hi[sl])
+        p.is_agent, p.agent_lane, p.agent_s = w.is_agent[sl], w.agent_lane[sl].copy(), w.agent_s[sl].copy()
+        p.agent_speed, p.agent_mode, p.lane_graph = w.agent_speed[sl].copy(), w.agent_mode[sl].copy(), w.lane_graph
+        parts.append(p)
+    return parts, n
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_agents_brake_for_vehicles_on_the_neighbour_tile_60_ticks(oracle, fused):
+    """The reference's obstacle ray sees the whole physics world (sc_traffic_ai.cpp:300-345 -> sc_physics.cpp:740-777).  On a tiled
+    world the rays are therefore cast in the pair half, behind the border merge, and the border messages carry the neighbours'
+    core-edge records (the halo section) into the ring bins: an agent within 20 m of the tile edge brakes for a vehicle on the
+    other tile.  2 x 1 tiles on one GPU (device copies as the network), every lane crossing the shared edge busy; brakes of BOTH
+    tiles against the WHOLE-world oracle's rays, bit for bit, on every tick; lane state and positions every ten ticks.
+    fused: the next frame's step rides on the end-of-tick kernel of the tick half, i.e. it runs BEFORE this tick's rays -- the brake
+    then acts one tick later (the reference's own ordering against Bullet's last step); the oracle is stepped the same way.
+    Explicit step behind the pair half: no lag."""
+    import torch
+    from sc_gameengine_amd import tiles
+    grid, S = (2, 1), (6, 8)
+    w = sw.generate_config5(S[0] * grid[0], S[1] * grid[1], laned=True, tiles=grid)
+    a = w.is_agent.astype(bool)
+    w.scale[a, 1] = np.float32(2.0)                                         # (the ray runs 0.6 m above the agents' origins: see the one-tile test)
+    # crowd the lanes near the shared edge (x = 6 * 64): agents there start rolling at once
+    edge_x = 64.0 * S[0]
+    near = a & (np.abs(w.pos[:, 0] - edge_x) < 40.0)
+    w.agent_speed[near] = np.float32(9.0)
+    parts, n = _split_laned(w, grid, S)
+    ow, ol, st = oracle_side(oracle, w)
+    vp = camera_view_proj(w.camera)
+    ticks, bufs = [], []
+    for r, p in enumerate(parts):
+        t = WorldTick.from_world(p, broadphase=True, max_pairs=1 << 19)
+        t.set_view_proj(vp)
+        t.set_traffic_sensors(True)                                         # before the border buffers: the messages get their halo section
+        if fused:
+            t.set_frame_producer(2, DT)
+        ticks.append(t)
+        bufs.append(tiles.BorderBuffers(t, r, grid, "cuda"))
+    assert ticks[0].border_bytes(4) > 64 * 32 * (S[1] + 2)                  # (the halo: a full bin per cell of the side)
+    flags = capi.FULL | capi.SPLIT_PAIRS | (capi.PRODUCE_NEXT if fused else 0)
+    prev = np.zeros(w.n, np.float32)
+    cross, braked = 0, 0
+    for k in range(60):
+        ow.transform_system()
+        mn, mx = ow.world_aabbs()
+        now = ow.traffic_front_ray_brakes(mn[:w.n], mx[:w.n], w.group, w.mask, w.is_agent, st["mode"])
+        ow.traffic_ai_onrails_braked(ol, w.is_agent, st["lane"], st["s"], st["speed"], st["mode"], st["look"], prev if fused else now, DT)
+        ow.advance_movers(w.mover_kind, st["vel"], w.mover_lo, w.mover_hi, DT)
+        for t in ticks:
+            t.run(flags)
+        for t in ticks:
+            t.sync()
+        for r, b in enumerate(bufs):
+            for d, nb in tiles.neighbours(r, grid).items():
+                bufs[nb].recv[7 - d].copy_(b.send[d])
+        torch.cuda.synchronize()
+        for t in ticks:
+            t.run_pairs()
+        got = np.concatenate([t.traffic_brakes() for t in ticks])
+        onr = a & (st["mode"] == 2)
+        assert np.array_equal(bits(got[onr]), bits(now[onr])), f"tick {k}: {(got[onr] != now[onr]).sum()} brakes differ from the whole world's"
+        # brakes caused by a box of the OTHER tile: recompute with only the agent's own tile's boxes and see which differ
+        if k % 15 == 0:
+            for r in range(2):
+                sl = slice(r * n, (r + 1) * n)
+                own = ow.traffic_front_ray_brakes(np.where(np.arange(w.n)[:, None] // n == r, mn[:w.n], np.float32(np.inf)), np.where(np.arange(w.n)[:, None] // n == r, mx[:w.n], np.float32(-np.inf)),
+                                                  w.group, w.mask, w.is_agent, st["mode"])
+                cross += int((own[sl] != now[sl]).sum())
+        braked += int((now[onr] > 0).sum())
+        if not fused:
+            for t in ticks:
+                t.advance_movers(DT)
+        prev = now
+        if k % 10 == 9:
+            for r, t in enumerate(ticks):
+                sl = slice(r * n, (r + 1) * n)
+                ln, ls, sp, md = t.traffic_agents()
+                ar = a[sl]
+                assert np.array_equal(ln[ar], st["lane"][sl][ar]) and np.array_equal(bits(ls[ar]), bits(st["s"][sl][ar])), f"tick {k} tile {r}"
+                assert np.array_equal(bits(sp[ar]), bits(st["speed"][sl][ar])), f"tick {k} tile {r}"
+                assert np.array_equal(bits(t.positions()), bits(ow.local_positions()[:w.n][sl])), f"tick {k} tile {r}"
+            assert all(t.counts().border_lost == 0 for t in ticks)
+    assert braked > 500 and cross > 0, (braked, cross)                      # agents braked, some of them for a box of the neighbour tile
+    for t in ticks:
+        t.close()
+    ow.close(); ol.close()
