@@ -149,9 +149,11 @@ struct DeviceState {
   uint32_t* borderRecv[8];
 };
 
-// Border message layout (uint32 words): [0] records, [1] overflow flag, [2..2+L) per-bin counts,
-// then records (8 words each) packed bin after bin, then the big-box section: [0] boxes, [1] overflow flag,
-// boxes (8 words each).  L = sectors on that ring side.
+// Border message layout (uint32 words): [0] records in the spill-over area, [1] overflow flag, [2..2+L) per-cell counts,
+// then the record capacity (8 words a record): borderFixedSlots() fixed slots for every cell, cell after cell, and behind
+// them the spill-over area (what cells hold beyond their fixed slots, packed cell after cell); then the big-box section:
+// [0] boxes, [1] overflow flag, boxes (8 words each); then, with traffic sensors on a tiled world, the halo section.
+// L = sectors on that ring side.
 constexpr uint32_t kBorderHeader = 2;
 constexpr uint32_t kBorderRecsPerBin = 16;    // default: a message holds L * 16 records (shared by the side's sectors: a crowded ring sector
                                               // may take more than its share), at least one full sector; scTickSetBorderCapacity raises it
@@ -236,6 +238,10 @@ __host__ __device__ inline bool hasNb(const TickParams& p, int dx, int dz) { ret
 // records one border message can carry: `recs` per ring sector of the side on average, at least one sector's bin and overflow list
 constexpr uint32_t kSectorRecMax = 64u + kOvfPerSector;      // what one sector can hold at all: its bin + its share of the overflow list
 __host__ __device__ inline uint32_t borderRecCap(uint32_t L, uint32_t recs) { return L * recs > kSectorRecMax ? L * recs : kSectorRecMax; }
+// of a message's record capacity, every cell owns this many FIXED slots (the first records of a cell travel without a scan);
+// the rest of the capacity is one spill-over area shared by the cells that hold more
+constexpr uint32_t kBorderFixed = 4;
+__host__ __device__ inline uint32_t borderFixedSlots(uint32_t L, uint32_t recs) { const uint32_t per = borderRecCap(L, recs) / L; return per < kBorderFixed ? per : kBorderFixed; }
 __host__ __device__ inline uint32_t borderBinWords(uint32_t d, uint32_t coreSX, uint32_t coreSZ, uint32_t recs) { const uint32_t L = borderLen(d, coreSX, coreSZ); return kBorderHeader + L + borderRecCap(L, recs) * 8u; }
 // The HALO section (round 4, traffic sensors on a tiled world): behind the big boxes, the records of the sender's CORE-EDGE sectors along that
 // side -- what an obstacle ray cast from the receiver's edge needs to see in the neighbour's territory (sc_traffic_ai.cpp:300-345: the

@@ -1284,6 +1284,12 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   //  unwritten what nothing in the world can meet, see k_home_flags)
   //  (the flag is read unconditionally, up front with the other scalars: behind a test of p.lazy it cost every workgroup a stall)
   const bool freshAll = kVocab ? false : (!p.homeReset || d.lazyCtl[1u + p.parity] != 0u);
+  // (Tried and dropped, profiles/r04/ab_quiet_tick_skip_lost.log.  (1) Skipping the sweep on a QUIET tick -- no bin whose reserved
+  //  records can form a pair, nothing reserved since the tick began: an all-static city -- behind two flags read here: config 3's end of
+  //  tick 9.36 us against 9.2, its waves do one round each and the flags cost what the round's own loads cost; the others within noise.
+  //  (2) The cast count folded into the homeCount word, one load fewer per sector: config3dyn 29.1 us against 27.1, config 5 43.2
+  //  against 40.6 in two sessions -- the word is also WRITTEN by the sweep (the hot mark), and the build that read one word for both
+  //  lost what the fast sectors had won; not understood further, the separate homeCast word stays.)
   constexpr bool vocabMode = kVocab;                   // (the launcher picks the instance by p.lazy)
   if (bid == 0u && threadIdx.x == 0u) d.lazyCtl[0] = nbig;             // (what the next fused kernel goes by)
   float4* T = tile[wave];
@@ -1962,11 +1968,12 @@ __device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickP
   uint32_t* msg = d.borderSend[dir];
   const uint32_t cap = borderRecCap(L, p.borderRecs);
   float4* records = reinterpret_cast<float4*>(msg + kBorderHeader + L);
-  // 2 * kTile ring bins at a time (one pass for a 256-sector side): a thread takes two neighbouring bins, finds their
-  // offsets (parallel scan, carry across chunks) and copies their records.  Ring bins are sparse, and 512 bins in flight
-  // hide the latency that a wave-per-bin walk would serialise (measured: 59 us against 14).
-  // (the kernel is a chain of dependent memory round trips, nothing else: a bin's FIRST record is requested together with its
-  //  count -- its address does not depend on the count, most ring bins hold none or one -- and so is the big-box count below)
+  // Layout of the bin part (round 4): per-cell counts, then kBorderFixed FIXED record slots per cell, then a shared spill-over area
+  // for what a cell holds beyond its fixed slots (packed cell after cell, offsets from a scan over the extras).  The kernel is a
+  // chain of dependent memory round trips and nothing else; with fixed slots a cell's first records are requested together with
+  // its count and stored where no other cell's count matters -- the scan, and the loads and stores behind it, exist only on
+  // ticks when some ring cell holds more than kBorderFixed records (round 3 packed everything behind the scan: count -> scan ->
+  // record load -> store; the usual tick is now count+records -> store).  A thread takes one cell (kTile cells in flight per pass).
   // A ring sector that holds more than its bin (round 3): the sector's counter kept counting and the rest of its records sit in
   // the sector overflow list, tagged with the sector.  They cross the border like the bin's records -- the message reserves
   // room for the sector's whole count, the thread copies the bin part, and the WAVE then sweeps the sector's slice of the
@@ -1975,13 +1982,11 @@ __device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickP
   const uint32_t ctr = kCtrPar + 8u * p.parity;
   const uint32_t nLocal = min(d.counters[ctr + kCtrBig], p.bigCap);          // the merge has not run yet: only this tile's boxes
   const uint32_t novf = min(d.counters[ctr + kCtrSpill], p.ovfCap);
-  auto copyBin = [&](uint32_t cell, uint32_t off, uint32_t take, const float4& lo0, const float4& hi0) {
-    const float4* src = d.bins + 2u * ((size_t)cell * kBinCap);
-    float4* dst = records + 2u * (size_t)off;
-    dst[0] = lo0; dst[1] = hi0;
-    for (uint32_t r = 1; r < take; ++r) { dst[2u * r] = src[2u * r]; dst[2u * r + 1u] = src[2u * r + 1u]; }
-  };
+  const uint32_t K = borderFixedSlots(L, p.borderRecs);
+  float4* extraRec = records + 2u * ((size_t)L * K);
+  const uint32_t capX = cap - L * K;
   // the overflow part of the bins a wave's lanes hold: one bin after the other, all 64 lanes on its slice of the list
+  // (off: where the cell's extras start in the spill-over area; its records K..63 come first, the list's behind them)
   auto sweepOverflow = [&](uint32_t cell, uint32_t off, uint32_t take) {
     unsigned long long todo = ballot64(take > kBinCap);
     while (todo) {
@@ -1991,7 +1996,7 @@ __device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickP
       const uint32_t want = wTake - kBinCap;                 // records to find in the list
       uint32_t eLo = d.ovfLo[wCell], eHi = d.ovfHi[wCell];
       if (eHi > novf) eHi = novf;
-      float4* dst = records + 2u * ((size_t)wOff + kBinCap);
+      float4* dst = extraRec + 2u * ((size_t)wOff + kBinCap - K);
       uint32_t found = 0;
       for (uint32_t e0 = eLo; e0 < eHi && found < want; e0 += 64u) {
         const uint32_t e = e0 + lane;
@@ -2005,31 +2010,48 @@ __device__ __forceinline__ void borderPackBody(const DeviceState& d, const TickP
       for (uint32_t q = (found < want ? found : want) + lane; q < want; q += 64u) { float4 lo, hi; nullRecord(lo, hi); dst[2u * q] = lo; dst[2u * q + 1u] = hi; }
     }
   };
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < L; base += 2u * kTile) {
-    const uint32_t l0 = base + 2u * threadIdx.x, l1 = l0 + 1u;
-    uint32_t c0 = 0, c1 = 0, cell0 = 0, cell1 = 0;
-    float4 a0 = make_float4(0, 0, 0, 0), b0 = a0, a1 = a0, b1 = a0;
-    uint32_t over = 0;
-    if (l0 < L) { bool send = false; cell0 = ringCell(p, dx, dz, l0, &send); if (send) { c0 = d.binCount[cell0]; const float4* r = d.bins + 2u * ((size_t)cell0 * kBinCap); a0 = r[0]; b0 = r[1]; } }
-    if (l1 < L) { bool send = false; cell1 = ringCell(p, dx, dz, l1, &send); if (send) { c1 = d.binCount[cell1]; const float4* r = d.bins + 2u * ((size_t)cell1 * kBinCap); a1 = r[0]; b1 = r[1]; } }
-    if (c0 > kSectorRecMax) { over += c0 - kSectorRecMax; c0 = kSectorRecMax; }
-    if (c1 > kSectorRecMax) { over += c1 - kSectorRecMax; c1 = kSectorRecMax; }
-    uint32_t total;
-    const uint32_t off0 = blockScanExclusive(c0 + c1, carry, sWave, &total), off1 = off0 + c0;
-    const uint32_t take0 = (off0 + c0 <= cap) ? c0 : (off0 < cap ? cap - off0 : 0u);
-    const uint32_t take1 = (off1 + c1 <= cap) ? c1 : (off1 < cap ? cap - off1 : 0u);
-    over += (c0 - take0) + (c1 - take1);                      // the message is full
+  uint32_t carry = 0;                                         // records in the spill-over area so far
+  for (uint32_t base = 0; base < L; base += kTile) {
+    const uint32_t l = base + threadIdx.x;
+    uint32_t c = 0, cell = 0, over = 0;
+    static_assert(kBorderFixed == 4, "the fixed slots are spelled out (arrays of float4 end up in scratch)");
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 a0 = zero4, b0 = zero4, a1 = zero4, b1 = zero4, a2 = zero4, b2 = zero4, a3 = zero4, b3 = zero4;
+    bool send = false;
+    if (l < L) cell = ringCell(p, dx, dz, l, &send);
+    if (send) {
+      c = d.binCount[cell];
+      const float4* r = d.bins + 2u * ((size_t)cell * kBinCap);       // (a bin row is there whatever it holds)
+      a0 = r[0]; b0 = r[1]; a1 = r[2]; b1 = r[3]; a2 = r[4]; b2 = r[5]; a3 = r[6]; b3 = r[7];
+    }
+    if (c > kSectorRecMax) { over += c - kSectorRecMax; c = kSectorRecMax; }
+    const uint32_t nf = c < K ? c : K;
+    {
+      float4* dst = records + 2u * ((size_t)l * K);
+      if (nf > 0u) { dst[0] = a0; dst[1] = b0; }
+      if (nf > 1u) { dst[2] = a1; dst[3] = b1; }
+      if (nf > 2u) { dst[4] = a2; dst[5] = b2; }
+      if (nf > 3u) { dst[6] = a3; dst[7] = b3; }
+    }
+    const uint32_t e = c - nf;                                // beyond the fixed slots
+    uint32_t take = c;
+    if (__syncthreads_or(e ? 1 : 0)) {
+      uint32_t total;
+      const uint32_t off = blockScanExclusive(e, carry, sWave, &total);
+      const uint32_t te = (off + e <= capX) ? e : (off < capX ? capX - off : 0u);
+      over += e - te;                                         // the message is full
+      take = nf + te;
+      const uint32_t inBin = take < kBinCap ? take : kBinCap;
+      const float4* src = d.bins + 2u * ((size_t)cell * kBinCap);
+      float4* dst = extraRec + 2u * (size_t)off;
+      for (uint32_t r = nf; r < inBin; ++r) { dst[2u * (r - nf)] = src[2u * r]; dst[2u * (r - nf) + 1u] = src[2u * r + 1u]; }
+      sweepOverflow(cell, off, take);
+      carry = total;
+    }
     if (over) atomicAdd(&d.counters[ctr + kCtrBorderLost], over);
-    if (l0 < L) msg[kBorderHeader + l0] = take0;
-    if (l1 < L) msg[kBorderHeader + l1] = take1;
-    if (take0) copyBin(cell0, off0, take0 < kBinCap ? take0 : kBinCap, a0, b0);
-    if (take1) copyBin(cell1, off1, take1 < kBinCap ? take1 : kBinCap, a1, b1);
-    sweepOverflow(cell0, off0, take0);
-    sweepOverflow(cell1, off1, take1);
-    carry = total;
+    if (l < L) msg[kBorderHeader + l] = take;
   }
-  if (threadIdx.x == 0) { msg[0] = carry < cap ? carry : cap; msg[1] = carry > cap ? 1u : 0u; }
+  if (threadIdx.x == 0) { msg[0] = carry < capX ? carry : capX; msg[1] = carry > capX ? 1u : 0u; }
 
   // ---- big-box section: this tile's big boxes that reach the neighbour's owned region (its core, unbounded on
   // the sides where the world ends) within kBigReach sectors
@@ -2155,16 +2177,27 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
     // (record r goes to slot0 + r while that is below the bin's capacity, else to list entry q0 + (slot0 + r - max(slot0, 64)))
   };
   constexpr uint32_t kSerial = 24;                         // a sector's records up to this many are landed by its own thread (the wave-wide path costs a few round trips per sector: it is for crowded sectors, not for bins with five records)
-  auto landBin = [&](uint32_t l, uint32_t off, uint32_t c) __attribute__((always_inline)) {
+  const uint32_t recCap = borderRecCap(L, p.borderRecs);
+  const uint32_t K = borderFixedSlots(L, p.borderRecs);
+  const float4* extraRec = records + 2u * ((size_t)L * K);
+  const uint32_t capX = recCap - L * K;
+  const uint32_t extras = msg[0];                          // records in the spill-over area: none on the usual tick -> no scan
+  // cell l's records: the first K in its fixed slots (already in registers: fa/fb), the rest at `off` of the spill-over area
+  auto landBin = [&](uint32_t l, uint32_t off, uint32_t c, const float4& a0, const float4& b0, const float4& a1, const float4& b1,
+                     const float4& a2, const float4& b2, const float4& a3, const float4& b3) __attribute__((always_inline)) {
     // the sender's ring cell l on its side (-dx,-dz) is this tile's cell l along its own side (dx,dz)
     const uint32_t sector = landingCell(p, dx, dz, l);
-    const float4* src = records + 2u * (size_t)off;
-    const float4 lo0 = src[0], hi0 = src[1];                      // in flight together with the slot reservation
     uint32_t slot0, q0; reserve(sector, c, slot0, q0);
     const uint32_t firstOver = slot0 < kBinCap ? kBinCap : slot0;
     uint32_t lay = 0;
-    for (uint32_t r = 0; r < c; ++r) {
-      const float4 lo = r ? src[2u * r] : lo0, hi = r ? src[2u * r + 1u] : hi0;
+    const uint32_t nf = c < K ? c : K;
+    if (nf > 0u) { lay |= __float_as_uint(a0.w); place(sector, slot0, q0 + (slot0 - firstOver), a0, b0); }
+    if (nf > 1u) { lay |= __float_as_uint(a1.w); place(sector, slot0 + 1u, q0 + (slot0 + 1u - firstOver), a1, b1); }
+    if (nf > 2u) { lay |= __float_as_uint(a2.w); place(sector, slot0 + 2u, q0 + (slot0 + 2u - firstOver), a2, b2); }
+    if (nf > 3u) { lay |= __float_as_uint(a3.w); place(sector, slot0 + 3u, q0 + (slot0 + 3u - firstOver), a3, b3); }
+    const float4* src = extraRec + 2u * (size_t)off;
+    for (uint32_t r = K; r < c; ++r) {
+      const float4 lo = src[2u * (r - K)], hi = src[2u * (r - K) + 1u];
       lay |= __float_as_uint(lo.w);
       place(sector, slot0 + r, q0 + (slot0 + r - firstOver), lo, hi);
     }
@@ -2184,10 +2217,12 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
       if (lane == 0) reserve(sector, wc, slot0, q0);
       slot0 = __shfl(slot0, 0, 64); q0 = __shfl(q0, 0, 64);
       const uint32_t firstOver = slot0 < kBinCap ? kBinCap : slot0;
-      const float4* src = records + 2u * (size_t)wOff;
+      const float4* fsrc = records + 2u * ((size_t)wl * K);
+      const float4* xsrc = extraRec + 2u * (size_t)wOff;
       uint32_t lay = 0;
       for (uint32_t r = lane; r < wc; r += 64u) {
-        const float4 lo = src[2u * r], hi = src[2u * r + 1u];
+        const float4* s = r < K ? fsrc + 2u * r : xsrc + 2u * (r - K);
+        const float4 lo = s[0], hi = s[1];
         lay |= __float_as_uint(lo.w);
         place(sector, slot0 + r, q0 + (slot0 + r - firstOver), lo, hi);
       }
@@ -2197,36 +2232,46 @@ __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, con
       if (lane == 0 && p.vocabKnown && (lay & ~p.vocab)) atomicAdd(&d.lazyCtl[1u + kMaxParity + p.parity], 1u);
     }
   };
-  // Two passes over the message's bins: the first lands the usual ones -- up to kSerial records, each bin by its own thread --,
-  // the second, which exists only when some bin holds more, lands those a wave at a time.  (kSerial was 4 at first: ring bins
+  // Two passes over the message's cells: the first lands the usual ones -- up to kSerial records, each cell by its own thread --,
+  // the second, which exists only when some cell holds more, lands those a wave at a time.  (kSerial was 4 at first: ring bins
   // of the usual world hold 0-3 records but now and then five or six, and every such bin then cost its wave a few round trips of
   // the wave-wide path -- the kernel took 23 instead of 10 us, the in-order tile step 89 instead of 73.)
+  // The count, the header and the cell's fixed slots are requested together (round 4); the slot reservation follows the count,
+  // the stores follow both: three round trips on the usual tick, where round 3 had count -> scan -> record -> store.
   uint32_t carry = 0;
   bool anyCrowded = false;
-  for (uint32_t base = 0; base < L; base += 2u * kTile) {
-    const uint32_t l0 = base + 2u * threadIdx.x, l1 = l0 + 1u;
+  for (uint32_t base = 0; base < L; base += kTile) {
+    const uint32_t l = base + threadIdx.x;
     // (counts are what a neighbour wrote: held to what a sector can hold whatever arrives)
-    const uint32_t c0 = l0 < L ? min(msg[kBorderHeader + l0], kSectorRecMax) : 0u, c1 = l1 < L ? min(msg[kBorderHeader + l1], kSectorRecMax) : 0u;
-    uint32_t total;
-    const uint32_t off0 = blockScanExclusive(c0 + c1, carry, sWave, &total);
-    const uint32_t recCap = borderRecCap(L, p.borderRecs);
-    const bool ok0 = c0 && off0 + c0 <= recCap, ok1 = c1 && off0 + c0 + c1 <= recCap;
-    if (ok0 && c0 <= kSerial) landBin(l0, off0, c0);
-    if (ok1 && c1 <= kSerial) landBin(l1, off0 + c0, c1);
-    anyCrowded = anyCrowded || (ok0 && c0 > kSerial) || (ok1 && c1 > kSerial);
-    carry = total;
+    uint32_t c = 0;
+    static_assert(kBorderFixed == 4, "the fixed slots are spelled out (arrays of float4 end up in scratch)");
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 a0 = zero4, b0 = zero4, a1 = zero4, b1 = zero4, a2 = zero4, b2 = zero4, a3 = zero4, b3 = zero4;
+    if (l < L) {
+      c = min(msg[kBorderHeader + l], kSectorRecMax);
+      const float4* r = records + 2u * ((size_t)l * K);
+      if (K > 0u) { a0 = r[0]; b0 = r[1]; }
+      if (K > 1u) { a1 = r[2]; b1 = r[3]; }
+      if (K > 2u) { a2 = r[4]; b2 = r[5]; }
+      if (K > 3u) { a3 = r[6]; b3 = r[7]; }
+    }
+    const uint32_t e = c > K ? c - K : 0u;
+    uint32_t off = 0;
+    if (extras) { uint32_t total; off = blockScanExclusive(e, carry, sWave, &total); carry = total; }
+    const bool ok = c && (e == 0u || (extras && off + e <= capX));
+    if (ok && c <= kSerial) landBin(l, off, c, a0, b0, a1, b1, a2, b2, a3, b3);
+    anyCrowded = anyCrowded || (ok && c > kSerial);
   }
   if (__syncthreads_or(anyCrowded ? 1 : 0)) {
     carry = 0;
-    for (uint32_t base = 0; base < L; base += 2u * kTile) {
-      const uint32_t l0 = base + 2u * threadIdx.x, l1 = l0 + 1u;
-      const uint32_t c0 = l0 < L ? min(msg[kBorderHeader + l0], kSectorRecMax) : 0u, c1 = l1 < L ? min(msg[kBorderHeader + l1], kSectorRecMax) : 0u;
+    for (uint32_t base = 0; base < L; base += kTile) {
+      const uint32_t l = base + threadIdx.x;
+      const uint32_t c = l < L ? min(msg[kBorderHeader + l], kSectorRecMax) : 0u;
+      const uint32_t e = c > K ? c - K : 0u;
       uint32_t total;
-      const uint32_t off0 = blockScanExclusive(c0 + c1, carry, sWave, &total);
-      const uint32_t recCap = borderRecCap(L, p.borderRecs);
-      const bool ok0 = c0 && off0 + c0 <= recCap, ok1 = c1 && off0 + c0 + c1 <= recCap;
-      landCrowded(l0, off0, c0, ok0 && c0 > kSerial);
-      landCrowded(l1, off0 + c0, c1, ok1 && c1 > kSerial);
+      const uint32_t off = blockScanExclusive(e, carry, sWave, &total);
+      const bool ok = c && (e == 0u || off + e <= capX);
+      landCrowded(l, off, c, ok && c > kSerial);
       carry = total;
     }
   }
