@@ -42,6 +42,7 @@ struct ScTickContext
   // host mirrors needed to (re)build link words
   std::vector<int32_t> hParent;
   std::vector<uint32_t> hLayers;     // group | mask << 16 as uploaded (scTickUploadLayers), for the world-vocabulary contract
+  bool layerSetStale = true, ownLayersCanPair = true; uint32_t layerSetN = 0;      // worldCanPair(): do any two of this context's layer words admit a pair?
   std::vector<uint8_t> hFlags;       // bit0 has mesh, bit1 has bounds, bits 2..4 rotation about X/Y/Z trivial (sin 0, cos 1)
   std::vector<uint32_t> hChildren;   // direct children per entity (valid while !linksStale)
   // child lists in dense-index space (-1 = none), valid while !linksStale: a despawn patches exactly the links that
@@ -888,6 +889,7 @@ int scTickUploadLayers(ScTickContext* c, uint32_t first, uint32_t count, const u
   if (!h2d(c, c->d.layers + first, packed.data(), (size_t)count * 4u)) return 0;
   if (c->hLayers.size() < (size_t)first + count) c->hLayers.resize((size_t)first + count, 0u);
   std::copy(packed.begin(), packed.end(), c->hLayers.begin() + first);      // (host mirror: what a later, narrower vocabulary is checked against)
+  c->layerSetStale = true;
   c->homeValid = false;                 // the bins' remembered layer summaries are behind
   return sync(c) ? 1 : 0;
 }
@@ -1028,6 +1030,7 @@ int scTickRemoveEntities(ScTickContext* c, const uint32_t* idx, uint32_t count, 
     if (!sync(c)) return 0;                          // the scratch buffer is reused for the parent patches below
     for (uint32_t k = 0; k < moves; ++k)             // (the layer words' host mirror moves along: sources lie beyond every target)
       if (src[k] < c->hLayers.size()) { if (c->hLayers.size() <= dst[k]) c->hLayers.resize((size_t)dst[k] + 1u, 0u); c->hLayers[dst[k]] = c->hLayers[src[k]]; }
+    c->layerSetStale = true;
   }
 
   std::vector<uint32_t> patch;                       // (entity, new parent) pairs for the device link words
@@ -1251,6 +1254,33 @@ static bool enqueuePairHalf(ScTickContext* c, const TickParams& pp, hipStream_t 
   return launchPairs(ds, pp, ps, done);
 }
 
+// Can any two colliders this context may ever hold in its bins meet (Bullet's filter, sc_physics.cpp:700-712 via SURVEY 8a)?  From the
+// host's mirror of the uploaded layer words -- and, on a tile, the declared vocabulary of the world (records arrive from neighbours).
+// An all-static city cannot: its pair role is a sweep over the bins' counters and nothing else, and the launcher sizes the grid for
+// that (pairGridFor).  A HINT for launch shapes only: the search itself never goes by it.
+static bool worldCanPair(ScTickContext* c)
+{
+  if (c->layerSetStale || c->layerSetN != c->n) {
+    std::vector<uint32_t> words;
+    uint32_t last = 0; bool any = false, many = false;
+    const size_t upto = std::min<size_t>(c->hLayers.size(), c->n);
+    for (size_t i = 0; i < upto && !many; ++i) {
+      const uint32_t w = c->hLayers[i];
+      if (any && w == last) continue;
+      last = w; any = true;
+      if (std::find(words.begin(), words.end(), w) == words.end()) { if (words.size() >= 64u) many = true; else words.push_back(w); }
+    }
+    bool can = many;
+    for (size_t a = 0; a < words.size() && !can; ++a)
+      for (size_t b = a; b < words.size() && !can; ++b)
+        can = ((words[a] & 0xFFFFu) & (words[b] >> 16)) && ((words[b] & 0xFFFFu) & (words[a] >> 16));
+    c->ownLayersCanPair = can; c->layerSetStale = false; c->layerSetN = c->n;
+  }
+  if (c->ownLayersCanPair) return true;
+  if (!c->neighbourMask) return false;
+  return !c->worldLayersKnown || ((c->worldLayers & 0xFFFFu) & (c->worldLayers >> 16)) != 0u;
+}
+
 int scTickRun(ScTickContext* c, uint32_t flags)
 {
   if (!c) return 0;
@@ -1296,7 +1326,8 @@ int scTickRun(ScTickContext* c, uint32_t flags)
       c->homeValid = true; c->homeEpoch = c->topoEpoch; c->homeAge = 0; c->lastTickLearn = true; c->learnTicks++;
     } else { p.homeMode = kHomeUse; c->homeAge++; }
     p.homeReset = 1u;
-    p.fastPairs = c->fastPairs ? 1u : 0u;
+    p.sweepOnly = worldCanPair(c) ? 0u : 1u;
+    p.fastPairs = (c->fastPairs && !p.sweepOnly) ? 1u : 0u;
     // lazy records: only while nothing but this tick's own pair search reads the bins, and that search runs before the next
     // tick rewrites the world matrices (it rebuilds unwritten records from them)
     // (a pipelined pair half cannot rebuild -- the matrices are the next tick's by then -- so there only the bins that nothing in the

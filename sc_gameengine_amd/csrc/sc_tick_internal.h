@@ -226,6 +226,7 @@ struct TickParams {
   uint32_t vocab;           // lazy 2: group bits | mask bits << 16 of every collider that can exist in the tiled world
   uint32_t halo;            // border messages carry the halo section (traffic sensors on a tiled world): the neighbours' core-edge records land in the ring bins
   uint32_t vocabKnown;      // scTickSetWorldLayers declared the world's layer vocabulary (`vocab`): the border merge counts arrivals outside it
+  uint32_t sweepOnly;       // host hint (worldCanPair): no two layer words of this world admit a pair -- the pair role only sweeps the counters; sizes its grid, nothing else
   uint32_t fastPairs;       // the pair role takes bins that hold nothing but their ordered reserved records through the fast path (homeCast)
 };
 // neighbour directions: d = (dz+1)*3 + (dx+1), skipping the centre -> 0..7; opposite(d) = 7 - d

@@ -2751,7 +2751,12 @@ static uint32_t pairGridFor(const TickParams& p)
 {
   const uint32_t sectors = p.binSX * p.binSZ;
   const uint32_t runs = (sectors + (1u << p.pairRunLog2) - 1u) >> p.pairRunLog2;
-  const uint32_t capWaves = std::min(((p.variant >> 8) ? (p.variant >> 8) : 2048u) * (kTile / 64u), kOvfWaves);
+  // (workgroups: as many as give every wave ONE round of 64 sectors where sectors hold work -- a heavy sector then delays one wave's
+  //  single round, not a queue of rounds: 768 workgroups cost config 5 49.2 us against 40.5, 256 cost 100.  Where the host knows that
+  //  nothing in the world can pair (TickParams::sweepOnly: an all-static city) the role is a sweep over counters, its per-workgroup
+  //  prologue -- pair table, barrier -- is what it costs, and a quarter of the workgroups do four rounds each: config 3's end of tick
+  //  8.7 us against 9.3.  profiles/r04/ab_pair_grid.log)
+  const uint32_t capWaves = std::min(((p.variant >> 8) ? (p.variant >> 8) : (p.sweepOnly ? 256u : 2048u)) * (kTile / 64u), kOvfWaves);
   const uint32_t rounds = (runs + capWaves - 1u) / capWaves;
   const uint32_t waves = (runs + rounds - 1u) / rounds;
   return std::max(1u, (waves + kTile / 64u - 1u) / (kTile / 64u));
