@@ -1295,6 +1295,17 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   float4* T = tile[wave];
   PairSink sink = { pairBuf[wave], 0u, bid % kPairShards };
 
+  // the counters of the wave's FIRST 64 sectors are requested here, ahead of the workgroup's prologue (pair table, barrier): their round
+  // trip runs behind it (most waves do one round; the loop below starts from these values)
+  const uint32_t runLog = p.pairRunLog2, runLen = 1u << runLog, runsPerRound = 64u >> runLog;
+  const uint32_t sector0 = ((((lane >> runLog)) * totalWaves + waveGlobal) << runLog) + ((lane + waveGlobal) & (runLen - 1u));
+  uint32_t preCount = 0, preLay = 0, preHc = 0, preHl = 0, preCast = 0;
+  if (sector0 < sectors) {
+    preCount = d.binCount[sector0]; preLay = d.binLayers[sector0];
+    if (p.homeReset) { preHc = d.homeCount[sector0]; preHl = d.homeLayers[sector0]; }
+    if (p.fastPairs) preCast = d.homeCast[sector0];
+  }
+
   // triangular pair table, built once per workgroup (row i starts at i(i-1)/2)
   for (uint32_t i = 1u + threadIdx.x / 64u * 16u; i < kBinCap && i < 17u + threadIdx.x / 64u * 16u; ++i)
     for (uint32_t j = lane; j < i; j += 64u) pairTab[i * (i - 1u) / 2u + j] = (uint16_t)(i << 8 | j);
@@ -1321,22 +1332,24 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   // runs apart, so a dense district of the world is still spread over many waves; inside a run the lanes are rotated by the
   // wave's index, so waves that start together do not all read bins at the same offset of a 2^k-byte stride.  The launcher
   // sizes the grid so that every wave gets the same number of runs (within one): the slowest wave ends the kernel.
-  const uint32_t runLog = p.pairRunLog2, runLen = 1u << runLog, runsPerRound = 64u >> runLog;
   for (uint32_t round = 0; ((round * runsPerRound) * totalWaves + waveGlobal) << runLog < sectors; ++round) {
     const uint32_t mySector = (((round * runsPerRound + (lane >> runLog)) * totalWaves + waveGlobal) << runLog) + ((lane + waveGlobal) & (runLen - 1u));
     uint32_t myCount = 0, myLay = 0, myHome = 0, myCast = 0;
     bool myStale = false;
     const uint32_t myGx = mySector % p.binSX, myGz = mySector / p.binSX;     // once per 64 sectors, not once per sector
     if (mySector < sectors) {
-      myCount = d.binCount[mySector];
-      const uint32_t lay = d.binLayers[mySector];      // requested together with the count: one round trip, not two
+      // (requested together: one round trip, not five; round 0's are in flight since before the prologue)
+      uint32_t lay, hc = 0u, hl = 0u;
+      if (round == 0u) { myCount = preCount; lay = preLay; hc = preHc; hl = preHl; myCast = preCast; }
+      else {
+        myCount = d.binCount[mySector]; lay = d.binLayers[mySector];
+        if (p.homeReset) { hc = d.homeCount[mySector]; hl = d.homeLayers[mySector]; }
+        if (p.fastPairs) myCast = d.homeCast[mySector];
+      }
       myLay = lay;
       // the bin's counters go back to where the next tick starts from: zero, or -- with remembered slots -- the slots that are
       // reserved and the layer summary of their records (binEntityWave, "home slots")
-      uint32_t hc = 0u, hl = 0u;
-      bool hot = false;
-      if (p.homeReset) { hc = d.homeCount[mySector]; hl = d.homeLayers[mySector]; hot = (hc & kHomeHot) != 0u; hc &= ~kHomeHot; }
-      if (p.fastPairs) myCast = d.homeCast[mySector];
+      const bool hot = (hc & kHomeHot) != 0u; hc &= ~kHomeHot;
       if (myCount != hc || lay != hl) { d.binCount[mySector] = hc; d.binLayers[mySector] = hl; }
       myHome = hc;
       const uint32_t hlTest = vocabMode ? layersThatCanMeet(hl, p.vocab) : hl;

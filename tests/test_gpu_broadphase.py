@@ -326,6 +326,35 @@ def test_remembered_slots_survive_uploads_appends_and_removals(oracle, monkeypat
     t.close(); ow.close()
 
 
+def test_a_world_that_cannot_pair_is_only_a_hint_for_the_launch_shape(oracle):
+    """The host sizes the pair role's grid by whether ANY two uploaded layer words admit a pair (an all-static city does not: its
+    pair role is a sweep over counters).  A hint only: the same context finds every pair once layers that can meet are uploaded,
+    and none again when they are taken back."""
+    w, d = _static_city_with_wanderers(6000, 0, seed=91)
+    ow = worlds.oracle_world(oracle, w, camera=False)
+    t = WorldTick.from_world(w, broadphase=True, max_pairs=1 << 19)
+
+    def check(expect_some):
+        for _ in range(3):
+            ow.nudge_roots_x(0.5); t.nudge_roots_x(0.5)
+            ow.transform_system(); t.run(FLAGS)
+            mn, mx = ow.world_aabbs()
+            want = oracle.broadphase_grid(mn, mx, w.group, w.mask, 64.0)
+            got, total = t.pairs()
+            assert total == len(want) and np.array_equal(sorted_pairs(got), want)
+            assert (len(want) > 0) == expect_some
+    check(False)
+    roots = np.flatnonzero(w.parent < 0)
+    dyn = roots[:400]
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    t.upload_layers(0, w.group, w.mask)
+    check(True)
+    w.group[dyn], w.mask[dyn] = sw.GROUP_STATIC, sw.MASK_STATIC
+    t.upload_layers(0, w.group, w.mask)
+    check(False)
+    t.close(); ow.close()
+
+
 def _static_city_with_wanderers(n, dyn, seed, spread=440.0):
     """Static props (group 2 / mask 1) everywhere, a few dynamic bodies (1 / all) among them: most bins admit no pair."""
     w = worlds.random_world(n, seed=seed, spread=spread, max_depth=1, p_child=0.2, p_no_bounds=0.02)
