@@ -689,6 +689,9 @@ def main():
                 # the k_xform_cull<..., 1u> row and k_snapshot_home / k_order_home / k_home_flags), i.e. ~0.4 us per step amortised
                 "learn_tick": {"period": int(os.environ.get("SC_TICK_HOME_PERIOD", "64")), "learn_ticks_inside_the_timed_region": int(learn_in_region),
                                "timed_steps": args.steps},
+                # the host's launch-shape hint (scTickGetBinStats bit 2): no two layer words of this world admit a pair, so the pair role of
+                # the end-of-tick kernel is sized as a sweep over the bins' counters (256 workgroups instead of 1041); the search is unchanged
+                "pair_role_sweep_only": bool(t.bin_stats()["pair_role_sweep_only"]) if (flags & capi.BROADPHASE) else None,
             },
             "parity_in_run": parity,
             "visible_assembly": visible_assembly,

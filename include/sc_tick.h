@@ -276,7 +276,9 @@ int scTickGatherVisibleCounts(ScTickContext* ctx, uint32_t* counts_out, uint32_t
  * record from elsewhere needs them (the pair search then rebuilds them; SC_TICK_VARIANT bit 5 switches that off; ticks with
  * ray queries or traffic sensors, and pipelined tiles, write every record).
  * stats[0] remembered slots, [1] of those written on every tick, [2] bit 0: the last tick was allowed to leave the other slots
- * unwritten, bit 1: it left records of entities whose matrix was not rebuilt as they were, [3] learn ticks so far.  Reads the slots back (a few MB): not for the frame loop. */
+ * unwritten, bit 1: it left records of entities whose matrix was not rebuilt as they were, bit 2: no two of the uploaded layer words
+ * (nor, on a tile, of the declared world vocabulary) admit a pair, so the pair role was launched as a sweep over the bins' counters
+ * (a quarter of the workgroups; a launch shape, never a shortcut of the search), [3] learn ticks so far.  Reads the slots back (a few MB): not for the frame loop. */
 int scTickGetBinStats(ScTickContext* ctx, uint32_t stats[4]);
 /* The layer VOCABULARY of the tiled world: the OR of the group words and the OR of the mask words of every collider that exists on
  * ANY tile, now or later (until the next call; bits 0..15, or 0xFFFFFFFF = all, as scTickUploadLayers).  With it a pipelined tile

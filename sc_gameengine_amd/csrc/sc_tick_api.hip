@@ -101,7 +101,7 @@ struct ScTickContext
   bool homeEnabled = true, homeValid = false, homeCountsLive = false;
   bool lazyEnabled = true;                             // lazy records (DeviceState::lazyCtl)
   bool fastPairs = true;                               // ordered home slots: bins without visitors take the pair role's fast path (DeviceState::homeCast)
-  bool lastTickLazy = false, lastTickStay = false; uint32_t learnTicks = 0;  // scTickGetBinStats
+  bool lastTickLazy = false, lastTickStay = false, lastTickSweepOnly = false; uint32_t learnTicks = 0;  // scTickGetBinStats
   bool worldLayersKnown = false; uint32_t worldLayers = 0;   // scTickSetWorldLayers: group bits | mask bits << 16 of every collider of the tiled world
   bool boxesTouched = false;                           // bounds or world matrices were uploaded since the last broadphase tick (TickParams::cleanStay)
   uint64_t homeEpoch = ~0ull; uint32_t homeAge = 0, homePeriod = 64;
@@ -1327,6 +1327,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
     } else { p.homeMode = kHomeUse; c->homeAge++; }
     p.homeReset = 1u;
     p.sweepOnly = worldCanPair(c) ? 0u : 1u;
+    c->lastTickSweepOnly = p.sweepOnly != 0u;
     p.fastPairs = (c->fastPairs && !p.sweepOnly) ? 1u : 0u;
     // lazy records: only while nothing but this tick's own pair search reads the bins, and that search runs before the next
     // tick rewrites the world matrices (it rebuilds unwritten records from them)
@@ -2313,7 +2314,7 @@ int scTickGetBinStats(ScTickContext* c, uint32_t stats[4])
   stats[0] = stats[1] = stats[2] = stats[3] = 0u;
   if (!bind(c)) return 0;
   if (!c->d.homeA || !c->n) return 1;
-  stats[2] = (c->lastTickLazy ? 1u : 0u) | (c->lastTickStay ? 2u : 0u); stats[3] = c->learnTicks;
+  stats[2] = (c->lastTickLazy ? 1u : 0u) | (c->lastTickStay ? 2u : 0u) | (c->lastTickSweepOnly ? 4u : 0u); stats[3] = c->learnTicks;
   if (!c->homeValid) return 1;
   if (!sync(c)) return 0;
   std::vector<uint32_t> a(c->n), b(c->n);

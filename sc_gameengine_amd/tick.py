@@ -442,7 +442,7 @@ class WorldTick:
         st = np.zeros(4, np.uint32)
         self._ok(self.lib.scTickGetBinStats(self.ctx, _u(st)), "scTickGetBinStats")
         return {"remembered_slots": int(st[0]), "written_every_tick": int(st[1]), "lazy_last_tick": bool(st[2] & 1),
-                "unchanged_records_stay": bool(st[2] & 2), "learn_ticks": int(st[3])}
+                "unchanged_records_stay": bool(st[2] & 2), "pair_role_sweep_only": bool(st[2] & 4), "learn_ticks": int(st[3])}
 
     def reset_host_times(self):
         self._ok(self.lib.scTickResetHostTimes(self.ctx), "scTickResetHostTimes")
