@@ -1913,8 +1913,16 @@ __global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_compact_pairs(const Devic
   __shared__ uint32_t moved[kMaxSpanWords];
   // (a workgroup plays one role: the compaction role borrows the pair role's tile area -- 8 KiB >= kCompactLdsWords dwords)
   static_assert(sizeof(tile) >= kCompactLdsWords * sizeof(uint32_t), "compaction scratch does not fit the pair tiles");
-  if (blockIdx.x < compactBlocks) compactBody<kEmit>(d, p, blockIdx.x, compactBlocks, group, scratch, moved, reinterpret_cast<uint32_t*>(&tile[0][0]));
-  else pairsBody<false>(d, p, blockIdx.x - compactBlocks, gridDim.x - compactBlocks, tile, pairTab, pairBuf, cellMembers);
+  // Which role takes the FIRST workgroup indices matters when the launch does not fit the chip at once (1M entities: ~512 compaction + 1041
+  // pair workgroups against 1280 resident ones at five per CU): workgroups start in index order, and the ones that do not fit start when
+  // others end.  The pair role is the long one on a world that searches (16 sectors a wave, 20-30 us), the compaction role takes ~8 us: with
+  // the compaction role first, a quarter of the pair workgroups started 8 us late and ended the kernel 8 us late (round 4; the average wave
+  // lived 32 of the kernel's 40 us on config 5).  Pair role first: every pair workgroup starts at once, the compaction workgroups that do not
+  // fit start behind the first compaction workgroups that end -- earlier compaction workgroups are always resident before later ones, which
+  // is what their look-back needs.  (Both orders behind a run-time switch doubled the kernel's code and cost every world 2-4 us.)
+  const uint32_t pairBlocks = gridDim.x - compactBlocks;
+  if (blockIdx.x < pairBlocks) pairsBody<false>(d, p, blockIdx.x, pairBlocks, tile, pairTab, pairBuf, cellMembers);
+  else compactBody<kEmit>(d, p, blockIdx.x - pairBlocks, compactBlocks, group, scratch, moved, reinterpret_cast<uint32_t*>(&tile[0][0]));
 }
 
 // ------------------------------------------------------------------------------------------
