@@ -60,6 +60,7 @@ struct ScTickContext
   int freeze = 0;
 
   uint32_t spansWanted = 1536;
+  uint32_t cus = 0;           // compute units (hipDeviceProp_t::multiProcessorCount)
   uint32_t variant = 0;       // SC_TICK_VARIANT: bit0 = chain-walk K1 instead of the wave-cooperative one
   uint32_t lastFlags = 0;
 
@@ -457,7 +458,8 @@ void fillParams(ScTickContext* c, uint32_t flags, TickParams& p, uint32_t& grid)
   p.trafficSmooth = 1.0f - std::exp(-2.5f * c->producerParam);       // smoothExp(current, target, 2.5f, dt), sc_traffic_ai.cpp:58-62, :437
   p.trafficMult = c->trafficMult;
   p.bigCap = c->cap + 8u * kBorderBigCap;
-  p.pairRunLog2 = pairRunLog2(p.binSX * p.binSZ);
+  p.cus = c->cus;
+  p.pairRun = pairRunFor(p.binSX * p.binSZ, c->cus, c->variant, false);
   p.borderRecs = c->borderRecs;
   p.halo = c->halo ? 1u : 0u;
   p.tileX = c->tileX; p.tileZ = c->tileZ; p.tilesX = c->tilesX; p.tilesZ = c->tilesZ;
@@ -684,6 +686,11 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
   if (const char* s = std::getenv("SC_TICK_VARIANT")) c->variant = (uint32_t)std::atoi(s);
 
   bool ok = bind(c);
+  if (ok) {
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cu > 0) c->cus = (uint32_t)cu;
+    else c->cus = 256u;                                   // MI355X
+  }
   if (ok) {
     // (keeping compute units out of the tick stream's reach with a CU mask, so that the RCCL kernel of the pair half finds
     //  free ones at once, was measured: 124-232 us per step against 89 -- masked queues schedule badly here)
@@ -1328,6 +1335,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
     p.homeReset = 1u;
     p.sweepOnly = worldCanPair(c) ? 0u : 1u;
     c->lastTickSweepOnly = p.sweepOnly != 0u;
+    if (p.sweepOnly) p.pairRun = pairRunFor(p.binSX * p.binSZ, c->cus, c->variant, true);
     p.fastPairs = (c->fastPairs && !p.sweepOnly) ? 1u : 0u;
     // lazy records: only while nothing but this tick's own pair search reads the bins, and that search runs before the next
     // tick rewrites the world matrices (it rebuilds unwritten records from them)

@@ -205,7 +205,8 @@ struct TickParams {
   float trafficSmooth, trafficMult;             // movers: 1 - exp(-2.5 dt) (smoothExp, sc_traffic_ai.cpp:58-62; host libm) and dbg->speedMultiplier
   uint32_t bigCap;          // entries the big list can hold (capacity + room for the neighbours' boxes): every index into it is held below this
   uint32_t ovfCap;          // entries the sector overflow list can hold
-  uint32_t pairRunLog2;     // pair role: a wave takes its sectors in runs of 2^pairRunLog2 consecutive ones (pairRunLog2())
+  uint32_t pairRun;         // pair role: a wave takes its sectors in runs of pairRun consecutive ones (pairRunFor())
+  uint32_t cus;             // compute units of the device (launch geometry)
   uint32_t homeMode;        // bins: 0 every record reserves its slot (atomics), 1 the same and the slots are remembered (learn tick),
                             // 2 records with a remembered slot are stored there directly (kHome*)
   uint32_t homeReset;       // the pair search leaves binCount / binLayers at homeCount / homeLayers instead of zero
@@ -292,7 +293,7 @@ void launchSnapshotHome(const DeviceState& d, uint32_t sectors, uint32_t n, uint
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 bool launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s, hipEvent_t done = nullptr);
-uint32_t pairRunLog2(uint32_t sectors);
+uint32_t pairRunFor(uint32_t sectors, uint32_t cus, uint32_t variant, bool sweepOnly);
 void launchCompactPairs(const DeviceState& d, const TickParams& p, uint32_t compactGrid, hipStream_t s, hipEvent_t evA = nullptr, hipEvent_t evB = nullptr);
 void launchGatherPairs(const DeviceState& d, const TickParams& p, uint32_t parity, uint2* dst, uint32_t* total, hipStream_t s);
 void launchCompactPack(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t done = nullptr);

@@ -1263,6 +1263,11 @@ __device__ __forceinline__ void rebuildHomeRecord(const DeviceState& d, const Ti
   rmin = lo; rmax = hi;
 }
 
+#ifdef SC_DIAG_WAVETIME
+// timing experiment (never in the product build): how long the sweep of every pair-role wave takes, against the slowest one
+__device__ unsigned long long g_waveDiag[40];
+__device__ uint32_t g_waveRows[8192 * 8];      // per wave: duration, fast sectors, sum S*n of them, general sectors, sum n of them, rounds, t0 - (min t0) low bits, wave id
+#endif
 // (kVocab: the vocabulary form of the lazy records, TickParams::lazy 2 -- an instance of its own, only ever the pairs-stream
 //  kernel's: with its branches merely present the in-order end-of-tick kernel ran 0.6 us (config 3) to 2.4 us (config 5) longer)
 template <bool kVocab>
@@ -1270,6 +1275,10 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
                                           float4 (*tile)[2 * kTileSlots], uint16_t* pairTab, uint2 (*pairBuf)[kWavePairBuf],
                                           unsigned long long (*cellMembers)[kCellWords])
 {
+#ifdef SC_DIAG_WAVETIME
+  const unsigned long long diagT0 = wall_clock64();
+  uint32_t diagFast = 0, diagFastWork = 0, diagGen = 0, diagGenN = 0, diagRounds = 0;
+#endif
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t waveGlobal = bid * (kTile / 64) + wave;
@@ -1297,8 +1306,10 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
 
   // the counters of the wave's FIRST 64 sectors are requested here, ahead of the workgroup's prologue (pair table, barrier): their round
   // trip runs behind it (most waves do one round; the loop below starts from these values)
-  const uint32_t runLog = p.pairRunLog2, runLen = 1u << runLog, runsPerRound = 64u >> runLog;
-  const uint32_t sector0 = ((((lane >> runLog)) * totalWaves + waveGlobal) << runLog) + ((lane + waveGlobal) & (runLen - 1u));
+  const uint32_t runLen = p.pairRun, runsPerRound = 64u / runLen;
+  const uint32_t laneRun = lane / runLen, laneOff = (lane - laneRun * runLen + waveGlobal) % runLen;      // once per wave
+  const bool laneInRound = laneRun < runsPerRound;                                                           // (64 need not be a multiple of the run)
+  const uint32_t sector0 = laneInRound ? (laneRun * totalWaves + waveGlobal) * runLen + laneOff : 0xFFFFFFFFu;
   uint32_t preCount = 0, preLay = 0, preHc = 0, preHl = 0, preCast = 0;
   if (sector0 < sectors) {
     preCount = d.binCount[sector0]; preLay = d.binLayers[sector0];
@@ -1327,13 +1338,13 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
 
   // a wave visits sectors waveGlobal, +totalWaves, ...; their counts are fetched 64 at a time (lane k
   // holds the k-th) and zeroed at once: this wave is the only consumer of those bins this tick
-  // 64 sectors per wave and round, as runs of R = 2^pairRunLog2 consecutive sectors (R = 16 on a large world): a wave's
+  // up to 64 sectors per wave and round, as runs of R = pairRun consecutive sectors (pairGeometry()): a wave's
   // counter loads and stores touch 64/R segments instead of 64 separate cache lines.  The runs of one wave are totalWaves
   // runs apart, so a dense district of the world is still spread over many waves; inside a run the lanes are rotated by the
   // wave's index, so waves that start together do not all read bins at the same offset of a 2^k-byte stride.  The launcher
   // sizes the grid so that every wave gets the same number of runs (within one): the slowest wave ends the kernel.
-  for (uint32_t round = 0; ((round * runsPerRound) * totalWaves + waveGlobal) << runLog < sectors; ++round) {
-    const uint32_t mySector = (((round * runsPerRound + (lane >> runLog)) * totalWaves + waveGlobal) << runLog) + ((lane + waveGlobal) & (runLen - 1u));
+  for (uint32_t round = 0; ((round * runsPerRound) * totalWaves + waveGlobal) * runLen < sectors; ++round) {
+    const uint32_t mySector = laneInRound ? ((round * runsPerRound + laneRun) * totalWaves + waveGlobal) * runLen + laneOff : 0xFFFFFFFFu;
     uint32_t myCount = 0, myLay = 0, myHome = 0, myCast = 0;
     bool myStale = false;
     const uint32_t myGx = mySector % p.binSX, myGz = mySector / p.binSX;     // once per 64 sectors, not once per sector
@@ -1365,6 +1376,9 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     const bool myOver = myCount > kBinCap;             // the sector holds more records than its bin: the rest is in the overflow list
     if (myOver) myCount = kBinCap;
     if (!ballot64(myCount != 0u)) continue;
+#ifdef SC_DIAG_WAVETIME
+    diagRounds += 1u;
+#endif
 
     // a ring sector on a side where a neighbour tile exists belongs to that neighbour: it reports the pairs whose low
     // corner lies there (it received these boxes through the border exchange).  Decided here, once per 64 sectors.
@@ -1425,6 +1439,9 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
         {
           const uint32_t n = info & 0xFFu, hc = (info >> 8) & 0xFFu, D = info >> 16, gxz = gxzF;
           const uint32_t V = n - hc, S = D + V;                      // visitors; sweepers
+#ifdef SC_DIAG_WAVETIME
+          diagFast += 1u; diagFastWork += S * n;
+#endif
           const float secX = (float)(gxz & 0xFFFFu), secZ = (float)(gxz >> 16);
           // (opaque here: the re-arrangement for the tile must not be moved up to the loads -- hipcc did, and waited for every load
           //  right behind its issue to shuffle the components, which left nothing in flight under the sweeps)
@@ -1596,6 +1613,9 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
         }
       }
 
+#ifdef SC_DIAG_WAVETIME
+      diagGen += 1u; diagGenN += n;
+#endif
       const uint32_t gx = gxz & 0xFFFFu, gz = gxz >> 16;
       const bool ours = (oursMask >> it) & 1ull;
       const bool valid = lane < n && ours;
@@ -1699,6 +1719,18 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       it = itNext; n = nNext; s = sNext; gxz = gxzNext; binLay = binLayNext; rmin = nmin; rmax = nmax;
     }
   }
+
+#ifdef SC_DIAG_WAVETIME
+  {
+    const unsigned long long diagT1 = wall_clock64();
+    if ((threadIdx.x & 63u) == 0u) {
+      atomicAdd(&g_waveDiag[0], diagT1 - diagT0); atomicMax(&g_waveDiag[1], diagT1 - diagT0); atomicAdd(&g_waveDiag[2], 1ull);
+      atomicMin(&g_waveDiag[3], diagT0); atomicMax(&g_waveDiag[4], diagT1); atomicMax(&g_waveDiag[5], diagT0);
+      if (waveGlobal < 8192u) { uint32_t* r = g_waveRows + 8u * waveGlobal; r[0] = (uint32_t)(diagT1 - diagT0); r[1] = diagFast; r[2] = diagFastWork; r[3] = diagGen; r[4] = diagGenN; r[5] = diagRounds; r[6] = (uint32_t)diagT0; r[7] = waveGlobal; }
+      { unsigned long long b = (diagT1 - diagT0) >> 7; if (b > 31ull) b = 31ull; atomicAdd(&g_waveDiag[8 + b], 1ull); }      // 1.28 us buckets (100 MHz)
+    }
+  }
+#endif
 
 
   // ---- crowded sectors, four waves to a sector (round 3).  A sector at the engine's own budget -- 200 boxes -- is a bin and
@@ -2758,28 +2790,39 @@ void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hip
   const uint32_t g = compactGroup(p, grid, false);
   hipLaunchKernelGGL(k_compact, dim3((grid + g - 1) / g), dim3(kTile), 0, s, d, p, g);
 }
-// Pair-role geometry: runs of R consecutive sectors (R = 16 when that still leaves ~4096 waves, smaller on smaller worlds),
-// and as many waves as give every wave the same number of runs: with W waves for U runs a wave takes ceil or floor of U / W
-// runs, and a grid just short of U (say 4096 waves for 4161 runs) would leave a few waves with twice the work of the rest --
-// measured on config 5: 80 us instead of 60 for the end-of-tick kernel.  SC_TICK_VARIANT bits 8+: workgroup cap (tuning).
-uint32_t pairRunLog2(uint32_t sectors)
+// Pair-role geometry (round 4, second form): four pair workgroups for every CU -- the fifth resident workgroup of each CU is left to the
+// compaction role, which shares the launch and comes behind the pair role in index order -- and the run as long as that needs:
+// R = ceil(sectors / waves), 17 for 258 x 258 sectors, a run per wave.  (Round 3: runs of 2^k sectors and as many waves as runs, 1041
+// workgroups for that world, a few CUs with five.)  What tools/wave_time.py shows of a searching world (-DSC_DIAG_WAVETIME): every wave
+// starts within a microsecond, waves with the SAME work end anywhere between 0.1 and 1.0 of the role's span, in the order of their
+// indices -- a SIMD serves its oldest wave first -- and the oldest wave of a SIMD gets through its sectors in a tenth of the span: the
+// SIMDs are busy throughout, the role is bound by what its four or five waves per SIMD issue together, not by a slow wave.  Hence no
+// gain from the evener spread itself (config 5: 34.0 us against 33.8, 37.4 with three workgroups per CU, 34.8 with five; config3dyn 23.2
+// / 24.4 / 23.1: profiles/r04/ab_pair_geometry.log); the form stays because it keeps the compaction workgroups resident from the start.
+// A world the host knows cannot pair (TickParams::sweepOnly) is a sweep over counters: runs of 64, about one workgroup per CU (the
+// per-workgroup prologue is what that role costs).  SC_TICK_VARIANT bits 8+: workgroups (tuning).
+uint32_t pairRunFor(uint32_t sectors, uint32_t cus, uint32_t variant, bool sweepOnly)
 {
-  uint32_t lg = 4;
-  while (lg > 0 && (sectors >> lg) < 4096u) --lg;
-  return lg;
+  if (!cus) cus = 256u;
+  uint32_t wgs = (variant >> 8) ? (variant >> 8) : (sweepOnly ? cus : 4u * cus);
+  wgs = std::min(wgs, kOvfWaves / (kTile / 64u));
+  const uint32_t waves = wgs * (kTile / 64u);
+  const uint32_t run = (sectors + waves - 1u) / waves;
+  return std::max(1u, std::min(run, 64u));
 }
 static uint32_t pairGridFor(const TickParams& p)
 {
   const uint32_t sectors = p.binSX * p.binSZ;
-  const uint32_t runs = (sectors + (1u << p.pairRunLog2) - 1u) >> p.pairRunLog2;
-  // (workgroups: as many as give every wave ONE round of 64 sectors where sectors hold work -- a heavy sector then delays one wave's
-  //  single round, not a queue of rounds: 768 workgroups cost config 5 49.2 us against 40.5, 256 cost 100.  Where the host knows that
-  //  nothing in the world can pair (TickParams::sweepOnly: an all-static city) the role is a sweep over counters, its per-workgroup
-  //  prologue -- pair table, barrier -- is what it costs, and a quarter of the workgroups do four rounds each: config 3's end of tick
-  //  8.7 us against 9.3.  profiles/r04/ab_pair_grid.log)
-  const uint32_t capWaves = std::min(((p.variant >> 8) ? (p.variant >> 8) : (p.sweepOnly ? 256u : 2048u)) * (kTile / 64u), kOvfWaves);
-  const uint32_t rounds = (runs + capWaves - 1u) / capWaves;
-  const uint32_t waves = (runs + rounds - 1u) / rounds;
+  const uint32_t run = std::max(1u, p.pairRun);
+  const uint32_t runs = (sectors + run - 1u) / run;
+  // (a wave takes 64 / run runs per round; the grid gives every wave the same number of rounds, within one)
+  const uint32_t perRound = 64u / run;
+  const uint32_t cap = std::min(((p.variant >> 8) ? (p.variant >> 8) : (p.sweepOnly ? 2u * p.cus : 4u * p.cus)) * (kTile / 64u), kOvfWaves);      // (sweep: runs of 64 are capped, leave room for the odd run)
+  uint32_t waves = runs;                                   // a run per wave where the waves suffice (pairRunFor sized the run for that)
+  if (runs > std::max(cap, 1u)) {
+    const uint32_t rounds = (runs + cap * perRound - 1u) / (cap * perRound);
+    waves = (runs + rounds * perRound - 1u) / (rounds * perRound);
+  }
   return std::max(1u, (waves + kTile / 64u - 1u) / (kTile / 64u));
 }
 // `done` (may be null): recorded by the dispatch itself; false = nothing launched (no sectors)
@@ -2895,3 +2938,22 @@ void launchEmitDraws(const DeviceState& d, uint32_t budget, void* items, hipStre
 }
 
 } // namespace sctick
+
+#ifdef SC_DIAG_WAVETIME
+extern "C" int scTickDiagWaveTime(unsigned long long out[40], int reset)
+{
+  using namespace sctick;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_waveDiag), sizeof(unsigned long long) * 40) != hipSuccess) return 0;
+  if (reset) {
+    unsigned long long z[40] = {0};
+    z[3] = ~0ull;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_waveDiag), z, sizeof z) != hipSuccess) return 0;
+  }
+  return 1;
+}
+extern "C" int scTickDiagWaveRows(uint32_t* out, uint32_t waves)
+{
+  using namespace sctick;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_waveRows), sizeof(uint32_t) * 8u * (waves < 8192u ? waves : 8192u)) == hipSuccess ? 1 : 0;
+}
+#endif
