@@ -2186,9 +2186,10 @@ __global__ __launch_bounds__(kTile) void k_compact_pack(const DeviceState d, con
   __shared__ uint32_t scratch[kTile / 64];
   __shared__ uint32_t moved[kMaxSpanWords];
   __shared__ uint32_t words[kCompactLdsWords];
-  if (blockIdx.x == 0 && (p.flags & kFlagDeferredReset)) resetParity(d, p.resetParity);      // pipelined tiles: next tick's counters
-  if (blockIdx.x < compactBlocks) compactBody<false>(d, p, blockIdx.x, compactBlocks, group, scratch, moved, words);
-  else borderPackBody(d, p, blockIdx.x - compactBlocks);
+  // (the eight pack workgroups take the first indices: theirs is the longer chain of round trips, and the exchange waits for them)
+  if (blockIdx.x == 8u && (p.flags & kFlagDeferredReset)) resetParity(d, p.resetParity);      // pipelined tiles: next tick's counters
+  if (blockIdx.x < 8u) borderPackBody(d, p, blockIdx.x);
+  else compactBody<false>(d, p, blockIdx.x - 8u, compactBlocks, group, scratch, moved, words);
 }
 
 __global__ __launch_bounds__(kTile) void k_border_merge(const DeviceState d, const TickParams p)
