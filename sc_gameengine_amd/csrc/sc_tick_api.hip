@@ -521,7 +521,7 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     if (p.homeMode == kHomeLearn) {
       // the slots handed out by the fused kernel are the remembered ones (the level kernels' and the neighbours' records reserve
       // behind them on every tick); the other copies of the bins start their next tick from the same counts
-      launchSnapshotHome(ds, c->sectors, c->n, p.binSX, p.binSZ, (c->pairsStream && c->worldLayersKnown) ? 1u : 0u, c->worldLayers, c->stream);
+      launchSnapshotHome(ds, c->sectors, c->n, p.binSX, p.binSZ, (c->pairsStream && c->worldLayersKnown) ? 1u : 0u, c->worldLayers, p.fastPairs, c->stream);
       if (c->pairsStream)
         for (uint32_t q = 0; q < c->pipeDepth; ++q) {
           if (q == p.parity) continue;

@@ -289,7 +289,7 @@ void launchOccupancy(const DeviceState& d, uint32_t n, const float4* q, uint32_t
 
 // launchers (sc_tick_kernels.hip)
 void launchXformCull(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s, hipEvent_t evA = nullptr, hipEvent_t evB = nullptr);
-void launchSnapshotHome(const DeviceState& d, uint32_t sectors, uint32_t n, uint32_t binSX, uint32_t binSZ, uint32_t vocabMode, uint32_t vocab, hipStream_t s);
+void launchSnapshotHome(const DeviceState& d, uint32_t sectors, uint32_t n, uint32_t binSX, uint32_t binSZ, uint32_t vocabMode, uint32_t vocab, uint32_t ordered, hipStream_t s);
 void launchDeepLevel(const DeviceState& d, const TickParams& p, const uint32_t* levelList, uint32_t count, hipStream_t s);
 void launchCompact(const DeviceState& d, const TickParams& p, uint32_t grid, hipStream_t s);
 bool launchPairs(const DeviceState& d, const TickParams& p, hipStream_t s, hipEvent_t done = nullptr);

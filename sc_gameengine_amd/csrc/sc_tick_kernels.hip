@@ -2685,7 +2685,7 @@ __global__ __launch_bounds__(kTile) void k_order_home(const DeviceState d, uint3
 // some record that can exist anywhere in the world could pass the filter against one of the bin's own -- the bins that fail THAT
 // test are never read by anybody, on any tick, so they need no rebuild either (which a pipelined pair half could not do: the
 // owners' matrices are the next tick's by then).
-__global__ __launch_bounds__(kTile) void k_home_flags(const DeviceState d, uint32_t n, uint32_t binSX, uint32_t binSZ, uint32_t vocabMode, uint32_t vocab)
+__global__ __launch_bounds__(kTile) void k_home_flags(const DeviceState d, uint32_t n, uint32_t binSX, uint32_t binSZ, uint32_t vocabMode, uint32_t vocab, uint32_t ordered)
 {
   const uint32_t i = blockIdx.x * kTile + threadIdx.x;
   if (i >= n) return;
@@ -2698,7 +2698,8 @@ __global__ __launch_bounds__(kTile) void k_home_flags(const DeviceState d, uint3
     if (byte == kNoSlot) continue;
     const uint32_t sec = hA + (k & 1u) + (k >> 1) * binSX;
     // the slot the record was moved to when its bin was put in order (k_order_home)
-    hB = (hB & ~(0xFFu << (8u * k))) | ((uint32_t)d.homePerm[(size_t)sec * kBinCap + (byte & kSlotMask)] << (8u * k));
+    // (not on a world whose bins were left in the order of arrival: nothing can pair there, or the fast sectors are switched off)
+    if (ordered) hB = (hB & ~(0xFFu << (8u * k))) | ((uint32_t)d.homePerm[(size_t)sec * kBinCap + (byte & kSlotMask)] << (8u * k));
     const uint32_t H = d.homeLayers[sec];
     if (binWrittenEveryTick(vocabMode ? layersThatCanMeet(H, vocab) : H, sec, binSX, binSZ)) hB |= kSlotAlways << (8u * k);
   }
@@ -2708,12 +2709,14 @@ __global__ __launch_bounds__(kTile) void k_home_flags(const DeviceState d, uint3
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-void launchSnapshotHome(const DeviceState& d, uint32_t sectors, uint32_t n, uint32_t binSX, uint32_t binSZ, uint32_t vocabMode, uint32_t vocab, hipStream_t s)
+void launchSnapshotHome(const DeviceState& d, uint32_t sectors, uint32_t n, uint32_t binSX, uint32_t binSZ, uint32_t vocabMode, uint32_t vocab, uint32_t ordered, hipStream_t s)
 {
   if (!sectors) return;
   hipLaunchKernelGGL(k_snapshot_home, dim3((sectors + kTile - 1) / kTile), dim3(kTile), 0, s, d, sectors);
-  hipLaunchKernelGGL(k_order_home, dim3((sectors + kTile / 64u - 1) / (kTile / 64u)), dim3(kTile), 0, s, d, sectors);
-  if (n) hipLaunchKernelGGL(k_home_flags, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, binSX, binSZ, vocabMode, vocab);
+  // (ordered = this learn period's pair search takes fast sectors, TickParams::fastPairs: only then are the bins put in cast-first order)
+  if (ordered) hipLaunchKernelGGL(k_order_home, dim3((sectors + kTile / 64u - 1) / (kTile / 64u)), dim3(kTile), 0, s, d, sectors);
+  else if (d.homeCast) (void)hipMemsetAsync(d.homeCast, 0, (size_t)sectors * sizeof(uint32_t), s);      // no bin is a fast sector until a learn tick orders it (should the pair search ask in between)
+  if (n) hipLaunchKernelGGL(k_home_flags, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, s, d, n, binSX, binSZ, vocabMode, vocab, ordered);
 }
 // `done` (may be null): recorded by the dispatch itself -- the event the copy stream waits for, without a marker packet
 void launchEmitDrawsStaged(const DeviceState& d, uint32_t budget, uint32_t* block, uint32_t maxVisible, uint64_t tick, hipStream_t s, hipEvent_t done)
