@@ -28,6 +28,11 @@ struct EventPair { hipEvent_t a = nullptr, b = nullptr; };
 
 } // namespace
 
+// SC_TICK_HOSTPROBE=1: where scTickRun's host time goes (printed when the context is destroyed; a development aid)
+struct HostProbe { double acc[8] = {0}; uint64_t n = 0; bool on = false; };
+static HostProbe g_probe;
+static inline double probeNow() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct ScTickContext
 {
   ScTickContextDesc desc{};
@@ -475,7 +480,15 @@ void waitParityFree(ScTickContext* c, const TickParams& p)
   const uint32_t q = p.resetParity;
   if (!(p.flags & kFlagDeferredReset) || !c->pairsInFlight[q]) return;
   // (a queue-to-queue wait costs a bubble of ~10 us on the device even when it is already satisfied: ask first)
-  if (hipEventQuery(c->pairsDone[q]) != hipSuccess) hipStreamWaitEvent(c->stream, c->pairsDone[q], 0);
+  if (hipEventQuery(c->pairsDone[q]) != hipSuccess) {
+    // The host is usually ahead of the device here (the flow is device-bound), so the pair half of pipeDepth - 1 ticks ago has often not ended
+    // when this tick is issued -- and the queue-to-queue wait then sits in front of this tick's fused kernel on every step: 4-5 us of
+    // bubble on the tick stream (tools/trace_timeline.py).  The HOST waits instead (round 4): no tick is issued more than pipeDepth - 1
+    // ticks ahead of a finished pair half, the tick stream never sees a barrier, and with the tick before this one already queued the
+    // device does not run dry.  (SC_TICK_VARIANT bit 7: the device-side wait of before, for an A/B.)
+    if (c->variant & 128u) hipStreamWaitEvent(c->stream, c->pairsDone[q], 0);
+    else (void)hipEventSynchronize(c->pairsDone[q]);
+  }
   (void)hipGetLastError();                        // hipErrorNotReady from the query is not an error
   c->pairsInFlight[q] = false;
 }
@@ -517,7 +530,7 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
       const EventPair ev = takeEvents(c);
       launchXformCull(ds, p, grid, c->stream, ev.a, ev.b);
       c->times[SC_TICK_K_XFORM_CULL].push_back(ev);
-    } else launchXformCull(ds, p, grid, c->stream);
+    } else { const double q0 = g_probe.on ? probeNow() : 0.0; launchXformCull(ds, p, grid, c->stream); if (g_probe.on) g_probe.acc[3] += probeNow() - q0; }
     if (p.homeMode == kHomeLearn) {
       // the slots handed out by the fused kernel are the remembered ones (the level kernels' and the neighbours' records reserve
       // behind them on every tick); the other copies of the bins start their next tick from the same counts
@@ -588,7 +601,9 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
       Scoped s(c, SC_TICK_K_COMPACT);
       // pipelined tile, eager: the `packed` event rides on the dispatch (publishPacked then only makes the pairs stream wait)
       const bool ride = c->pairsStream && !c->capturing && !s.on && (c->variant & 4u) == 0u;
+      const double q0 = g_probe.on ? probeNow() : 0.0;
       launchCompactPack(ds, p, grid, c->stream, ride ? c->packed[p.parity] : nullptr);      // compaction and pack share a launch
+      if (g_probe.on) g_probe.acc[4] += probeNow() - q0;
       c->packedRides = ride;
     } else if (needCompact) {
       Scoped s(c, SC_TICK_K_COMPACT);
@@ -749,6 +764,7 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
   }
   if (c->variant & 32u) c->lazyEnabled = false;         // SC_TICK_VARIANT bit 5: every remembered slot is written on every tick (A/B)
   if (c->variant & 2u) c->homeEnabled = false;          // SC_TICK_VARIANT bit 1: every record reserves its slot on every tick (A/B)
+  if (std::getenv("SC_TICK_HOSTPROBE")) g_probe.on = true;
   if (const char* fp = std::getenv("SC_TICK_FAST_PAIRS")) c->fastPairs = std::atoi(fp) != 0;      // 0: every bin goes through the general pair search (A/B)
   if (const char* hp = std::getenv("SC_TICK_HOME_PERIOD")) { const int v = std::atoi(hp); if (v > 0) c->homePeriod = (uint32_t)v; }
   if (ok && c->sectors) { e = hipMemset(d.ovfLo, 0xFF, (size_t)c->sectors * sizeof(uint32_t)); if (e != hipSuccess) ok = fail(c, "hipMemset", e); }
@@ -771,6 +787,11 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
 
 void scTickDestroyContext(ScTickContext* c)
 {
+  if (g_probe.on && g_probe.n) {
+    std::fprintf(stderr, "[sc_tick host probe] %llu ticks: waitParityFree %.2f us, enqueueStages %.2f (fused launch %.2f, compaction+pack launch %.2f), publishPacked %.2f\n", (unsigned long long)g_probe.n,
+                 g_probe.acc[0] / g_probe.n, g_probe.acc[1] / g_probe.n, g_probe.acc[3] / g_probe.n, g_probe.acc[4] / g_probe.n, g_probe.acc[2] / g_probe.n);
+    g_probe = HostProbe(); g_probe.on = true;
+  }
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
@@ -1291,6 +1312,7 @@ static bool worldCanPair(ScTickContext* c)
 int scTickRun(ScTickContext* c, uint32_t flags)
 {
   if (!c) return 0;
+  const double prA = g_probe.on ? probeNow() : 0.0;
   if (!bind(c)) return 0;
   if (!flushLinks(c)) return 0;
   if ((flags & SC_TICK_BROADPHASE) && c->desc.tile_sectors_x == 0) return fail(c, "broadphase requested but the context has no tile rectangle");
@@ -1367,7 +1389,10 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   const uint32_t q = (flags & SC_TICK_BROADPHASE) ? c->parity : 0u;
   const bool sampledTick = c->profiling && (c->tickIndex % c->profPeriod) == 0;     // events need eager launches
   c->lastTickSampled = sampledTick;
+  const double pr0 = g_probe.on ? probeNow() : 0.0;
+  if (g_probe.on) g_probe.acc[5] += pr0 - prA;
   waitParityFree(c, p);
+  const double pr1 = g_probe.on ? probeNow() : 0.0;
   if (c->graphMode && !sampledTick && !c->lastTickLearn) {
     const bool stale = !c->graphExec[q] || c->graphEpoch[q] != c->topoEpoch || std::memcmp(&p, &c->graphParams[q], sizeof p) != 0 || c->graphWhole[q] != c->captureWholeStep;
     if (stale) {
@@ -1393,7 +1418,10 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   } else {
     enqueueStages(c, p, grid, true);
   }
+  const double pr2 = g_probe.on ? probeNow() : 0.0;
   publishPacked(c, p);
+  double prEnd = 0.0;
+  if (g_probe.on) { const double pr3 = probeNow(); g_probe.acc[0] += pr1 - pr0; g_probe.acc[1] += pr2 - pr1; g_probe.acc[2] += pr3 - pr2; g_probe.n++; prEnd = pr3; }
   if (flags & SC_TICK_BROADPHASE) {
     const bool pairHalfDone = c->graphMode && !sampledTick && !c->lastTickLearn && c->captureWholeStep;
     if ((flags & SC_TICK_SPLIT_PAIRS) && !pairHalfDone) { c->pairsPending = true; c->pendingParams = p; }
@@ -1401,6 +1429,7 @@ int scTickRun(ScTickContext* c, uint32_t flags)
   }
   c->tickIndex++;
   const hipError_t e = hipGetLastError();
+  if (g_probe.on) g_probe.acc[6] += probeNow() - prEnd;
   if (e != hipSuccess) return fail(c, "kernel launch", e);
   return 1;
 }
@@ -2447,6 +2476,12 @@ int scTickGetCommInfo(ScTickContext* c, ScTickCommInfo* out)
   }
   if (c->comm) { std::string why; if (const RcclApi* r = rccl(&why)) { int v = 0; if (r->GetVersion(&v) == ncclSuccess) out->rccl_version = (uint32_t)v; } }
   out->host_steps = c->hostSteps;
+  if (g_probe.on && g_probe.n) {
+    std::fprintf(stderr, "[sc_tick host probe] %llu ticks since the reset: waitParityFree %.2f us, enqueueStages %.2f (fused launch %.2f, compaction+pack launch %.2f), publishPacked %.2f, before %.2f, after %.2f\n",
+                 (unsigned long long)g_probe.n, g_probe.acc[0] / g_probe.n, g_probe.acc[1] / g_probe.n, g_probe.acc[3] / g_probe.n, g_probe.acc[4] / g_probe.n, g_probe.acc[2] / g_probe.n,
+                 g_probe.acc[5] / g_probe.n, g_probe.acc[6] / g_probe.n);
+    g_probe = HostProbe(); g_probe.on = true;
+  }
   out->host_tick_half_us = c->hostSteps ? c->hostAcc[0] / (double)c->hostSteps : 0.0;
   out->host_pair_half_us = c->hostSteps ? c->hostAcc[1] / (double)c->hostSteps : 0.0;
   return 1;
@@ -2483,6 +2518,7 @@ int scTickResetHostTimes(ScTickContext* c)
 {
   if (!c) return 0;
   c->hostAcc[0] = c->hostAcc[1] = 0.0; c->hostSteps = 0;
+  if (g_probe.on) { g_probe = HostProbe(); g_probe.on = true; }
   return 1;
 }
 

@@ -1465,6 +1465,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
             // record in registers, each sweeper's xz rectangle is read into scalar registers (v_readlane) and tested by all lanes at
             // once -- four compares with a scalar operand, AND-ed as wave masks with the lanes the sweeper has to meet: a cast record
             // the slots behind it, a visitor the rest and the visitors behind it.  A touch (rare) is followed up on the spot, from registers.
+#pragma clang loop unroll(disable)
             for (uint32_t k = 0; k < S; ++k) {
               const uint32_t sl = k < D ? k : hc + (k - D);
               unsigned long long meet = ~((2ull << sl) - 1ull);

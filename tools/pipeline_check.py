@@ -58,6 +58,7 @@ for pipelined in (0, 2, 3, 4):
     for _ in range(30):
         t.tile_step(flags)
     t.sync()
+    t.reset_host_times()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         t.tile_step(flags)
@@ -67,6 +68,9 @@ for pipelined in (0, 2, 3, 4):
     key = f"pipelined_depth{pipelined}" if pipelined else "in_order"
     out[key + "_us_per_step"] = round(total / args.steps * 1e6, 2)
     out[key + "_host_issue_us"] = round(issued / args.steps * 1e6, 2)
+    ci = t.comm_info()                                     # the library's own clock around each half of the step (scTickGetCommInfo)
+    out[key + "_host_tick_half_us"] = round(ci["host_tick_half_us"], 2)
+    out[key + "_host_pair_half_us"] = round(ci["host_pair_half_us"], 2)
     # host issue alone, with the device idle between steps (the queue never fills up: what the call itself costs)
     lone = []
     for _ in range(50):
