@@ -46,7 +46,7 @@ def short(name):
 
 
 # pass boundaries by the fused kernel's launch index (the secondary legs of the line, if present, come after these)
-bounds = [("warmup", args.warmup), ("timed_region", args.steps), ("every_launch_pass", every), ("end_to_end_warmup", args.warmup), ("end_to_end_pass", args.steps)]
+bounds = [("warmup", args.warmup), ("timed_region", args.steps), ("every_launch_pass", every), ("end_to_end_warmup", max(args.warmup, 10)), ("end_to_end_pass", max(args.steps, 200))]      # (bench.py: that leg is at least 10 + 200 steps long)
 edges, at = [], 0
 for name, n in bounds:
     edges.append((name, at, at + n)); at += n
