@@ -151,7 +151,8 @@ def run_tiles(oracle, w, grid, S, steps=2, nudge=0.9, border_capacity=None, max_
         wkey = want[:, 0].astype(np.uint64) << np.uint64(32) | want[:, 1].astype(np.uint64)
         assert len(key) == len(np.unique(key)), "a pair was reported twice"
         missing, extra = np.setdiff1d(wkey, key), np.setdiff1d(key, wkey)
-        assert len(missing) == 0 and len(extra) == 0, f"step {step}: {len(missing)} pairs missing, {len(extra)} unexpected of {len(wkey)}"
+        assert len(missing) == 0 and len(extra) == 0, (f"step {step}: {len(missing)} pairs missing, {len(extra)} unexpected of {len(wkey)}; "
+                                                       f"border_lost per tile {[int(c.border_lost) for c in counts]}")
     for t in ticks:
         t.close()
     ow.close()
@@ -226,6 +227,28 @@ def test_crowded_sectors_on_tile_edges_lose_nothing(oracle, grid, K):
     assert sum(c.bin_overflow for c in counts) > 500                 # the overflow lists really carry records
     crossing = (want[:, 0] // n) != (want[:, 1] // n)
     assert crossing.sum() > 200
+
+
+@pytest.mark.parametrize("capacity", [1, 5, 16])
+def test_a_long_border_with_fewer_than_four_fixed_slots_per_cell(oracle, capacity):
+    """Round 4's message layout gives every ring cell up to four FIXED record slots and packs the rest into a shared spill-over area.
+    On a 600-sector border with a capacity of ONE record per cell on average a cell owns one fixed slot (borderFixedSlots: 1 088
+    records for 602 cells) and every cell that holds more goes through the spill-over path (486 records); with 5 or 16 the cells own
+    four and the spill-over area is rarely needed: same pair set, nothing lost."""
+    S, grid = (600, 2), (1, 2)
+    w = sw.generate(S[0] * grid[0], S[1] * grid[1], 4, tiles=grid, ground=False)      # (ground slabs alone would put two records into every ring cell)
+    rng = np.random.default_rng(41)
+    dyn = rng.random(w.n) < 0.5
+    w.group[dyn], w.mask[dyn] = sw.GROUP_DYNAMIC, sw.MASK_ALL
+    roots = np.flatnonzero(w.parent < 0)
+    TH = 64.0 * S[1]
+    e = rng.choice(roots, len(roots) // 4, replace=False)          # boxes onto the 600-sector edge: most cells hold 0-2 records, some more
+    w.pos[e, 2] = (np.round(w.pos[e, 2] / TH) * TH + rng.uniform(-1.0, 1.0, len(e))).astype(np.float32)
+    counts, want, n = run_tiles(oracle, w, grid, S, steps=3, nudge=0.4, border_capacity=capacity, max_pairs=1 << 20)
+    assert all(c.pairs_truncated == 0 for c in counts)
+    assert all(c.border_lost == 0 for c in counts)
+    crossing = (want[:, 0] // n) != (want[:, 1] // n)
+    assert crossing.sum() > 5, crossing.sum()
 
 
 def test_border_capacity_is_validated():
