@@ -687,11 +687,14 @@ def main():
                 "control_plane": args.control if world_size > 1 else None,
                 "rehearsal_same_device": bool(args.same_device),
                 # the bins' remembered slots are relearned every `period` broadphase ticks (SC_TICK_HOME_PERIOD, default 64): that tick
-                # reserves every slot with atomics again and runs three small kernels behind the fused one (slot counts, the bins'
-                # cast-first order, the slots' flags) -- about 25 us more than an ordinary tick at 1M entities (profiles/r04:
-                # the k_xform_cull<..., 1u> row and k_snapshot_home / k_order_home / k_home_flags), i.e. ~0.4 us per step amortised
+                # reserves every slot with atomics again and runs two or three small kernels behind the fused one (slot counts, the
+                # bins' cast-first order where the pair search takes fast sectors, the slots' flags)
                 "learn_tick": {"period": int(os.environ.get("SC_TICK_HOME_PERIOD", "64")), "learn_ticks_inside_the_timed_region": int(learn_in_region),
-                               "timed_steps": args.steps},
+                               "timed_steps": args.steps,
+                               "cost": "at 1M entities a learn tick takes ~24 us more than an ordinary one on a world that cannot pair (the fused kernel's learn "
+                                       "instance +10, k_snapshot_home 5, k_home_flags 9) and ~45 us more on a searching world (+ k_order_home 17-20): the "
+                                       "k_xform_cull<..., 1u> / k_snapshot_home / k_order_home / k_home_flags rows of profiles/r04/<workload>_kernel_stats.csv; "
+                                       "0.4-0.7 us per step amortised, inside the timed region only when learn_ticks_inside_the_timed_region > 0"},
                 # the host's launch-shape hint (scTickGetBinStats bit 2): no two layer words of this world admit a pair, so the pair role of
                 # the end-of-tick kernel is sized as a sweep over the bins' counters (256 workgroups instead of 1041); the search is unchanged
                 "pair_role_sweep_only": bool(t.bin_stats()["pair_role_sweep_only"]) if (flags & capi.BROADPHASE) else None,
