@@ -1424,13 +1424,17 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
       // (Deeper prefetch -- three register sets, loads and waits written by hand because hipcc waits with vmcnt(0) -- was built and
       //  measured: no gain, the role is held by instruction issue, not by the records' latency; profiles/r04/ab_fast_sectors.log.)
       float4 lo, hi; uint32_t info, gxzF;
+      // (a sector's three numbers are packed in its lane once per round, so a fetch is three cross-lane reads and two scalar selects:
+      //  with the packing and the "no sector left" case inside, it was five reads, a handful of scalar shifts and three branches per sector)
+      const uint32_t myInfo = myCount | (myHome << 8) | ((myCast & 0xFFu) << 16);
       auto fetch = [&]() __attribute__((always_inline)) {
         const bool more = restF != 0ull;
         const int itF = more ? __ffsll((long long)restF) - 1 : 0;
         restF &= restF - 1ull;
-        const uint32_t nF = more ? __builtin_amdgcn_readlane(myCount, itF) : 0u, sF = __builtin_amdgcn_readlane(mySector, itF);
-        info = more ? (nF | (__builtin_amdgcn_readlane(myHome, itF) << 8) | ((__builtin_amdgcn_readlane(myCast, itF) & 0xFFu) << 16)) : 0u;
+        const uint32_t pk = __builtin_amdgcn_readlane(myInfo, itF), sF = __builtin_amdgcn_readlane(mySector, itF);
         gxzF = __builtin_amdgcn_readlane(myGxz, itF);
+        info = more ? pk : 0u;
+        const uint32_t nF = info & 0xFFu;
         const float4* r = lane < nF ? d.bins + 2u * ((size_t)sF * kBinCap + lane) : d.nullRec;
         lo = r[0]; hi = r[1];
       };
