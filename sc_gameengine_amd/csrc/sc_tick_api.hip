@@ -761,6 +761,18 @@ ScTickContext* scTickCreateContext(const ScTickContextDesc* desc)
       ok = h2d(c, nr, words, sizeof words) && sync(c);
       d.nullRec = nr;
     }
+    // the pair role's constant tables (sc_tick_kernels.hip: pairsBody's prologue copies them into LDS)
+    uint32_t* pc = nullptr;
+    ok = ok && dalloc(c, pc, kPairConstWords);
+    if (ok) {
+      std::vector<uint32_t> words(kPairConstWords, 0u);
+      uint16_t* tab = reinterpret_cast<uint16_t*>(words.data());
+      for (uint32_t i = 1; i < kBinCap; ++i)
+        for (uint32_t j = 0; j < i; ++j) tab[i * (i - 1u) / 2u + j] = (uint16_t)(i << 8 | j);
+      for (uint32_t t = 1; t <= kBinCap; ++t) { const uint32_t G = 64u / t; words[kPairConstCast + t] = G | ((65536u / G + 1u) << 8); }
+      ok = h2d(c, pc, words.data(), words.size() * sizeof(uint32_t)) && sync(c);
+      d.pairConst = pc;
+    }
   }
   if (c->variant & 32u) c->lazyEnabled = false;         // SC_TICK_VARIANT bit 5: every remembered slot is written on every tick (A/B)
   if (c->variant & 2u) c->homeEnabled = false;          // SC_TICK_VARIANT bit 1: every record reserves its slot on every tick (A/B)

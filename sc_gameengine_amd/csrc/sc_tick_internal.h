@@ -110,6 +110,7 @@ struct DeviceState {
   // nothing but its reserved records on a later tick is then searched without classifying anything: the cast records are slots
   // [0, D), everything else behind them (k_order_home, "fast sectors" in the pair role).
   uint32_t* homeCast;          // [sectors] bits 0..7: D, cast records among the reserved slots; kCastFast: the rest cannot meet each other
+  const uint32_t* pairConst;   // what every pair-role workgroup copies into LDS: words [0, 1008) the triangular pair table (2016 x uint16), [kPairConstCast, +65) the cast table
   const float4* nullRec;       // one null record (nullRecord(): inverted box, layers 0) for lanes that have no bin slot to load
   uint8_t* homePerm;           // [sectors][kBinCap] learn tick only: slot a reserved record moved to (k_home_flags re-numbers homeB through it)
   // Lazy records (round 3): a bin whose reserved records cannot pass the group/mask filter against each other is read by the
@@ -154,6 +155,8 @@ struct DeviceState {
 // them the spill-over area (what cells hold beyond their fixed slots, packed cell after cell); then the big-box section:
 // [0] boxes, [1] overflow flag, boxes (8 words each); then, with traffic sensors on a tiled world, the halo section.
 // L = sectors on that ring side.
+constexpr uint32_t kPairConstCast = 1008;      // DeviceState::pairConst: first word of the cast table
+constexpr uint32_t kPairConstWords = 1076;     // (padded to 16 bytes)
 constexpr uint32_t kBorderHeader = 2;
 constexpr uint32_t kBorderRecsPerBin = 16;    // default: a message holds L * 16 records (shared by the side's sectors: a crowded ring sector
                                               // may take more than its share), at least one full sector; scTickSetBorderCapacity raises it

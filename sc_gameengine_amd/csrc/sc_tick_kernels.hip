@@ -1317,9 +1317,11 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
     if (p.fastPairs) preCast = d.homeCast[sector0];
   }
 
-  // triangular pair table, built once per workgroup (row i starts at i(i-1)/2)
-  for (uint32_t i = 1u + threadIdx.x / 64u * 16u; i < kBinCap && i < 17u + threadIdx.x / 64u * 16u; ++i)
-    for (uint32_t j = lane; j < i; j += 64u) pairTab[i * (i - 1u) / 2u + j] = (uint16_t)(i << 8 | j);
+  // triangular pair table (row i starts at i(i-1)/2; entry = i << 8 | j): the same 4 KB for every workgroup of every launch, so it is
+  // COPIED from a constant block the context made once (DeviceState::pairConst) -- one 16-byte load and store per thread -- instead of
+  // being built by every workgroup (16 rows per wave: ~130 wave-instructions of prologue, which is what a world with little to search pays for)
+  static_assert(kPairTabSize * sizeof(uint16_t) == 252u * 16u, "the copy below moves the table as 252 x 16 bytes");
+  if (threadIdx.x < 252u) reinterpret_cast<uint4*>(pairTab)[threadIdx.x] = reinterpret_cast<const uint4*>(d.pairConst)[threadIdx.x];
 
   // broadcast path: with D records to cast, lane l plays (record l / G, partner phase l % G), G = 64 / D; the division by
   // the wave-uniform G is a multiplication by ceil(2^16 / G) (exact for l < 64)
@@ -1329,7 +1331,7 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
   // "crowded sectors" below)
   __shared__ uint32_t crowdGathered, crowdItem, crowdLayers;
   if (threadIdx.x == 0) { crowdGathered = 0u; crowdLayers = 0u; }
-  if (threadIdx.x >= 1u && threadIdx.x <= kBinCap) { const uint32_t G = 64u / threadIdx.x; castTab[threadIdx.x] = G | ((65536u / G + 1u) << 8); }
+  if (threadIdx.x <= kBinCap) castTab[threadIdx.x] = d.pairConst[kPairConstCast + threadIdx.x];      // (G | ceil(2^16 / G) << 8 for G = 64 / D: the same block)
 
   // next tick's counter set starts clean (pipelined tiles do this in the end-of-tick kernel on the tick stream instead:
   // there the next tick's fused kernel may already be filling it while this pair search runs)
@@ -1912,7 +1914,7 @@ template <bool kVocab>
 __global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_pairs(const DeviceState d, const TickParams p)
 {
   __shared__ float4 tile[kTile / 64][2 * kTileSlots];     // 2 KiB per wave: the bin as an LDS tile (+ a null record)
-  __shared__ uint16_t pairTab[kPairTabSize];              // q -> (i << 8 | j), 0 <= j < i < 64
+  __shared__ __attribute__((aligned(16))) uint16_t pairTab[kPairTabSize];              // q -> (i << 8 | j), 0 <= j < i < 64
   __shared__ uint2 pairBuf[kTile / 64][kWavePairBuf];     // 2 KiB per wave: hits waiting for a flush
   __shared__ unsigned long long cellMembers[kTile / 64][kCellWords];   // per wave: which records touch each of the 4x4 cells, per tile of 64
   pairsBody<kVocab>(d, p, blockIdx.x, gridDim.x, tile, pairTab, pairBuf, cellMembers);
@@ -1943,7 +1945,7 @@ template <bool kEmit>
 __global__ __launch_bounds__(kTile) SC_PAIR_OCC void k_compact_pairs(const DeviceState d, const TickParams p, uint32_t compactBlocks, uint32_t group)
 {
   __shared__ float4 tile[kTile / 64][2 * kTileSlots];
-  __shared__ uint16_t pairTab[kPairTabSize];
+  __shared__ __attribute__((aligned(16))) uint16_t pairTab[kPairTabSize];
   __shared__ uint2 pairBuf[kTile / 64][kWavePairBuf];
   __shared__ unsigned long long cellMembers[kTile / 64][kCellWords];
   __shared__ uint32_t scratch[kTile / 64];
