@@ -1537,6 +1537,9 @@ __device__ __forceinline__ void pairsBody(const DeviceState& d, const TickParams
                 cnt += (uint32_t)__popcll(m);
               }
               // the touching pairs of the window: the full box test, filter, ids, low corner of the intersection in this sector -- every lane busy
+              // (Resolving ACROSS sectors -- a sector only notes its three to five touching pairs, one resolve per wave from the records in the
+              //  bins -- was built and measured: same pairs, no gain; that resolve's global loads stand exposed at the end of the wave's run.
+              //  profiles/r04/ab_deferred_resolve_lost.log)
               __builtin_amdgcn_wave_barrier();
 #ifdef SC_DIAG_NORESOLVE
               cnt = 0;                                            // diagnostic build: what the sweeps alone cost (no pairs reported)
