@@ -18,6 +18,9 @@ namespace sctick {
 // The pair role is bound by instruction issue and LDS latency: five waves per SIMD hide it measurably better than four
 // (config 5: 66 -> 55 us for the end-of-tick kernel).  Its rarely entered overflow phase would push the allocation to 107
 // VGPRs (four waves); held to five waves the compiler spills eight dwords instead, on that rare path.
+#ifndef SC_XFORM_OCC
+#define SC_XFORM_OCC      // (an occupancy attribute for the fused kernel, for experiments: seven and eight waves per SIMD by force both lost -- profiles/r03/ab_eight_waves.log, profiles/r04/ab_fused_kernel_slp_fma.log)
+#endif
 #ifndef SC_PAIR_OCC
 #define SC_PAIR_OCC __attribute__((amdgpu_waves_per_eu(5, 5)))
 #endif
@@ -522,7 +525,7 @@ template <bool kCull, bool kAabb, uint32_t kChain, uint32_t kHome>
 __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p);
 
 template <bool kCull, bool kAabb, uint32_t kChain, uint32_t kHome>
-__global__ __launch_bounds__(kTile) void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, kChain, kHome>(d, p); }
+__global__ __launch_bounds__(kTile) SC_XFORM_OCC void k_xform_cull(const DeviceState d, const TickParams p) { xformCullBody<kCull, kAabb, kChain, kHome>(d, p); }
 
 template <bool kCull, bool kAabb, uint32_t kChain, uint32_t kHome>
 __device__ __forceinline__ void xformCullBody(const DeviceState& d, const TickParams& p)
