@@ -567,6 +567,9 @@ int scTickQueryOccupied(ScTickContext* ctx, uint32_t count, const float* pos3, c
 /* record HIP events around the kernel launches (on the context's stream) of every `enable`-th tick
  * from now on (1 = every tick; event records cost host time, so long runs sample); 0 = stop */
 int scTickSetProfiling(ScTickContext* ctx, int enable);
+/* ... and only around the kernels of `mask` (bit SC_TICK_K_*; 0 = all, the default).  Timing a launch by events costs ~6 us of gap on the
+ * queue: a run that is itself being timed samples the dominant kernel alone. */
+int scTickSetProfilingKernels(ScTickContext* ctx, uint32_t mask);
 /* durations (ms) of the launches of `kernel` recorded since profiling was enabled; synchronises */
 int scTickGetKernelTimes(ScTickContext* ctx, uint32_t kernel, float* ms, uint32_t capacity, uint32_t* count);
 /* capture the current stage sequence into a hipGraph and replay it on scTickRun (0 = eager launches).  scTickTileStep on

@@ -172,6 +172,7 @@ SYMBOLS = {
     "scTickReadRayHits": (C.c_int, [_CTX, C.POINTER(RayHit), C.c_uint32, U32P]),
     "scTickQueryOccupied": (C.c_int, [_CTX, C.c_uint32, F32P, F32P, U32P, U8P]),
     "scTickSetProfiling": (C.c_int, [_CTX, C.c_int]),
+    "scTickSetProfilingKernels": (C.c_int, [_CTX, C.c_uint32]),
     "scTickGetKernelTimes": (C.c_int, [_CTX, C.c_uint32, F32P, C.c_uint32, U32P]),
     "scTickSetGraphMode": (C.c_int, [_CTX, C.c_int]),
     "scTickGetStream": (C.c_void_p, [_CTX]),

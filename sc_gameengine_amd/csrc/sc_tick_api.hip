@@ -81,6 +81,7 @@ struct ScTickContext
   // profiling
   bool profiling = false;
   uint32_t profPeriod = 1;     // record events on every profPeriod-th tick only (event records are not free)
+  uint32_t profMask = 0xFFFFFFFFu;   // ... and only around these kernels (bit SC_TICK_K_*; scTickSetProfilingKernels)
   uint64_t tickIndex = 0;
   std::vector<EventPair> times[SC_TICK_K_COUNT];
   std::vector<EventPair> eventPool;
@@ -417,7 +418,7 @@ EventPair takeEvents(ScTickContext* c)
 struct Scoped
 {
   ScTickContext* c; uint32_t k; EventPair p; bool on;
-  Scoped(ScTickContext* c_, uint32_t k_) : c(c_), k(k_), on(c_->profiling && (c_->tickIndex % c_->profPeriod) == 0)
+  Scoped(ScTickContext* c_, uint32_t k_) : c(c_), k(k_), on(c_->profiling && ((c_->profMask >> k_) & 1u) && (c_->tickIndex % c_->profPeriod) == 0)
   {
     if (on) { p = takeEvents(c); hipEventRecord(p.a, c->stream); }
   }
@@ -526,7 +527,7 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
   }
   if (flags & (SC_TICK_XFORM | SC_TICK_CULL | SC_TICK_BROADPHASE)) {
     // the dominant kernel is timed by its own begin / end timestamps (the figure the roofline uses)
-    if (c->profiling && (c->tickIndex % c->profPeriod) == 0) {
+    if (c->profiling && (c->profMask & (1u << SC_TICK_K_XFORM_CULL)) && (c->tickIndex % c->profPeriod) == 0) {
       const EventPair ev = takeEvents(c);
       launchXformCull(ds, p, grid, c->stream, ev.a, ev.b);
       c->times[SC_TICK_K_XFORM_CULL].push_back(ev);
@@ -589,7 +590,7 @@ void enqueueStages(ScTickContext* c, const TickParams& p, uint32_t grid, bool al
     }
     // both depend only on the fused kernel: one launch, workgroups split by role (timed as K_PAIRS, by the dispatch's own
     // begin / end timestamps like the fused kernel: no marker packets on the queue)
-    if (c->profiling && (c->tickIndex % c->profPeriod) == 0) {
+    if (c->profiling && (c->profMask & (1u << SC_TICK_K_PAIRS)) && (c->tickIndex % c->profPeriod) == 0) {
       const EventPair ev = takeEvents(c);
       launchCompactPairs(ds, pe, grid, c->stream, ev.a, ev.b);
       c->times[SC_TICK_K_PAIRS].push_back(ev);
@@ -1977,6 +1978,13 @@ int scTickQueryOccupied(ScTickContext* c, uint32_t count, const float* pos3, con
   launchOccupancy(c->d, c->n, dq, count, bits, c->stream);
   if (!d2h(c, out, bits, sizeof out) || !sync(c)) return 0;
   for (uint32_t k = 0; k < count; ++k) blocked[k] = (uint8_t)((out[k >> 5] >> (k & 31u)) & 1u);
+  return 1;
+}
+
+int scTickSetProfilingKernels(ScTickContext* c, uint32_t mask)
+{
+  if (!c) return 0;
+  c->profMask = mask ? mask : 0xFFFFFFFFu;
   return 1;
 }
 

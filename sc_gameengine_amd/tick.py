@@ -462,6 +462,11 @@ class WorldTick:
         """0 = off, n = record HIP events on every n-th tick"""
         self._ok(self.lib.scTickSetProfiling(self.ctx, int(period)), "scTickSetProfiling")
 
+    def set_profiling_kernels(self, kernels=None):
+        """time only these kernels (capi.K_* indices; None = all): a launch timed by events costs ~6 us of gap on its queue"""
+        mask = 0 if kernels is None else sum(1 << int(k) for k in kernels)
+        self._ok(self.lib.scTickSetProfilingKernels(self.ctx, mask), "scTickSetProfilingKernels")
+
     def set_graph_mode(self, on):
         self._ok(self.lib.scTickSetGraphMode(self.ctx, 1 if on else 0), "scTickSetGraphMode")
 
