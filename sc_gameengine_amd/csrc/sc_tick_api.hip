@@ -241,8 +241,6 @@ bool d2h(ScTickContext* c, void* dst, const void* src, size_t bytes)
 }
 bool sync(ScTickContext* c)
 {
-  static const bool spin = std::getenv("SC_TICK_SPIN_SYNC") != nullptr;       // (experiment: poll the stream instead of the runtime's wait)
-  if (spin) { while (hipStreamQuery(c->stream) == hipErrorNotReady) {} (void)hipGetLastError(); }
   hipError_t e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) return fail(c, "hipStreamSynchronize", e);
   if (c->pairsStream) {                       // pipelined tiles: the pair search half runs on its own stream
