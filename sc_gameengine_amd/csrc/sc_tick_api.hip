@@ -1475,7 +1475,7 @@ static int runPendingPairs(ScTickContext* c, bool withExchange)
       HIP_OK(c, hipEventRecord(c->pairsDone[q], ps));
     } else {
       // a sampled tick times its pair chain too (exchange + merge + queries + pair search, on the pairs stream): SC_TICK_K_PAIRS
-      EventPair ev; const bool timed = c->profiling && c->lastTickSampled;
+      EventPair ev; const bool timed = c->profiling && c->lastTickSampled && (c->profMask & (1u << SC_TICK_K_PAIRS));
       if (timed) { ev = takeEvents(c); hipEventRecord(ev.a, ps); }
       if (withExchange && !exchangeBorders(c, q, ps, false)) return 0;
       const bool rides = enqueuePairHalf(c, pp, ps, (c->variant & 4u) ? nullptr : c->pairsDone[q]);
