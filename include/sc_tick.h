@@ -280,6 +280,8 @@ int scTickGatherVisibleCounts(ScTickContext* ctx, uint32_t* counts_out, uint32_t
  * (nor, on a tile, of the declared world vocabulary) admit a pair, so the pair role was launched as a sweep over the bins' counters
  * (a quarter of the workgroups; a launch shape, never a shortcut of the search), [3] learn ticks so far.  Reads the slots back (a few MB): not for the frame loop. */
 int scTickGetBinStats(ScTickContext* ctx, uint32_t stats[4]);
+/* stats[3] of the above alone: learn ticks so far.  Host-side, no read-back, no synchronisation (what a timed loop may ask). */
+int scTickGetLearnTicks(ScTickContext* ctx, uint32_t* learn_ticks);
 /* The layer VOCABULARY of the tiled world: the OR of the group words and the OR of the mask words of every collider that exists on
  * ANY tile, now or later (until the next call; bits 0..15, or 0xFFFFFFFF = all, as scTickUploadLayers).  With it a pipelined tile
  * (scTickSetPipelined / scTickSetPairsStream) leaves the bins unwritten whose own records can meet nothing the world contains --

@@ -129,6 +129,7 @@ SYMBOLS = {
     "scTickGetCommInfo": (C.c_int, [_CTX, C.POINTER(CommInfo)]),
     "scTickGatherVisibleCounts": (C.c_int, [_CTX, U32P, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "scTickGetBinStats": (C.c_int, [_CTX, U32P]),
+    "scTickGetLearnTicks": (C.c_int, [_CTX, U32P]),
     "scTickSetWorldLayers": (C.c_int, [_CTX, C.c_uint32, C.c_uint32, C.c_int]),
     "scTickResetHostTimes": (C.c_int, [_CTX]),
     "scTickTileStep": (C.c_int, [_CTX, C.c_uint32]),

@@ -2365,6 +2365,13 @@ int scTickSetWorldLayers(ScTickContext* c, uint32_t groupOr, uint32_t maskOr, in
   return 1;
 }
 
+int scTickGetLearnTicks(ScTickContext* c, uint32_t* learn_ticks)
+{
+  if (!c || !learn_ticks) return c ? fail(c, "null argument") : 0;
+  *learn_ticks = c->learnTicks;            // (host-side: no read-back, no synchronisation)
+  return 1;
+}
+
 int scTickGetBinStats(ScTickContext* c, uint32_t stats[4])
 {
   if (!c || !stats) return c ? fail(c, "null argument") : 0;

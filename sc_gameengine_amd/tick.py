@@ -444,6 +444,12 @@ class WorldTick:
         return {"remembered_slots": int(st[0]), "written_every_tick": int(st[1]), "lazy_last_tick": bool(st[2] & 1),
                 "unchanged_records_stay": bool(st[2] & 2), "pair_role_sweep_only": bool(st[2] & 4), "learn_ticks": int(st[3])}
 
+    def learn_ticks(self):
+        """learn ticks so far (host-side counter: no read-back)"""
+        st = np.zeros(1, np.uint32)
+        self._ok(self.lib.scTickGetLearnTicks(self.ctx, _u(st)), "scTickGetLearnTicks")
+        return int(st[0])
+
     def reset_host_times(self):
         self._ok(self.lib.scTickResetHostTimes(self.ctx), "scTickResetHostTimes")
 
