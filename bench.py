@@ -309,6 +309,24 @@ def end_of_tick_line(w, workload, SX, SZ, counts, kp_ms, stages, kind):
     return eot_ms, eot_bytes, eot_achieved
 
 
+DEVICE_WAKE_MS = float(os.environ.get("SC_BENCH_WAKE_MS", "20"))
+
+
+def device_wake(torch, device_index):
+    """Neutral device activity (fills of a 64 MB buffer, DEVICE_WAKE_MS long) right ahead of the W warm-up steps.  A run of W + K = 25 steps
+    lasts a millisecond and starts on a device that idled for seconds while the world was built on the CPU: its first steps run at idle
+    clocks (first fused kernel 30.7-31.4 us against 28.5 in steady state; 20 steps 40.9-42.4 us per step without this, 40.1-40.5 with it,
+    200 steps unchanged).  Not a step, not inside the timed region, and stated in the line (config.device_wake_ms); SC_BENCH_WAKE_MS=0 turns it off."""
+    if DEVICE_WAKE_MS <= 0:
+        return
+    buf = torch.empty(64 << 20, dtype=torch.uint8, device=f"cuda:{device_index}")
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < DEVICE_WAKE_MS:
+        buf.zero_()
+        torch.cuda.synchronize()
+    del buf
+
+
 def secondary_leg(args, workload, device, steps=20, warmup=5):
     """The workloads whose pair search really searches, under the driver's clock: the same tick on a
     config3dyn / config 5 world of the same size -- `steps` timed steps bracketed by synchronisation, then as many with every
@@ -328,6 +346,7 @@ def secondary_leg(args, workload, device, steps=20, warmup=5):
     (t.advance_movers if kind == 2 else t.nudge_roots_x)(param)
     flags = capi.FULL | capi.PRODUCE_NEXT
     ticks = 0
+    device_wake(torch, device)
     for _ in range(warmup):
         t.run(flags); ticks += 1
     t.sync(); torch.cuda.synchronize()
@@ -497,6 +516,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    device_wake(torch, local_rank)
     for _ in range(args.warmup):
         step()
     fence()
@@ -690,6 +710,8 @@ def main():
                 "resident": "device SoA authoritative; no per-step host transfer",
                 "control_plane": args.control if world_size > 1 else None,
                 "rehearsal_same_device": bool(args.same_device),
+                # neutral device activity right ahead of the W warm-up steps, in ms (device_wake(): the device idled while the world was built)
+                "device_wake_ms": DEVICE_WAKE_MS,
                 # the bins' remembered slots are relearned every `period` broadphase ticks (SC_TICK_HOME_PERIOD, default 64): that tick
                 # reserves every slot with atomics again and runs two or three small kernels behind the fused one (slot counts, the
                 # bins' cast-first order where the pair search takes fast sectors, the slots' flags)
