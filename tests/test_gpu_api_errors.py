@@ -5,8 +5,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from sc_gameengine_amd import capi
-from sc_gameengine_amd.tick import WorldTick
+from sc_gameengine_amd import capi, synth_world as sw
+from sc_gameengine_amd.tick import WorldTick, camera_view_proj
 from tests import worlds
 
 pytestmark = pytest.mark.gpu
@@ -77,4 +77,30 @@ def test_split_pairs_protocol_is_enforced():
     t.run_pairs()
     got, total = t.pairs()
     assert total == len(got)
+    t.close()
+
+
+def test_profiling_samples_only_the_kernels_asked_for_and_learn_ticks_is_a_host_counter():
+    """scTickSetProfiling(n) times every n-th tick's launches by events; scTickSetProfilingKernels narrows that to some kernels (what a
+    run that is itself being timed uses: a timed launch costs its queue a few microseconds); scTickGetLearnTicks is scTickGetBinStats'
+    learn-tick count without the read-back."""
+    w = sw.generate(8, 8, 15)
+    t = WorldTick.from_world(w, broadphase=True)
+    t.set_view_proj(camera_view_proj(w.camera))
+    flags = capi.FULL
+    t.set_profiling_kernels([capi.K_XFORM_CULL])
+    t.set_profiling(2)
+    for _ in range(6):
+        t.run(flags)
+    t.sync()
+    assert len(t.kernel_times_ms(capi.K_XFORM_CULL)) == 3 and len(t.kernel_times_ms(capi.K_PAIRS)) == 0
+    t.set_profiling_kernels(None)
+    t.set_profiling(1)
+    for _ in range(4):
+        t.run(flags)
+    t.sync()
+    k1, kp = t.kernel_times_ms(capi.K_XFORM_CULL), t.kernel_times_ms(capi.K_PAIRS)
+    assert len(k1) == 4 and len(kp) == 4 and all(x > 0 for x in list(k1) + list(kp))
+    t.set_profiling(0)
+    assert t.learn_ticks() == t.bin_stats()["learn_ticks"] >= 1
     t.close()
